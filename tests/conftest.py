@@ -1,0 +1,47 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def refvec():
+    with open(os.path.join(GOLDEN, "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def glvec():
+    with open(os.path.join(GOLDEN, "goldilocks_derived.json")) as f:
+        return json.load(f)
+
+
+def splitmix_field(seed, n, p=0xFFFFFFFF00000001):
+    """i.i.d. uniform on [0,p) by rejection from SplitMix64 (numpy, vectorised)."""
+    import numpy as np
+    out = np.empty(0, dtype=np.uint64)
+    state = np.uint64(seed)
+    with np.errstate(over="ignore"):
+        while out.size < n:
+            m = max(1024, int((n - out.size) * 1.01) + 16)
+            idx = np.arange(1, m + 1, dtype=np.uint64)
+            z = state + idx * np.uint64(0x9E3779B97F4A7C15)
+            state = z[-1]
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            if p < (1 << 62):
+                z = z % np.uint64(p)  # small test fields: reduce instead of rejecting
+            out = np.concatenate([out, z[z < np.uint64(p)]])
+    return out[:n].copy()

@@ -1,0 +1,182 @@
+"""Pin the CPU oracle on every golden vector the reference's own tests hold for the path
+(SURVEY.md section 8c), plus first-principles Goldilocks vectors.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from oracle import OraclePanic
+
+GP, GG = orc.GOLDILOCKS_P, orc.GOLDILOCKS_G
+
+
+def gen(p):
+    return orc.find_primitive_element(p)
+
+
+def test_field_kats(refvec):
+    for p, a, b, r in refvec["field_add"]["cases"]:
+        assert orc.add(p, orc.new(p, a), orc.new(p, b)) == r
+    for p, a, b, r in refvec["field_sub"]["cases"]:
+        assert orc.sub(p, orc.new(p, a), orc.new(p, b)) == r
+    for p, a, b, r in refvec["field_mul"]["cases"]:
+        assert orc.mul(p, a, b) == r
+    for p, a, e, r in refvec["field_pow"]["cases"]:
+        assert orc.pow_(p, a, e) == r
+    for p, a, r in refvec["field_inverse"]["cases"]:
+        assert orc.inverse(p, a) == r
+        assert orc.mul(p, orc.inverse(p, a), a) == 1
+    for p, a in refvec["field_inverse"]["panics"]:
+        with pytest.raises(OraclePanic):
+            orc.inverse(p, a)
+    for p, a, r in refvec["field_halve"]["cases"]:
+        assert orc.div(p, a, 2) == r
+
+
+def test_prime_and_generator(refvec):
+    assert not orc.is_prime(refvec["non_prime_panics"]["p"])
+    for p in refvec["generator"]["primes"]:
+        assert orc.is_prime(p)
+        g = gen(p)
+        val, counter = g, 1
+        while val != 1:
+            val = orc.mul(p, val, g)
+            counter += 1
+        assert counter == p - 1
+    # the heuristic gives 2 / 14 / 3 and a NON-generator 3 for Goldilocks
+    assert [gen(101), gen(17), gen(127), gen(GP)] == [2, 14, 3, 3]
+    assert orc.pow_(GP, 3, (GP - 1) // 2) == 1          # 3 is a quadratic residue
+    assert orc.pow_(GP, 7, (GP - 1) // 2) == GP - 1     # 7 is not
+    assert orc.is_prime(GP)
+
+
+def test_field_exhaustive_identities():
+    # prime/mod.rs:346-384, prime/arithmetic.rs:221-236
+    for p in (17, 101):
+        for i in range(p):
+            assert orc.add(p, i, 0) == i and orc.mul(p, i, 1) == i and orc.mul(p, i, 0) == 0
+            assert orc.add(p, i, orc.neg(p, i)) == 0
+            if i:
+                assert orc.inverse(p, orc.inverse(p, i)) == i
+        assert orc.new(p, p) == 0 and orc.new(p, 0) == 0
+
+
+def test_roots(refvec):
+    for p, n in refvec["no_root"]["cases"]:
+        with pytest.raises(OraclePanic) as e:
+            orc.primitive_root_of_unity(p, gen(p), n)
+        assert e.value.code == -1
+        with pytest.raises(OraclePanic):
+            orc.dft(p, gen(p), [1, 2, 3])
+    for p, n, w in refvec["roots_of_unity"]["cases"]:
+        assert orc.primitive_root_of_unity(p, gen(p), n) == w
+
+
+def test_polynomial_kats(refvec):
+    v = refvec
+    for p, c, x, y in v["poly_eval"]["cases"]:
+        assert orc.poly_eval(p, c, x) == y
+    d = v["poly_dft"]
+    assert orc.dft(d["p"], gen(d["p"]), d["in"]).tolist() == d["out"]
+    d = v["poly_fft"]
+    assert orc.fft(d["p"], gen(d["p"]), d["in"]).tolist() == d["out"]
+    d = v["poly_ifft_roundtrip"]
+    g = gen(d["p"])
+    assert orc.ifft(d["p"], g, orc.fft(d["p"], g, d["in"])).tolist() == d["in"]
+    d = v["lagrange_eval"]
+    g = gen(d["p"])
+    assert orc.lagrange_eval(d["p"], orc.dft(d["p"], g, d["coeffs"]), orc.lagrange_nodes(d["p"], g, 4), d["x"]) == d["y"]
+    assert orc.degree(v["degree"]["c"]) == v["degree"]["degree"]
+    assert orc.leading_coefficient(v["leading_coefficient"]["c"]) == v["leading_coefficient"]["lc"]
+    d = v["pow_mult"]
+    assert orc.pow_mult(d["p"], d["c"], d["d2"], d["coeff"]).tolist() == d["out"]
+    d = v["poly_add"]
+    assert orc.poly_add(d["p"], d["a"], d["b"]).tolist() == d["out"]
+    for a, b, r in v["poly_sub"]["cases"]:
+        assert orc.poly_sub(101, a, b).tolist() == r
+    d = v["poly_neg"]
+    assert orc.poly_neg(d["p"], d["a"]).tolist() == d["out"]
+    for a, b, q in v["poly_div"]["cases"]:
+        assert orc.poly_divrem(101, a, b)[0].tolist() == q
+    for a, b, r in v["poly_rem"]["cases"]:
+        assert orc.poly_divrem(101, a, b)[1].tolist() == r
+    for a, b, c in v["poly_mul"]["cases"]:
+        assert orc.poly_mul(101, a, b).tolist() == c
+
+
+def test_callers(refvec):
+    d = refvec["rs_encode"]
+    xs, ys = orc.rs_encode(d["p"], gen(d["p"]), d["msg"], d["n"])
+    assert xs.tolist() == d["x"] and ys.tolist() == d["y"]
+    # encode IS a size-n DFT of the zero-padded message
+    assert orc.dft(d["p"], gen(d["p"]), orc.poly_from(d["msg"], d["n"])).tolist() == d["y"]
+    xs7, ys7 = orc.rs_encode(127, 3, [1, 2, 3], 7)
+    assert orc.dft(127, 3, orc.poly_from([1, 2, 3], 7)).tolist() == ys7.tolist()
+    d = refvec["kzg_open_quotient"]
+    assert orc.kzg_open_quotient(d["p"], d["coeffs"], d["z"]).tolist() == d["quot"]
+
+
+def test_reference_quirks():
+    # Lagrange evaluate AT a node: the fold's `return c` replaces the accumulator and the product
+    # with l(x) == 0 gives ZERO (polynomial/mod.rs:382-415)
+    nodes = orc.lagrange_nodes(101, 2, 4)
+    assert orc.lagrange_eval(101, [10, 79, 99, 18], nodes, int(nodes[1])) == 0
+    # long division: the loop guard uses the divisor's UNTRIMMED length (mod.rs:186-188)
+    q, r = orc.poly_divrem(101, [1, 2, 3], [1, 1, 0, 0])
+    assert q.tolist() == [0, 0, 0] and r.tolist() == [1, 2, 3]
+    # zero divisor: rposition(..).unwrap() panics
+    with pytest.raises(OraclePanic):
+        orc.poly_divrem(101, [1, 2, 3], [0, 0])
+    # pow(0, 0) == ONE; inverse(0) is None
+    assert orc.pow_(101, 0, 0) == 1
+    # fft on a non power of two is a compile-time error in the reference
+    with pytest.raises(OraclePanic) as e:
+        orc.fft(127, 3, [1, 2, 3])
+    assert e.value.code == -3
+    # power of two that does not divide p-1: 8 over F_101
+    with pytest.raises(OraclePanic) as e:
+        orc.fft(101, 2, list(range(8)))
+    assert e.value.code == -1
+
+
+def test_goldilocks_derived(glvec):
+    v = glvec
+    assert v["p"] == GP
+    for k, w in v["roots"].items():
+        assert orc.primitive_root_of_unity(GP, GG, 1 << int(k)) == w
+    for k, ni in v["n_inverse"].items():
+        assert orc.inverse(GP, 1 << int(k)) == ni
+    assert orc.fft(GP, GG, [1, 2, 3, 4]).tolist() == v["dft_1234"]
+    for case in v["dft_random"]:
+        assert orc.dft(GP, GG, case["in"]).tolist() == case["out"]
+        assert orc.fft(GP, GG, case["in"]).tolist() == case["out"]
+        assert orc.ifft(GP, GG, case["out"]).tolist() == case["in"]
+    for case in v["dft_non_pow2"]:
+        assert orc.dft(GP, GG, case["in"]).tolist() == case["out"]
+    for case in v["mul_random"]:
+        assert orc.poly_mul(GP, case["a"], case["b"]).tolist() == case["out"]
+    e = v["field_edge"]
+    vals = e["values"]
+    for i, a in enumerate(vals):
+        for j, b in enumerate(vals):
+            assert orc.add(GP, a, b) == e["add"][i][j]
+            assert orc.sub(GP, a, b) == e["sub"][i][j]
+            assert orc.mul(GP, a, b) == e["mul"][i][j]
+        if a:
+            assert orc.inverse(GP, a) == e["inv"][i]
+
+
+def test_self_consistency_large():
+    # dft == fft == definition on moderately large n; ifft(fft) == id at 2^16 (config 2)
+    from conftest import splitmix_field
+    x = splitmix_field(0x5EED0002, 1 << 10)
+    assert np.array_equal(orc.dft(GP, GG, x), orc.fft(GP, GG, x))
+    x = splitmix_field(0x5EED0002, 1 << 16)
+    assert np.array_equal(orc.ifft(GP, GG, orc.fft(GP, GG, x)), x)
+    # NTT-multiply == schoolbook (config 1 shape: 17 x 17 over F_101 is schoolbook only)
+    a = splitmix_field(1, 17, 101); b = splitmix_field(2, 17, 101)
+    c = orc.poly_mul(101, a, b)
+    assert c.size == 33
+    a = splitmix_field(3, 100); b = splitmix_field(4, 157)
+    fa = orc.fft(GP, GG, orc.poly_from(a, 256)); fb = orc.fft(GP, GG, orc.poly_from(b, 256))
+    c = orc.ifft(GP, GG, orc.vec_mul(GP, fa, fb))
+    assert np.array_equal(c[:256], orc.poly_mul(GP, a, b))
