@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: forward NTTs/s at degree 2^22 over the 64-bit Goldilocks prime.
+
+python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one forward 2^22-point NTT (natural order in/out, device resident, synthetic uniform
+coefficients).  With N ranks every rank transforms its own polynomials (the path shards by
+polynomial, no data-path collective): weak scaling, value = N*K / max-over-ranks time.
+Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Other workloads (--workload): batch16 (1024 x 2^16), mul22 (polynomial multiply, NTT size 2^22),
+roundtrip16 (fwd+inv 2^16), fourstep (sharded four-step NTT with an RCCL all-to-all, N >= 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synth(n, seed):
+    """i.i.d. uniform on [0, p), as int64-viewable uint64"""
+    rng = np.random.default_rng(seed)
+    P = np.uint64(0xFFFFFFFF00000001)
+    x = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    bad = x >= P
+    while bad.any():
+        x[bad] = rng.integers(0, 2**64, size=int(bad.sum()), dtype=np.uint64)
+        bad = x >= P
+    return x
+
+
+def cpu_baseline(log2n, budget_s=12.0):
+    """oracle (port of the reference's recursive fft, polynomial/mod.rs:295-323) on one host core"""
+    import oracle as orc
+    n = 1 << log2n
+    x = synth(n, 99)
+    w = orc.primitive_root_of_unity(orc.GOLDILOCKS_P, orc.GOLDILOCKS_G, n)  # root excluded from the timed region
+    reps, t = 0, 0.0
+    while True:
+        v = x.copy()
+        t0 = time.perf_counter()
+        orc.fft_recursive_inplace(orc.GOLDILOCKS_P, v, w)
+        t += time.perf_counter() - t0
+        reps += 1
+        if t > budget_s or reps >= 8:
+            break
+    return {"value": reps / t, "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": "%d forward 2^%d NTTs, recursive even/odd algorithm of the reference restated in C, 1 thread" % (reps, log2n),
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="ntt22")
+    ap.add_argument("--log2n", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import ronkathon_amd as R
+    from ronkathon_amd import _lib as L
+    P, G = R.GOLDILOCKS_P, R.GOLDILOCKS_G
+
+    wl = args.workload
+    if wl == "fourstep":
+        from ronkathon_amd import dist as rdist
+        res = rdist.bench_fourstep(args.log2n or 26, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(res))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16}[wl]
+    batch = 1024 if wl == "batch16" else 1
+    n = 1 << log2n
+    stream = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(synth(n * batch, 0x5EED0000 + rank).view(np.int64)).cuda()
+    y = torch.empty_like(x)
+    plan = L.Plan(P, G, log2n, batch, local_rank)
+    if wl == "mul22":
+        b = torch.from_numpy(synth(n // 2, 0x5EED1000 + rank).view(np.int64)).cuda()
+        a = x[: n // 2].contiguous()
+        out = torch.empty(n - 1, dtype=torch.int64, device="cuda")
+
+    def step():
+        if wl == "mul22":
+            L.check(L.lib.ronk_poly_mul_dev(P, G, a.data_ptr(), n // 2, b.data_ptr(), n // 2, out.data_ptr(), stream))
+        elif wl == "roundtrip16":
+            plan.forward_dev(x.data_ptr(), y.data_ptr(), stream)
+            plan.inverse_dev(y.data_ptr(), y.data_ptr(), stream)
+        else:
+            plan.forward_dev(x.data_ptr(), y.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    units_per_step = batch if wl != "roundtrip16" else 1
+    value = world * args.steps * units_per_step / dt
+
+    # per-kernel device time (hipEvents on the launch stream) for the roofline of the dominant kernel
+    pass_ms = None
+    if wl in ("ntt22", "batch16"):
+        pass_ms = plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
+    ntts_per_step = {"ntt22": 1, "batch16": batch, "mul22": 3, "roundtrip16": 2}[wl]
+    alg_bytes_step = 16.0 * n * ntts_per_step                       # 16*n bytes per n-point NTT
+    step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
+    achieved = alg_bytes_step / step_s / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes()),
+                "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
+                "pass_us": [m * 1e3 for m in pass_ms] if pass_ms else None}
+
+    if rank == 0:
+        res = {"metric": "forward NTTs/s, degree 2^%d, 64-bit Goldilocks prime" % log2n if wl == "ntt22" else wl,
+               "value": value, "unit": "NTT/s" if wl in ("ntt22", "batch16") else "op/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "forward NTT, n = 2^%d, batch %d, p = 2^64 - 2^32 + 1, natural order in/out, device resident"
+                          % (log2n, batch) if wl in ("ntt22", "batch16") else wl,
+                          "log2n": log2n, "batch": batch, "parallelism": "independent polynomials per GPU (x%d)" % world},
+               "roofline": roofline}
+        if not args.no_cpu and wl == "ntt22":
+            res["cpu_baseline"] = cpu_baseline(log2n)
+        print(json.dumps(res))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * ronk_ntt.h -- C ABI of libronk_ntt.so, the MI355X-native (gfx950, hand-written HIP)
+ * finite-field / NTT / polynomial engine that sits behind ronkathon's
+ * `Polynomial<B, F, D>` + `Field` / `FiniteField` trait surface.
+ *
+ * ronkathon (Rust) has no FFI of its own: the seam is its generic trait surface.  Each
+ * entry point below states which reference item it replaces (paths relative to the
+ * ronkathon repository).  INTEGRATION.md shows the Rust `extern "C"` block and the trait
+ * impls a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - every field element is a canonical residue in [0, p) stored as uint64_t -- exactly what
+ *    `PrimeField<P>{ value: usize }` holds (src/algebra/field/prime/mod.rs:39-42); Montgomery
+ *    form never crosses this boundary;
+ *  - transforms are natural order in, natural order out, with omega = g^((p-1)/n)
+ *    (src/algebra/field/mod.rs:70-75, src/polynomial/mod.rs:240-323);
+ *  - buffers are caller-owned, no ownership transfer, no callbacks; functions without a
+ *    `_dev` suffix take HOST pointers (and stage through HBM), `_dev` functions take DEVICE
+ *    pointers and enqueue on `stream` (a hipStream_t, NULL = the null stream) without
+ *    synchronising;
+ *  - the reference reports errors by panicking; here every function returns 0 or a negative
+ *    RONK_ERR_* code, and the Rust shim turns a non-zero code back into the same panic;
+ *  - re-entrant: plans are immutable after creation; concurrent calls on ONE plan must use
+ *    different streams only if they do not share the plan's scratch buffer (see
+ *    ronk_plan_create).
+ *  - the 64-bit hot path is the Goldilocks field p = 2^64 - 2^32 + 1 with generator g = 7;
+ *    any other odd prime p < 2^64 (e.g. the reference's F_101, F_17, F_127) runs through a
+ *    generic Montgomery path so that the reference's own test vectors pass on the GPU.
+ *  - there is NO CPU fallback: without a HIP device every compute entry point returns
+ *    RONK_ERR_NO_DEVICE.
+ */
+#ifndef RONK_NTT_H
+#define RONK_NTT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RONK_GOLDILOCKS_P 0xFFFFFFFF00000001ull
+#define RONK_GOLDILOCKS_G 7ull
+
+/* error codes; messages via ronk_strerror() repeat the reference's panic texts */
+#define RONK_OK 0
+#define RONK_ERR_NO_ROOT (-1)       /* assert!(p_minus_one % n == 0, "n must divide p^q - 1"), field/mod.rs:72; polynomial/mod.rs:361 */
+#define RONK_ERR_ZERO_INVERSE (-2)  /* inverse().unwrap() on ZERO, prime/arithmetic.rs:54, polynomial/mod.rs:196 */
+#define RONK_ERR_NOT_POW2 (-3)      /* fft()/ifft() bound `D.is_power_of_two()`, polynomial/mod.rs:274, :431 */
+#define RONK_ERR_NOT_PRIME (-4)     /* is_prime() panic "input is not a prime number", prime/mod.rs:92-100 */
+#define RONK_ERR_NO_GENERATOR (-5)  /* find_primitive_element panic, prime/mod.rs:122 */
+#define RONK_ERR_INDEX (-6)         /* slice index / unwrap-on-None panics (zero divisor, ragged division) */
+#define RONK_ERR_INVALID (-7)       /* NULL pointer, zero length, bad plan */
+#define RONK_ERR_HIP (-8)           /* a HIP runtime call failed; ronk_last_hip_error() has the text */
+#define RONK_ERR_UNSUPPORTED (-9)   /* size outside what the kernels cover (stated per function) */
+#define RONK_ERR_NO_DEVICE (-10)    /* no HIP device: the library never computes on the CPU */
+
+const char* ronk_strerror(int code);
+const char* ronk_last_hip_error(void);
+int ronk_device_count(int* count);
+
+/* ---- field: src/algebra/field/mod.rs:17-76, src/algebra/field/prime/{mod,arithmetic}.rs ---- */
+
+/* FiniteField::PRIMITIVE_ELEMENT (prime/mod.rs:87-90, :110-123): the reference's heuristic for
+ * small primes, the explicit generator 7 for Goldilocks (the heuristic returns a non-generator
+ * there).  Host-side integer logic, no device work. */
+int ronk_primitive_element(uint64_t p, uint64_t* g);
+/* FiniteField::primitive_root_of_unity(n) (field/mod.rs:70-75) */
+int ronk_root_of_unity(uint64_t p, uint64_t g, uint64_t n, uint64_t* out);
+/* PrimeField::new's primality assertion (prime/mod.rs:48-51, :92-100): 0 or RONK_ERR_NOT_PRIME */
+int ronk_check_prime(uint64_t p);
+
+/* Element-wise Field operators over arrays (Add/Sub/Mul/Neg, prime/arithmetic.rs:3-65;
+ * Field::inverse prime/mod.rs:62-72 -> RONK_ERR_ZERO_INVERSE if any a[i] == 0;
+ * Field::pow prime/mod.rs:74-84).  These are also what Polynomial Add/Sub/Neg reduce to. */
+int ronk_vec_add(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int ronk_vec_sub(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int ronk_vec_mul(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int ronk_vec_neg(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
+int ronk_vec_inv(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
+int ronk_vec_pow(uint64_t p, const uint64_t* a, uint64_t e, uint64_t* out, size_t n);
+int ronk_vec_add_dev(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int ronk_vec_sub_dev(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int ronk_vec_mul_dev(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+
+/* ---- transforms: src/polynomial/mod.rs ---- */
+
+typedef struct ronk_plan ronk_plan;
+
+/* A plan fixes (p, g, n = 2^log2n, batch) on one device: twiddle tables in HBM, the pass
+ * decomposition, and a scratch buffer of batch*n elements.  `batch` polynomials are stored
+ * back to back ([batch][n], row-major).  device < 0 = current device.
+ * Errors: RONK_ERR_NO_ROOT if 2^log2n does not divide p-1; RONK_ERR_NOT_PRIME. */
+int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device);
+int ronk_plan_destroy(ronk_plan* plan);
+
+/* Polynomial::<Monomial,F,D>::fft() (polynomial/mod.rs:273-323; same values as dft() :240-258).
+ * `nodes`, if non-NULL, receives Lagrange::nodes = [omega^i] (mod.rs:358-365), n elements. */
+int ronk_ntt_forward(ronk_plan* plan, const uint64_t* in, uint64_t* out, uint64_t* nodes);
+/* Polynomial::<Lagrange<F>,F,D>::ifft() (polynomial/mod.rs:430-484), includes the D^-1 scale */
+int ronk_ntt_inverse(ronk_plan* plan, const uint64_t* in, uint64_t* out);
+/* device-resident forms; in == out is allowed; asynchronous on `stream` */
+int ronk_ntt_forward_dev(ronk_plan* plan, const uint64_t* d_in, uint64_t* d_out, void* stream);
+int ronk_ntt_inverse_dev(ronk_plan* plan, const uint64_t* d_in, uint64_t* d_out, void* stream);
+/* Lagrange::<F>::new's node table [omega^i], i < n (polynomial/mod.rs:358-365) */
+int ronk_lagrange_nodes(uint64_t p, uint64_t g, uint64_t* nodes, size_t n);
+
+/* Polynomial::dft() for ANY n dividing p-1 (polynomial/mod.rs:240-258), e.g. n = 3, 5, 7, 25.
+ * Direct O(n^2) kernel; power-of-two n >= 16 over Goldilocks is routed to the NTT. n <= 2^16. */
+int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n);
+
+/* plan introspection for benchmarks: number of kernel launches per transform, and the
+ * average device time of each launch over `iters` forward (inverse != 0: inverse) transforms
+ * measured with hipEvents on `stream`.  ms must hold ronk_plan_num_passes() floats. */
+int ronk_plan_num_passes(const ronk_plan* plan);
+int ronk_plan_time_passes(ronk_plan* plan, const uint64_t* d_in, uint64_t* d_out, int inverse, int iters,
+                          float* ms, void* stream);
+
+/* ---- polynomial arithmetic: src/polynomial/arithmetic.rs ---- */
+
+/* impl Mul (arithmetic.rs:97-119): out has d + d2 - 1 coefficients.  Goldilocks: NTT -> pointwise
+ * -> inverse NTT on the padded size; other primes: schoolbook kernel.  d, d2 >= 1. */
+int ronk_poly_mul(uint64_t p, uint64_t g, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* out);
+int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2,
+                      uint64_t* d_out, void* stream);
+/* impl Add / Sub (arithmetic.rs:16-68): rhs zero-extended or truncated to d = len(lhs) */
+int ronk_poly_add(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* out);
+int ronk_poly_sub(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* out);
+
+/* ---- callers either side of the path ---- */
+
+/* Polynomial::<Monomial>::evaluate (polynomial/mod.rs:133-139): sum c_i x^i */
+int ronk_poly_eval(uint64_t p, const uint64_t* c, size_t d, uint64_t x, uint64_t* out);
+/* quotient_and_remainder (polynomial/mod.rs:170-225) behind impl Div / Rem (arithmetic.rs:121-146);
+ * quot and rem both have d coefficients.  Used by kzg::open (src/kzg/setup.rs:63-78). */
+int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,
+                     uint64_t* rem);
+/* Reed-Solomon Message::encode::<N> (src/codes/reed_solomon.rs:42-52): xs[i] = omega_N^i,
+ * ys[i] = poly(omega_N^i) -- a size-N DFT of the zero-padded K-coefficient message. */
+int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t n, uint64_t* xs, uint64_t* ys);
+
+/* ---- multi-GPU four-step building blocks (one process per GPU; the exchange between the two
+ *      phases is an RCCL all-to-all issued by the host side, see ronkathon_amd/dist.py) ----
+ * n = 2^log2n split as R x C with R = 2^(log2n - log2n/2) rows and C = 2^(log2n/2) columns;
+ * rank `rank` of `world` owns columns [rank*C/world, (rank+1)*C/world) of the R x C input
+ * (layout [R][C/world], row-major) and, after the exchange, rows [rank*R/world, ...) of the
+ * twiddled intermediate (layout [R/world][C]); its output block is X[k1 + R*k2] for its k1
+ * range, laid out [C][R/world] (k2-major). */
+typedef struct ronk_dist_plan ronk_dist_plan;
+int ronk_dist_plan_create(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world, int device);
+int ronk_dist_plan_destroy(ronk_dist_plan* plan);
+/* phase 1: R-point NTTs down the local columns, times omega_n^{c*k1}; output is written as `world`
+ * consecutive send blocks, block h = rows k1 in h's range, layout [R/world][C/world] */
+int ronk_dist_phase1_dev(ronk_dist_plan* plan, const uint64_t* d_in, uint64_t* d_send, void* stream);
+/* phase 2: d_recv holds `world` blocks [R/world][C/world] (block g from rank g); C-point NTTs along
+ * each local row k1; d_out[k2*(R/world) + (k1 - k1_0)] = X[k1 + R*k2] */
+int ronk_dist_phase2_dev(ronk_dist_plan* plan, const uint64_t* d_recv, uint64_t* d_out, void* stream);
+
+/* ---- small device-memory helpers so a non-HIP host (ctypes, cgo, JNI) can stay device-resident ---- */
+int ronk_dev_alloc(void** ptr, size_t bytes);
+int ronk_dev_free(void* ptr);
+int ronk_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int ronk_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ronk_dev_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,160 @@
+"""ctypes binding of ronkathon_amd/libronk_ntt.so (the C ABI in include/ronk_ntt.h).
+
+There is no CPU implementation behind this module: if the shared library is missing it
+raises at import, and without a HIP device every compute call raises RonkPanic(-10).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libronk_ntt.so")
+
+GOLDILOCKS_P = 0xFFFFFFFF00000001
+GOLDILOCKS_G = 7
+
+OK, ERR_NO_ROOT, ERR_ZERO_INVERSE, ERR_NOT_POW2, ERR_NOT_PRIME = 0, -1, -2, -3, -4
+ERR_NO_GENERATOR, ERR_INDEX, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = -5, -6, -7, -8, -9, -10
+
+
+class RonkPanic(Exception):
+    """A non-zero return code: what the reference reports by panicking (same message text)."""
+
+    def __init__(self, code, detail=""):
+        msg = lib.ronk_strerror(code).decode()
+        if code == ERR_HIP:
+            msg += ": " + lib.ronk_last_hip_error().decode()
+        super().__init__(msg + (" " + detail if detail else ""))
+        self.code = code
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "ronkathon_amd: %s not found -- build the HIP extension first (`make` at the repo root or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_u64, _sz, _pu, _vp, _int = C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64), C.c_void_p, C.c_int
+_SIG = {
+    "ronk_strerror": (C.c_char_p, [_int]),
+    "ronk_last_hip_error": (C.c_char_p, []),
+    "ronk_device_count": (_int, [C.POINTER(_int)]),
+    "ronk_primitive_element": (_int, [_u64, _pu]),
+    "ronk_root_of_unity": (_int, [_u64, _u64, _u64, _pu]),
+    "ronk_check_prime": (_int, [_u64]),
+    "ronk_vec_add": (_int, [_u64, _vp, _vp, _vp, _sz]),
+    "ronk_vec_sub": (_int, [_u64, _vp, _vp, _vp, _sz]),
+    "ronk_vec_mul": (_int, [_u64, _vp, _vp, _vp, _sz]),
+    "ronk_vec_neg": (_int, [_u64, _vp, _vp, _sz]),
+    "ronk_vec_inv": (_int, [_u64, _vp, _vp, _sz]),
+    "ronk_vec_pow": (_int, [_u64, _vp, _u64, _vp, _sz]),
+    "ronk_vec_add_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
+    "ronk_vec_sub_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
+    "ronk_vec_mul_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
+    "ronk_plan_create": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int]),
+    "ronk_plan_destroy": (_int, [_vp]),
+    "ronk_ntt_forward": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_ntt_inverse": (_int, [_vp, _vp, _vp]),
+    "ronk_ntt_forward_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_ntt_inverse_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_lagrange_nodes": (_int, [_u64, _u64, _vp, _sz]),
+    "ronk_dft": (_int, [_u64, _u64, _vp, _vp, _sz]),
+    "ronk_plan_num_passes": (_int, [_vp]),
+    "ronk_plan_time_passes": (_int, [_vp, _vp, _vp, _int, _int, C.POINTER(C.c_float), _vp]),
+    "ronk_poly_mul": (_int, [_u64, _u64, _vp, _sz, _vp, _sz, _vp]),
+    "ronk_poly_mul_dev": (_int, [_u64, _u64, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "ronk_poly_add": (_int, [_u64, _vp, _sz, _vp, _sz, _vp]),
+    "ronk_poly_sub": (_int, [_u64, _vp, _sz, _vp, _sz, _vp]),
+    "ronk_poly_eval": (_int, [_u64, _vp, _sz, _u64, _pu]),
+    "ronk_poly_divrem": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),
+    "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
+    "ronk_dist_plan_destroy": (_int, [_vp]),
+    "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_dist_phase2_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_dev_alloc": (_int, [C.POINTER(_vp), _sz]),
+    "ronk_dev_free": (_int, [_vp]),
+    "ronk_memcpy_h2d": (_int, [_vp, _vp, _sz]),
+    "ronk_memcpy_d2h": (_int, [_vp, _vp, _sz]),
+    "ronk_dev_sync": (_int, []),
+}
+for _name, (_res, _args) in _SIG.items():
+    _f = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _f.restype, _f.argtypes = _res, _args
+
+EXPORTS = sorted(_SIG)
+
+
+def check(rc, detail=""):
+    if rc != 0:
+        raise RonkPanic(rc, detail)
+
+
+def device_count():
+    n = _int(0)
+    check(lib.ronk_device_count(C.byref(n)))
+    return n.value
+
+
+def arr(x):
+    """canonical residues as a contiguous numpy uint64 array"""
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+def ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+def out_scalar(fn, *args):
+    o = _u64(0)
+    check(fn(*args, C.byref(o)))
+    return o.value
+
+
+class Plan:
+    """RAII wrapper of ronk_plan: (p, g, n = 2^log2n, batch) on one device."""
+
+    def __init__(self, p, g, log2n, batch=1, device=-1):
+        self.h = None
+        h = _vp()
+        check(lib.ronk_plan_create(C.byref(h), p, g, log2n, batch, device))
+        self.h, self.p, self.g, self.log2n, self.n, self.batch = h, p, g, log2n, 1 << log2n, batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.ronk_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def num_passes(self):
+        return lib.ronk_plan_num_passes(self.h)
+
+    def forward(self, x, nodes=False):
+        x = arr(x)
+        assert x.size == self.n * self.batch
+        out = np.empty_like(x)
+        nd = np.empty(self.n, dtype=np.uint64) if nodes else None
+        check(lib.ronk_ntt_forward(self.h, ptr(x), ptr(out), ptr(nd) if nodes else None))
+        return (out, nd) if nodes else out
+
+    def inverse(self, x):
+        x = arr(x)
+        assert x.size == self.n * self.batch
+        out = np.empty_like(x)
+        check(lib.ronk_ntt_inverse(self.h, ptr(x), ptr(out)))
+        return out
+
+    def forward_dev(self, d_in, d_out, stream=0):
+        check(lib.ronk_ntt_forward_dev(self.h, d_in, d_out, stream))
+
+    def inverse_dev(self, d_in, d_out, stream=0):
+        check(lib.ronk_ntt_inverse_dev(self.h, d_in, d_out, stream))
+
+    def time_passes(self, d_in, d_out, inverse=False, iters=20, stream=0):
+        np_ = self.num_passes()
+        ms = (C.c_float * np_)()
+        check(lib.ronk_plan_time_passes(self.h, d_in, d_out, int(inverse), iters, ms, stream))
+        return [float(v) for v in ms]

@@ -1,0 +1,252 @@
+// field_kernels.h -- element-wise field kernels and the generic (any prime) polynomial kernels.
+//
+// Templated on an Ops type that supplies canonical-in / canonical-out add, sub, mul:
+//   GlOps    Goldilocks fast path (gl64.h)
+//   MontOps  any odd prime p < 2^64 (mont64.h) -- the reference's PrimeField<P> for F_101, F_17, ...
+//   Mod2Ops  p = 2 (the reference's AESField = PrimeField<2>)
+// These restate ronkathon's per-element semantics (src/algebra/field/prime/arithmetic.rs:3-71,
+// src/polynomial/mod.rs:133-258, src/polynomial/arithmetic.rs:16-119) as grid-stride HIP kernels.
+// HBM-bound streaming work: 8-byte loads, lanes along the array, no LDS needed except reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gl64.h"
+#include "mont64.h"
+
+namespace ronk {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+struct GlOps {
+  __device__ __forceinline__ u64 add(u64 a, u64 b) const { return gl64::add(a, b); }
+  __device__ __forceinline__ u64 sub(u64 a, u64 b) const { return gl64::sub(a, b); }
+  __device__ __forceinline__ u64 mul(u64 a, u64 b) const { return gl64::mul(a, b); }
+  __device__ __forceinline__ u64 neg(u64 a) const { return gl64::neg(a); }
+  __device__ __forceinline__ u64 pow(u64 a, u64 e) const { return gl64::pow(a, e); }
+  __device__ __forceinline__ u64 one() const { return 1; }
+  __device__ __forceinline__ u64 order() const { return gl64::P; }
+};
+
+struct MontOps {
+  mont64::Field f;
+  __device__ __forceinline__ u64 add(u64 a, u64 b) const { return mont64::add(f, a, b); }
+  __device__ __forceinline__ u64 sub(u64 a, u64 b) const { return mont64::sub(f, a, b); }
+  __device__ __forceinline__ u64 mul(u64 a, u64 b) const { return mont64::mul(f, a, b); }
+  __device__ __forceinline__ u64 neg(u64 a) const { return mont64::neg(f, a); }
+  __device__ __forceinline__ u64 pow(u64 a, u64 e) const { return mont64::pow(f, a, e); }
+  __device__ __forceinline__ u64 one() const { return 1; }
+  __device__ __forceinline__ u64 order() const { return f.p; }
+};
+
+struct Mod2Ops {
+  __device__ __forceinline__ u64 add(u64 a, u64 b) const { return a ^ b; }
+  __device__ __forceinline__ u64 sub(u64 a, u64 b) const { return a ^ b; }
+  __device__ __forceinline__ u64 mul(u64 a, u64 b) const { return a & b; }
+  __device__ __forceinline__ u64 neg(u64 a) const { return a; }
+  __device__ __forceinline__ u64 pow(u64 a, u64 e) const { return e ? a : 1; }
+  __device__ __forceinline__ u64 one() const { return 1; }
+  __device__ __forceinline__ u64 order() const { return 2; }
+};
+
+enum VecOp { VEC_ADD, VEC_SUB, VEC_MUL };
+
+// out[i] = a[i] (op) b[i]; b is read as ZERO beyond nb (Polynomial Add/Sub zero-extension,
+// polynomial/arithmetic.rs:23-34)
+template <class Ops, int OP>
+__global__ void __launch_bounds__(256) vec_binary_kernel(Ops ops, const u64* __restrict__ a, const u64* __restrict__ b,
+                                                          u64* __restrict__ out, size_t n, size_t nb) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    u64 x = a[i], y = i < nb ? b[i] : 0;
+    out[i] = OP == VEC_ADD ? ops.add(x, y) : OP == VEC_SUB ? ops.sub(x, y) : ops.mul(x, y);
+  }
+}
+
+template <class Ops>
+__global__ void __launch_bounds__(256) vec_neg_kernel(Ops ops, const u64* __restrict__ a, u64* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ops.neg(a[i]);
+}
+
+// Field::pow (prime/mod.rs:74-84); with e = p-2 and flag != null it is Field::inverse
+// (prime/mod.rs:62-72): a zero input raises *flag (the reference returns None / panics on unwrap)
+template <class Ops>
+__global__ void __launch_bounds__(256) vec_pow_kernel(Ops ops, const u64* __restrict__ a, u64 e, u64* __restrict__ out,
+                                                       size_t n, int* flag) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    u64 x = a[i];
+    if (flag && x == 0) *flag = 1;
+    out[i] = ops.pow(x, e);
+  }
+}
+
+// t[i] = w^i (Lagrange::new's nodes, polynomial/mod.rs:363)
+template <class Ops>
+__global__ void __launch_bounds__(256) power_table_kernel(Ops ops, u64 w, u64* __restrict__ t, size_t n) {
+  size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  if (i0 >= n) return;
+  u64 x = ops.pow(w, i0), ws = ops.pow(w, step);
+  for (size_t i = i0; i < n; i += step) { t[i] = x; x = ops.mul(x, ws); }
+}
+
+// Polynomial::dft (polynomial/mod.rs:240-258): out[i] = sum_j c[j] * w^(i*j).  One work-item per
+// output, the input staged through LDS in chunks.  O(n^2): only for n without a fast path.
+template <class Ops>
+__global__ void __launch_bounds__(256) dft_naive_kernel(Ops ops, const u64* __restrict__ in, u64* __restrict__ out,
+                                                         size_t n, u64 w) {
+  __shared__ u64 chunk[256];
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const u64 wi = ops.pow(w, i < n ? i : 0);
+  u64 acc = 0, wij = 1;
+  for (size_t j0 = 0; j0 < n; j0 += 256) {
+    __syncthreads();
+    if (j0 + threadIdx.x < n) chunk[threadIdx.x] = in[j0 + threadIdx.x];
+    __syncthreads();
+    const size_t lim = n - j0 < 256 ? n - j0 : 256;
+    for (size_t j = 0; j < lim; j++) {
+      acc = ops.add(acc, ops.mul(chunk[j], wij));
+      wij = ops.mul(wij, wi);
+    }
+  }
+  if (i < n) out[i] = acc;
+}
+
+// impl Mul (polynomial/arithmetic.rs:97-119), schoolbook: out[k] = sum_{i+j=k} a[i] b[j]
+template <class Ops>
+__global__ void __launch_bounds__(256) poly_mul_schoolbook_kernel(Ops ops, const u64* __restrict__ a, size_t d,
+                                                                   const u64* __restrict__ b, size_t d2,
+                                                                   u64* __restrict__ out) {
+  const size_t m = d + d2 - 1;
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < m; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t lo = k >= d2 ? k - d2 + 1 : 0, hi = k < d ? k : d - 1;
+    u64 acc = 0;
+    for (size_t i = lo; i <= hi; i++) acc = ops.add(acc, ops.mul(a[i], b[k - i]));
+    out[k] = acc;
+  }
+}
+
+// Polynomial::evaluate (polynomial/mod.rs:133-139): sum c_i x^i.  Each work-item walks a strided
+// subsequence with a running power, a block tree-reduces in LDS, one partial per block.
+template <class Ops>
+__global__ void __launch_bounds__(256) poly_eval_partial_kernel(Ops ops, const u64* __restrict__ c, size_t d, u64 x,
+                                                                 u64* __restrict__ partial) {
+  __shared__ u64 red[256];
+  const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  u64 acc = 0;
+  if (i0 < d) {
+    u64 xi = ops.pow(x, i0), xs = ops.pow(x, step);
+    for (size_t i = i0; i < d; i += step) { acc = ops.add(acc, ops.mul(c[i], xi)); xi = ops.mul(xi, xs); }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = ops.add(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+template <class Ops>
+__global__ void __launch_bounds__(256) sum_kernel(Ops ops, const u64* __restrict__ partial, size_t n, u64* out) {
+  __shared__ u64 red[256];
+  u64 acc = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) acc = ops.add(acc, partial[i]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = ops.add(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+// quotient_and_remainder (polynomial/mod.rs:170-225), one workgroup, followed step by step:
+// the loop guard compares the remainder's TRIMMED length with the divisor's UNTRIMMED length d2,
+// the update walks all d2 divisor coefficients, a zero divisor or an out-of-range update is the
+// reference's panic (status -6), a zero leading inverse cannot occur for a non-zero divisor.
+// work: rem[] (d entries, starts as the dividend), quot[] zeroed here.
+template <class Ops>
+__global__ void __launch_bounds__(1024) poly_divrem_kernel(Ops ops, u64* __restrict__ rem, size_t d,
+                                                            const u64* __restrict__ b, size_t d2,
+                                                            u64* __restrict__ quot, int* status) {
+  __shared__ unsigned long long s_top;   // 1 + highest non-zero index found by the scan (0 = none)
+  __shared__ u64 s_s;
+  const int T = blockDim.x, tid = threadIdx.x;
+  for (size_t i = tid; i < d; i += T) quot[i] = 0;
+  // divisor degree / leading coefficient
+  if (tid == 0) s_top = 0;
+  __syncthreads();
+  long long mine = -1;
+  for (size_t i = tid; i < d2; i += T) if (b[i] != 0) mine = (long long)i;
+  if (mine >= 0) atomicMax(&s_top, (unsigned long long)(mine + 1));
+  __syncthreads();
+  const long long rhs_degree = (long long)s_top - 1;
+  __syncthreads();
+  u64 cinv = 0;
+  if (rhs_degree >= 0) cinv = ops.pow(b[rhs_degree], ops.order() - 2);
+  size_t plen = d;
+  for (;;) {
+    // p_degree = rposition(!= 0) over the current (trimmed) remainder
+    if (tid == 0) s_top = 0;
+    __syncthreads();
+    mine = -1;
+    for (size_t i = tid; i < plen; i += T) if (rem[i] != 0) mine = (long long)i;
+    if (mine >= 0) atomicMax(&s_top, (unsigned long long)(mine + 1));
+    __syncthreads();
+    const long long p_degree = (long long)s_top - 1;
+    __syncthreads();
+    if (!(p_degree >= 0 && plen >= d2)) break;       // while nonzero-count > 0 && len >= rhs.len()
+    if (rhs_degree < 0) { if (tid == 0) *status = -6; break; }  // rposition(..).unwrap() on zero divisor
+    if (p_degree < rhs_degree) break;
+    const size_t diff = (size_t)(p_degree - rhs_degree);
+    if (diff + d2 > plen) { if (tid == 0) *status = -6; break; }  // p_coeffs[diff + i] out of bounds
+    if (tid == 0) { s_s = ops.mul(rem[p_degree], cinv); quot[diff] = s_s; }
+    __syncthreads();
+    const u64 s = s_s;
+    for (size_t i = tid; i < d2; i += T) rem[diff + i] = ops.sub(rem[diff + i], ops.mul(b[i], s));
+    __syncthreads();
+    // trim_zeros: the new length is one past the highest non-zero entry (found by the next scan);
+    // entries above it are already zero, so only the guard `plen >= d2` needs the trimmed value
+    if (tid == 0) s_top = 0;
+    __syncthreads();
+    mine = -1;
+    for (size_t i = tid; i < plen; i += T) if (rem[i] != 0) mine = (long long)i;
+    if (mine >= 0) atomicMax(&s_top, (unsigned long long)(mine + 1));
+    __syncthreads();
+    plen = (size_t)s_top;
+    __syncthreads();
+  }
+}
+
+// ---- generic power-of-two NTT for fields without the Goldilocks fast path -------------------
+// bit-reversal copy, then log2(n) radix-2 decimation-in-time stages over HBM (the reference's
+// recursion, polynomial/mod.rs:295-323, unrolled bottom-up); twiddles from a w^i table.
+__device__ __forceinline__ u32 bitrev32(u32 x, int bits) { return __brev(x) >> (32 - bits); }
+
+template <class Ops>
+__global__ void __launch_bounds__(256) bitrev_copy_kernel(Ops, const u64* __restrict__ in, u64* __restrict__ out,
+                                                           int log2n, size_t total) {
+  const size_t n = (size_t)1 << log2n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t poly = i >> log2n, j = i & (n - 1);
+    out[(poly << log2n) + (log2n ? bitrev32((u32)j, log2n) : 0)] = in[i];
+  }
+}
+// stage s (half = 2^s): pairs (i, i+half) inside blocks of 2*half, twiddle w^(j * n/(2 half))
+template <class Ops>
+__global__ void __launch_bounds__(256) radix2_stage_kernel(Ops ops, u64* __restrict__ x, const u64* __restrict__ wtab,
+                                                            int log2n, int s, size_t total_pairs, u64 scale) {
+  const size_t half = (size_t)1 << s;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total_pairs; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t poly = t >> (log2n - 1), r = t & (((size_t)1 << (log2n - 1)) - 1);
+    const size_t j = r & (half - 1), blk = r >> s;
+    const size_t i0 = (poly << log2n) + (blk << (s + 1)) + j;
+    const u64 w = wtab[j << (log2n - 1 - s)];
+    const u64 u = x[i0], v = ops.mul(x[i0 + half], w);
+    u64 a = ops.add(u, v), b = ops.sub(u, v);
+    if (scale != 1) { a = ops.mul(a, scale); b = ops.mul(b, scale); }
+    x[i0] = a;
+    x[i0 + half] = b;
+  }
+}
+
+}  // namespace ronk

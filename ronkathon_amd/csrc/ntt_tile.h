@@ -1,0 +1,227 @@
+// ntt_tile.h -- the one NTT kernel every plan is composed from (Goldilocks, gfx950).
+//
+// A workgroup transforms a TILE: C adjacent "columns" x R "rows" (R = 2^LOGR, 16..4096),
+// i.e. C independent R-point NTTs whose elements sit at arbitrary (row, column) strides in
+// HBM.  Lanes always run fastest along the column index, so every 8-16 lane group touches
+// one 64-128 B segment on both the load and the store side, whatever the strides are.  A
+// thread owns 16 coefficients in VGPRs; the R-point transform is done as up to three
+// register-resident radix-16 (last round radix-2..16) decimation-in-frequency rounds with
+// the tile staged through LDS between rounds (in place, two barriers at most):
+//
+//   round i : 16-point sub-DFT over digit j_i (pure shifts: omega_16^k = +-2^K, gl64.h)
+//             then one table twiddle omega_M^{rest * k_i} per coefficient
+//   output  : natural index k = k_1 + 16 k_2 + 256 k_3, optional inter-pass twiddle
+//             omega_N^{X*Y} (two-level table) and optional scale (n^-1 of the inverse)
+//
+// which restates, pass by pass, what Polynomial::fft / ifft compute recursively
+// (reference src/polynomial/mod.rs:273-323, :430-484): X[k] = sum_j x[j] omega^{jk},
+// natural order in, natural order out, omega = g^((p-1)/n).  No MFMA: this is 64-bit
+// modular integer work, bounded by HBM traffic and the VALU integer-multiply rate.
+//
+// LDS image: row-major [R][C] u64 with rows XOR-swizzled, row' = row ^ ((row>>4)&15), so
+// that the strided accesses of the early rounds and the 16-consecutive-row accesses of the
+// last round are both bank-conflict free for ds_read_b64 / ds_write_b64.
+//
+// The body is plain C++ over (tid, bid, lds, barrier) so that tests/emu can run the very
+// same code on host threads to check the index algebra without a GPU.
+#pragma once
+#include "gl64.h"
+
+namespace ronk {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int64_t i64;
+
+struct TileArgs {
+  const u64* in;
+  const u64* in2;  // optional second operand: x = in * in2 on load (fused pointwise product)
+  u64* out;
+  // element (j, c) of tile t in batch (b1, b2):
+  //   in [b1*in_sb1 + b2*in_sb2 + (t*C + c)*in_sc + j*in_sj]
+  //   out[b1*out_sb1 + b2*out_sb2 + (t*C + c)*out_sc + k*out_sk]
+  // row j may be split in two levels (the multi-GPU receive buffer is a list of blocks):
+  //   row offset = (j >> js_log)*in_sj_hi + (j & (2^js_log - 1))*in_sj      (js_log = 31: flat)
+  i64 in_sj, in_sc, in_sb1, in_sb2;
+  i64 in_sj_hi;
+  u32 js_log;
+  i64 out_sk, out_sc, out_sb1, out_sb2;
+  u32 logc;   // C = 2^logc columns per tile
+  u32 tiles;  // tiles per (b1, b2)
+  u32 nb1, nb2;
+  u64 ncols;  // valid columns per (b1, b2); columns >= ncols of the last tile are skipped
+  const u64* wr;  // round twiddles omega_R^e, e in [0, R)
+  // output twiddle omega_N^{(X*Y) mod N}, N = 2^tw_log (0 = none), w^e = tw_lo[e & m] * tw_hi[e >> bits]
+  u32 tw_log, tw_lo_bits;
+  const u64* tw_lo;
+  const u64* tw_hi;
+  u64 xc, xb1, xb2, x0;  // X = xc*(t*C + c) + xb1*b1 + xb2*b2 + x0
+  u64 yk, yb1, yb2, y0;  // Y = yk*k + yb1*b1 + yb2*b2 + y0
+  u64 scale;             // 1 = none
+};
+
+// ---- compile-time helpers -------------------------------------------------------------
+
+constexpr int brev(int x, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+// exponent E with omega_N^j == 2^E (mod p), N | 64; inverse direction uses omega^-1
+constexpr int root_exp(int n, int j, bool inv) {
+  int e = (39 * (64 / n) * j) % 192;
+  return inv ? (192 - e) % 192 : e;
+}
+
+// (a - b) * omega_N^J
+template <int N, int J, bool INV>
+RONK_HD u64 sub_mul_root(u64 a, u64 b) {
+  constexpr int E = root_exp(N, J, INV);
+  if constexpr (E >= 96) {
+    return gl64::mul_2exp<E - 96>(gl64::sub(b, a));  // omega = -2^(E-96)
+  } else {
+    return gl64::mul_2exp<E>(gl64::sub(a, b));
+  }
+}
+
+// one DIF stage on x[0..N): (a, b) -> (a + b, (a - b) * omega_N^j), j = J..N/2-1
+template <int N, bool INV, int J>
+RONK_HD void dif_stage(u64* x) {
+  if constexpr (J < N / 2) {
+    u64 a = x[J], b = x[J + N / 2];
+    x[J] = gl64::add(a, b);
+    x[J + N / 2] = sub_mul_root<N, J, INV>(a, b);
+    dif_stage<N, INV, J + 1>(x);
+  }
+}
+
+// N-point DIF DFT in registers; x[t] ends up holding X[brev(t)]
+template <int N, bool INV>
+struct Dif {
+  static RONK_HD void run(u64* x) {
+    dif_stage<N, INV, 0>(x);
+    Dif<N / 2, INV>::run(x);
+    Dif<N / 2, INV>::run(x + N / 2);
+  }
+};
+template <bool INV>
+struct Dif<1, INV> {
+  static RONK_HD void run(u64*) {}
+};
+
+RONK_HD u32 swz_row(u32 row) { return row ^ ((row >> 4) & 15u); }
+
+// ---- the tile body --------------------------------------------------------------------
+//
+// LOGR = 4*(Q-1) + LOGLAST, Q rounds; radices 16,..,16,2^LOGLAST.
+template <int LOGR, bool INV, class Barrier>
+RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
+  constexpr int R = 1 << LOGR;
+  constexpr int Q = (LOGR + 3) / 4;              // rounds
+  constexpr int LOGLAST = LOGR - 4 * (Q - 1);    // 1..4
+  constexpr int RLAST = 1 << LOGLAST;
+  constexpr int M = R / 16;                      // threads per column
+  static_assert(LOGR >= 4 && LOGR <= 12, "pass size");
+
+  const u32 logc = a.logc;
+  const u32 C = 1u << logc;
+  const u32 c = tid & (C - 1);
+  const u32 m = tid >> logc;  // [0, M)
+
+  // block -> (tile, b1, b2)
+  u32 t = bid % a.tiles;
+  u32 bb = bid / a.tiles;
+  u32 b1 = bb % a.nb1, b2 = bb / a.nb1;
+  const u64 col = (u64)t * C + c;
+  const u64* in = a.in + b1 * a.in_sb1 + b2 * a.in_sb2 + (i64)col * a.in_sc;
+  u64* out = a.out + b1 * a.out_sb1 + b2 * a.out_sb2 + (i64)col * a.out_sc;
+
+  const bool live = col < a.ncols;  // ragged last tile: dead columns compute on zeros
+
+  u64 x[16];
+
+  // ---- round 1: j = j1*M + m, straight from HBM
+  const u32 jmask = (1u << a.js_log) - 1;
+  i64 joff[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const u32 j = i * M + m;
+    joff[i] = (i64)(j >> a.js_log) * a.in_sj_hi + (i64)(j & jmask) * a.in_sj;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) x[i] = live ? in[joff[i]] : 0;
+  if (a.in2 && live) {
+    const u64* in2 = a.in2 + b1 * a.in_sb1 + b2 * a.in_sb2 + (i64)col * a.in_sc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], in2[joff[i]]);
+  }
+  Dif<16, INV>::run(x);
+
+  u32 klow[16];  // natural output row of register i, minus the last digit's contribution
+  if (Q == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) klow[i] = brev(i, 4);
+  } else {
+    // twiddle omega_R^{m*k1}, then park at row k1*M + m
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 k1 = brev(i, 4);
+      if (k1) x[i] = gl64::mul(x[i], a.wr[m * k1]);
+      lds[((u64)swz_row(k1 * M + m) << logc) + c] = x[i];
+    }
+    barrier();
+
+    if (Q == 3) {
+      // ---- round 2: thread (d1, d3) = (m / RLAST, m % RLAST), register digit d2
+      const u32 d1 = m >> LOGLAST, d3 = m & (RLAST - 1);
+      const u32 base = d1 * (16 * RLAST) + d3;
+#pragma unroll
+      for (int i = 0; i < 16; i++) x[i] = lds[((u64)swz_row(base + i * RLAST) << logc) + c];
+      Dif<16, INV>::run(x);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const u32 k2 = brev(i, 4);
+        if (k2) x[i] = gl64::mul(x[i], a.wr[16 * d3 * k2]);  // omega_{R/16}^{d3*k2}
+        lds[((u64)swz_row(base + k2 * RLAST) << logc) + c] = x[i];
+      }
+      barrier();
+    }
+
+    // ---- last round: thread m owns rows 16m .. 16m+15; row = v*RLAST + d_last
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = lds[((u64)swz_row(16 * m + i) << logc) + c];
+#pragma unroll
+    for (int g = 0; g < 16 / RLAST; g++) Dif<RLAST, INV>::run(x + g * RLAST);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 v = m * (16 / RLAST) + (i >> LOGLAST);           // (d1[,d2]) pair index
+      const u32 kl = (Q == 3) ? ((v >> 4) + 16 * (v & 15)) : v;  // k1 + 16 k2  |  k1
+      klow[i] = kl + (R / RLAST) * brev(i & (RLAST - 1), LOGLAST);
+    }
+  }
+
+  // ---- output: optional inter-pass twiddle, optional scale, store at natural row k
+  if (a.tw_log) {
+    const u64 X = a.xc * col + a.xb1 * b1 + a.xb2 * b2 + a.x0;
+    const u64 Yb = a.yb1 * b1 + a.yb2 * b2 + a.y0;
+    const u64 nmask = ((u64)1 << a.tw_log) - 1;
+    const u64 lmask = ((u64)1 << a.tw_lo_bits) - 1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u64 e = (X * (a.yk * klow[i] + Yb)) & nmask;
+      const u64 w = gl64::mul(a.tw_lo[e & lmask], a.tw_hi[e >> a.tw_lo_bits]);
+      x[i] = gl64::mul(x[i], w);
+    }
+  }
+  if (a.scale != 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], a.scale);
+  }
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[(i64)klow[i] * a.out_sk] = x[i];
+  }
+}
+
+}  // namespace ronk

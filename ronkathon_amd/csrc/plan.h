@@ -1,0 +1,312 @@
+// plan.h -- host-side decomposition of an n-point NTT (n = 2^k) into tile passes.
+//
+// Pure C++ (no HIP calls): produces pass descriptors and the twiddle tables they index.
+// The same code is used by the library (ronk_ntt.hip uploads the tables and launches one
+// ntt_tile kernel per pass) and by the host kernel emulator under tests/emu.
+//
+// Decomposition (natural order in, natural order out; reference semantics
+// src/polynomial/mod.rs:273-323 / :430-484, omega = g^((p-1)/n)):
+//   k <= 12          one pass, the polynomial batch is the tile's column axis
+//   13 <= k <= 24    n = A*B:   pass 1  A-point NTTs down the B columns of [A][B], * omega_n^{b*ka}
+//                               pass 2  B-point NTTs along rows, output index ka + A*kb
+//   25 <= k <= 36    n = A*B*C: the B*C-point row transforms of pass 2 are split the same way
+// Every pass is the same kernel with different strides; exactly one pass transposes
+// (rows in, columns out), so it reads its input from a scratch buffer.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <vector>
+
+#include "gl64.h"
+#include "ntt_tile.h"
+
+namespace ronk {
+
+enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_TMP = 2 };
+
+struct PassDesc {
+  int logr;
+  TileArgs args;      // pointers left null; filled at launch from the ids below
+  Buf in_buf, out_buf;
+  int wr_id;          // index into PlanDesc::wr (round twiddles for 2^logr)
+  int tw_id;          // index into PlanDesc::tw, or -1
+  u32 grid, block;
+  size_t lds_bytes;
+};
+
+struct TwTable {
+  int log_n, lo_bits;
+  std::vector<u64> lo, hi;
+};
+
+struct PlanDesc {
+  int log2n = 0;
+  u64 batch = 1;
+  bool inverse = false;
+  std::vector<PassDesc> passes;
+  std::vector<std::vector<u64>> wr;  // one table per distinct logr
+  std::vector<int> wr_logr;
+  std::vector<TwTable> tw;
+  bool needs_tmp = false;
+};
+
+inline u64 root_of_unity_pow2(int log_n, bool inverse) {
+  // field/mod.rs:70-75 with PRIMITIVE_ELEMENT = 7: w = g^((p-1)/n)
+  u64 w = gl64::pow(gl64::GENERATOR, (gl64::P - 1) >> log_n);
+  return inverse ? gl64::inv(w) : w;
+}
+
+inline std::vector<u64> power_table(u64 w, size_t count) {
+  std::vector<u64> t(count);
+  u64 x = 1;
+  for (size_t i = 0; i < count; i++) { t[i] = x; x = gl64::mul(x, w); }
+  return t;
+}
+
+struct PlanBuilder {
+  PlanDesc d;
+
+  int wr_table(int logr) {
+    for (size_t i = 0; i < d.wr_logr.size(); i++)
+      if (d.wr_logr[i] == logr) return (int)i;
+    d.wr_logr.push_back(logr);
+    d.wr.push_back(power_table(root_of_unity_pow2(logr, d.inverse), (size_t)1 << logr));
+    return (int)d.wr.size() - 1;
+  }
+  int tw_table(int log_n) {
+    for (size_t i = 0; i < d.tw.size(); i++)
+      if (d.tw[i].log_n == log_n) return (int)i;
+    TwTable t;
+    t.log_n = log_n;
+    t.lo_bits = (log_n + 1) / 2;
+    u64 w = root_of_unity_pow2(log_n, d.inverse);
+    t.lo = power_table(w, (size_t)1 << t.lo_bits);
+    t.hi = power_table(gl64::pow(w, (u64)1 << t.lo_bits), (size_t)1 << (log_n - t.lo_bits));
+    d.tw.push_back(t);
+    return (int)d.tw.size() - 1;
+  }
+
+  // columns per tile for an R-row pass over `ncols` columns
+  static u32 pick_logc(int logr, u64 ncols, int max_logc) {
+    int lc = 14 - logr;                 // R*C <= 16384 coefficients (128 KiB LDS, 1024 threads)
+    int want = max_logc > 12 - logr ? max_logc : 12 - logr;  // small R: widen to 256 threads
+    if (lc > want) lc = want;
+    if (lc < 0) lc = 0;
+    while (lc > 0 && ((u64)1 << lc) > ncols) lc--;
+    return (u32)lc;
+  }
+
+  PassDesc& add_pass(int logr, u64 ncols, int max_logc) {
+    PassDesc p;
+    p.logr = logr;
+    p.args = TileArgs();
+    p.args.in = p.args.in2 = nullptr;
+    p.args.out = nullptr;
+    p.args.logc = pick_logc(logr, ncols, max_logc);
+    u64 C = (u64)1 << p.args.logc;
+    p.args.tiles = (u32)((ncols + C - 1) / C);
+    p.args.ncols = ncols;
+    p.args.nb1 = p.args.nb2 = 1;
+    p.args.in_sb1 = p.args.in_sb2 = p.args.out_sb1 = p.args.out_sb2 = 0;
+    p.args.in_sj_hi = 0; p.args.js_log = 31;
+    p.args.tw_log = 0; p.args.tw_lo_bits = 0;
+    p.args.tw_lo = p.args.tw_hi = nullptr;
+    p.args.xc = p.args.xb1 = p.args.xb2 = p.args.x0 = 0;
+    p.args.yk = p.args.yb1 = p.args.yb2 = p.args.y0 = 0;
+    p.args.scale = 1;
+    p.wr_id = wr_table(logr);
+    p.args.wr = nullptr;
+    p.tw_id = -1;
+    p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
+    p.block = (u32)((((u64)1 << logr) * C) / 16);
+    p.lds_bytes = logr > 4 ? ((size_t)8 << logr) * C : 0;
+    d.passes.push_back(p);
+    return d.passes.back();
+  }
+  void finish(PassDesc& p) { p.grid = p.args.tiles * p.args.nb1 * p.args.nb2; }
+};
+
+// max_logc: widest tile (log2 columns) the builder may pick; 4 = 128-byte segments.
+inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4) {
+  PlanBuilder b;
+  b.d.log2n = log2n; b.d.batch = batch; b.d.inverse = inverse;
+  const u64 n = (u64)1 << log2n;
+  const u64 scale = inverse ? gl64::inv(n % gl64::P) : 1;  // F::from(D).inverse(), mod.rs:442
+  if (log2n <= 12) {
+    // the batch is the column axis: column c = polynomial c, rows contiguous
+    PassDesc& p = b.add_pass(log2n, batch, max_logc);
+    p.args.in_sj = 1; p.args.in_sc = (i64)n;
+    p.args.out_sk = 1; p.args.out_sc = (i64)n;
+    p.args.scale = scale;
+    b.finish(p);
+  } else if (log2n <= 24) {
+    const int ka = (log2n + 1) / 2, kb = log2n - ka;
+    const u64 A = (u64)1 << ka, B = (u64)1 << kb;
+    {
+      PassDesc& p = b.add_pass(ka, B, max_logc);  // [A][B]: columns b, rows a
+      p.args.in_sj = (i64)B; p.args.in_sc = 1; p.args.out_sk = (i64)B; p.args.out_sc = 1;
+      p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
+      p.tw_id = b.tw_table(log2n);
+      p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+      p.args.xc = 1; p.args.yk = 1;              // omega_n^{b * ka}
+      p.in_buf = BUF_IN; p.out_buf = BUF_TMP;
+      b.finish(p);
+    }
+    {
+      PassDesc& p = b.add_pass(kb, A, max_logc);  // rows ka are the columns of this pass
+      p.args.in_sj = 1; p.args.in_sc = (i64)B; p.args.out_sk = (i64)A; p.args.out_sc = 1;
+      p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
+      p.args.scale = scale;
+      p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
+      b.finish(p);
+    }
+    b.d.needs_tmp = true;
+  } else {
+    const int ka = (log2n + 2) / 3, kb = (log2n - ka + 1) / 2, kc = log2n - ka - kb;
+    const u64 A = (u64)1 << ka, B = (u64)1 << kb, C = (u64)1 << kc, BC = B * C;
+    {
+      PassDesc& p = b.add_pass(ka, BC, max_logc);  // [A][B*C]
+      p.args.in_sj = (i64)BC; p.args.in_sc = 1; p.args.out_sk = (i64)BC; p.args.out_sc = 1;
+      p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
+      p.tw_id = b.tw_table(log2n);
+      p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+      p.args.xc = 1; p.args.yk = 1;
+      p.in_buf = BUF_IN; p.out_buf = BUF_TMP;
+      b.finish(p);
+    }
+    {
+      PassDesc& p = b.add_pass(kb, C, max_logc);  // inside row ka: [B][C], in place
+      p.args.in_sj = (i64)C; p.args.in_sc = 1; p.args.out_sk = (i64)C; p.args.out_sc = 1;
+      p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
+      p.args.nb2 = (u32)A; p.args.in_sb2 = p.args.out_sb2 = (i64)BC;
+      p.tw_id = b.tw_table(kb + kc);
+      p.args.tw_log = kb + kc; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+      p.args.xc = 1; p.args.yk = 1;              // omega_{BC}^{c * kb}
+      p.in_buf = BUF_TMP; p.out_buf = BUF_TMP;
+      b.finish(p);
+    }
+    {
+      PassDesc& p = b.add_pass(kc, A, max_logc);  // columns ka, batch kb; k = ka + A*(kb + B*kc)
+      p.args.in_sj = 1; p.args.in_sc = (i64)BC; p.args.out_sk = (i64)(A * B); p.args.out_sc = 1;
+      p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
+      p.args.nb2 = (u32)B; p.args.in_sb2 = (i64)C; p.args.out_sb2 = (i64)A;
+      p.args.scale = scale;
+      p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
+      b.finish(p);
+    }
+    b.d.needs_tmp = true;
+  }
+  return b.d;
+}
+
+// ---- multi-GPU four-step (one process per GPU; the exchange between the two phases is an
+// all-to-all over xGMI issued by the host side).  n = R*C, R = 2^(k - k/2), C = 2^(k/2);
+// input index i = r*C + c, output index k = k1 + R*k2.  Rank g of W owns columns
+// [g*C/W, (g+1)*C/W) as [R][C/W]; phase 1 = R-point NTTs down those columns times
+// omega_n^{c*k1}, written as [R][C/W] (= W consecutive send blocks of R/W rows);
+// after the exchange rank h holds W blocks [R/W][C/W] (block g from rank g) and phase 2 =
+// C-point NTTs along each of its R/W rows, written as out[k2*(R/W) + k1_local].
+struct DistShape {
+  int log2n, logR, logC, logW;
+  u64 n, R, C, W, Rw, Cw;
+};
+inline bool dist_shape(int log2n, int world, DistShape* s) {
+  int lw = 0;
+  while ((1 << lw) < world) lw++;
+  if ((1 << lw) != world) return false;
+  s->log2n = log2n; s->logC = log2n / 2; s->logR = log2n - s->logC; s->logW = lw;
+  s->n = (u64)1 << log2n; s->R = (u64)1 << s->logR; s->C = (u64)1 << s->logC; s->W = (u64)world;
+  if (s->logC < lw + 4 || s->logR > 24 || s->logC > 24) return false;  // >= 16 columns and rows per rank
+  s->Rw = s->R / s->W; s->Cw = s->C / s->W;
+  return true;
+}
+
+inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, int max_logc = 4) {
+  DistShape sh;
+  PlanBuilder b;
+  b.d.log2n = log2n; b.d.inverse = inverse;
+  if (!dist_shape(log2n, world, &sh)) return b.d;
+  const u64 Cw = sh.Cw, g0 = (u64)rank * Cw;
+  if (sh.logR <= 12) {
+    PassDesc& p = b.add_pass(sh.logR, Cw, max_logc);
+    p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)Cw; p.args.out_sc = 1;
+    p.tw_id = b.tw_table(log2n);
+    p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+    p.args.xc = 1; p.args.x0 = g0; p.args.yk = 1;            // omega_n^{(g0 + cl) * k1}
+    p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
+    b.finish(p);
+  } else {
+    const int ka = (sh.logR + 1) / 2, kb = sh.logR - ka;
+    const u64 A = (u64)1 << ka, B = (u64)1 << kb;
+    {
+      PassDesc& p = b.add_pass(ka, Cw, max_logc);             // r = a*B + b: A-point over a, batch b
+      p.args.in_sj = (i64)(B * Cw); p.args.in_sc = 1; p.args.out_sk = (i64)(B * Cw); p.args.out_sc = 1;
+      p.args.nb2 = (u32)B; p.args.in_sb2 = p.args.out_sb2 = (i64)Cw;
+      p.tw_id = b.tw_table(sh.logR);
+      p.args.tw_log = sh.logR; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+      p.args.xb2 = 1; p.args.yk = 1;                          // omega_R^{b * ka}
+      p.in_buf = BUF_IN; p.out_buf = BUF_TMP;
+      b.finish(p);
+    }
+    {
+      PassDesc& p = b.add_pass(kb, Cw, max_logc);             // B-point over b, batch ka; k1 = ka + A*kb
+      p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)(A * Cw); p.args.out_sc = 1;
+      p.args.nb2 = (u32)A; p.args.in_sb2 = (i64)(B * Cw); p.args.out_sb2 = (i64)Cw;
+      p.tw_id = b.tw_table(log2n);
+      p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+      p.args.xc = 1; p.args.x0 = g0; p.args.yk = A; p.args.yb2 = 1;   // omega_n^{c * (ka + A*kb)}
+      p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
+      b.finish(p);
+    }
+    b.d.needs_tmp = true;
+  }
+  return b.d;
+}
+
+inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, int max_logc = 4) {
+  (void)rank;
+  DistShape sh;
+  PlanBuilder b;
+  b.d.log2n = log2n; b.d.inverse = inverse;
+  if (!dist_shape(log2n, world, &sh)) return b.d;
+  const u64 Cw = sh.Cw, Rw = sh.Rw, C = sh.C;
+  const u64 scale = inverse ? gl64::inv(sh.n % gl64::P) : 1;
+  if (sh.logC <= 12) {
+    PassDesc& p = b.add_pass(sh.logC, Rw, max_logc);          // columns = local rows k1, rows j = c (blocked)
+    p.args.in_sc = (i64)Cw; p.args.in_sj = 1;
+    p.args.js_log = (u32)(sh.logC - sh.logW); p.args.in_sj_hi = (i64)(Rw * Cw);
+    p.args.out_sk = (i64)Rw; p.args.out_sc = 1;
+    p.args.scale = scale;
+    p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
+    b.finish(p);
+  } else {
+    const int ka = (sh.logC + 1) / 2, kb = sh.logC - ka;
+    const u64 A2 = (u64)1 << ka, B2 = (u64)1 << kb;
+    {
+      PassDesc& p = b.add_pass(ka, B2, max_logc);             // c = a2*B2 + b2: A2-point over a2; batch k1
+      p.args.in_sc = 1; p.args.in_sj = (i64)B2;
+      p.args.js_log = (u32)(sh.logC - sh.logW - kb); p.args.in_sj_hi = (i64)(Rw * Cw);
+      p.args.nb2 = (u32)Rw; p.args.in_sb2 = (i64)Cw;
+      p.args.out_sb2 = (i64)C; p.args.out_sk = (i64)B2; p.args.out_sc = 1;   // tmp: natural [k1][a2][b2]
+      p.tw_id = b.tw_table(sh.logC);
+      p.args.tw_log = sh.logC; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
+      p.args.xc = 1; p.args.yk = 1;                           // omega_C^{b2 * ka2}
+      p.in_buf = BUF_IN; p.out_buf = BUF_TMP;
+      b.finish(p);
+    }
+    {
+      PassDesc& p = b.add_pass(kb, Rw, max_logc);             // B2-point over b2; columns k1; batch ka2
+      p.args.in_sc = (i64)C; p.args.in_sj = 1;
+      p.args.nb2 = (u32)A2; p.args.in_sb2 = (i64)B2;
+      p.args.out_sc = 1; p.args.out_sb2 = (i64)Rw; p.args.out_sk = (i64)(A2 * Rw);   // k2 = ka2 + A2*kb2
+      p.args.scale = scale;
+      p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
+      b.finish(p);
+    }
+    b.d.needs_tmp = true;
+  }
+  return b.d;
+}
+
+}  // namespace ronk

@@ -1,0 +1,183 @@
+"""Multi-GPU four-step NTT: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI) for the single exchange step.
+
+n = R*C with R = 2^(k - k/2) rows, C = 2^(k/2) columns; input index i = r*C + c, output index
+k = k1 + R*k2.  Rank g of W owns
+
+    input    columns [g*C/W, (g+1)*C/W) of the R x C matrix       local layout [R][C/W]
+    output   X[k1 + R*k2] for k1 in [g*R/W, (g+1)*R/W)             local layout [C][R/W] (k2-major)
+
+    phase 1  (local, HIP)  R-point NTTs down the local columns, times omega_n^{c*k1}
+    exchange (RCCL)        all_to_all_single: block h of the [R][C/W] result (rows k1 of rank h) -> rank h
+    phase 2  (local, HIP)  C-point NTTs along each local row k1
+
+This restates Polynomial::fft (reference src/polynomial/mod.rs:273-323) for sizes beyond one GPU;
+the reference itself has no distributed path.  The local phases are the same tile kernel as the
+single-GPU plans (csrc/plan.h: build_dist_phase1/2).  The all-to-all moves n/W^2 elements per pair
+over the point-to-point xGMI links, all W-1 links of a GPU busy at once.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib as L
+
+
+def shape(log2n, world):
+    logc = log2n // 2
+    logr = log2n - logc
+    R, Cc = 1 << logr, 1 << logc
+    assert world >= 1 and world & (world - 1) == 0, "world size must be a power of two"
+    assert Cc // world >= 16 and R // world >= 16, "need at least 16 rows and columns per rank"
+    return R, Cc, R // world, Cc // world
+
+
+def scatter_input(x, rank, world):
+    """rank's [R][C/W] column block of the natural-order input"""
+    log2n = int(x.size).bit_length() - 1
+    R, Cc, Rw, Cw = shape(log2n, world)
+    return np.ascontiguousarray(x.reshape(R, Cc)[:, rank * Cw:(rank + 1) * Cw]).reshape(-1)
+
+
+def place_output(out_global, local_out, rank, world):
+    """write rank's [C][R/W] block into the natural-order output: X[k1 + R*k2]"""
+    log2n = int(out_global.size).bit_length() - 1
+    R, Cc, Rw, Cw = shape(log2n, world)
+    out_global.reshape(Cc, R)[:, rank * Rw:(rank + 1) * Rw] = local_out.reshape(Cc, Rw)
+
+
+class HipEngine:
+    """the product local engine: ronk_dist_plan over the C ABI (HIP kernels); torch tensors only carry memory"""
+
+    def __init__(self, log2n, inverse, rank, world, device=-1):
+        self.h = None
+        h = C.c_void_p()
+        L.check(L.lib.ronk_dist_plan_create(C.byref(h), log2n, int(inverse), rank, world, device))
+        self.h = h
+
+    def phase1(self, d_in, d_send, stream=0):
+        L.check(L.lib.ronk_dist_phase1_dev(self.h, d_in, d_send, stream))
+
+    def phase2(self, d_recv, d_out, stream=0):
+        L.check(L.lib.ronk_dist_phase2_dev(self.h, d_recv, d_out, stream))
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib.ronk_dist_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class FourStepNTT:
+    """Sharded NTT over a torch.distributed process group.  `engine` is the local-phase
+    implementation; the default (and only product) engine is HipEngine -- the CPU/gloo tests inject
+    a checker engine to exercise the exchange logic without a GPU."""
+
+    def __init__(self, log2n, inverse=False, group=None, engine=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.log2n = log2n
+        self.R, self.C, self.Rw, self.Cw = shape(log2n, self.world)
+        self.per_rank = (1 << log2n) // self.world
+        self.engine = engine if engine is not None else HipEngine(log2n, inverse, self.rank, self.world)
+
+    def _ptr(self, t):
+        return t.data_ptr()
+
+    def transform(self, local_in, send=None, recv=None, out=None):
+        """local_in: int64 tensor [R*C/W] (canonical residues, bit pattern of uint64) -> [C*R/W]"""
+        import torch
+        assert local_in.numel() == self.per_rank
+        send = torch.empty_like(local_in) if send is None else send
+        recv = torch.empty_like(local_in) if recv is None else recv
+        out = torch.empty_like(local_in) if out is None else out
+        stream = torch.cuda.current_stream().cuda_stream if local_in.is_cuda else 0
+        self.engine.phase1(self._ptr(local_in), self._ptr(send), stream)
+        if self.world > 1:
+            self.dist.all_to_all_single(recv, send, group=self.group)   # RCCL over xGMI
+        else:
+            recv = send
+        self.engine.phase2(self._ptr(recv), self._ptr(out), stream)
+        return out
+
+
+def fourstep_single_process(x, world, inverse=False):
+    """Run every rank's two phases on ONE GPU, the exchange as a host-side block copy.  Used by the
+    single-GPU parity tests to cover the multi-GPU kernels and index maps without 8 GPUs."""
+    x = L.arr(x)
+    log2n = int(x.size).bit_length() - 1
+    R, Cc, Rw, Cw = shape(log2n, world)
+    per = x.size // world
+    blk = Rw * Cw
+    send = []
+    d_a, d_b = C.c_void_p(), C.c_void_p()
+    L.check(L.lib.ronk_dev_alloc(C.byref(d_a), per * 8))
+    L.check(L.lib.ronk_dev_alloc(C.byref(d_b), per * 8))
+    try:
+        for g in range(world):
+            eng = HipEngine(log2n, inverse, g, world)
+            loc = scatter_input(x, g, world)
+            L.check(L.lib.ronk_memcpy_h2d(d_a, L.ptr(loc), per * 8))
+            eng.phase1(d_a, d_b)
+            L.check(L.lib.ronk_dev_sync())
+            s = np.empty(per, dtype=np.uint64)
+            L.check(L.lib.ronk_memcpy_d2h(L.ptr(s), d_b, per * 8))
+            send.append(s)
+            eng.close()
+        out = np.empty_like(x)
+        for h in range(world):
+            recv = np.concatenate([send[g][h * blk:(h + 1) * blk] for g in range(world)])  # all_to_all_single
+            eng = HipEngine(log2n, inverse, h, world)
+            L.check(L.lib.ronk_memcpy_h2d(d_a, L.ptr(recv), per * 8))
+            eng.phase2(d_a, d_b)
+            L.check(L.lib.ronk_dev_sync())
+            o = np.empty(per, dtype=np.uint64)
+            L.check(L.lib.ronk_memcpy_d2h(L.ptr(o), d_b, per * 8))
+            place_output(out, o, h, world)
+            eng.close()
+    finally:
+        L.lib.ronk_dev_free(d_a)
+        L.lib.ronk_dev_free(d_b)
+    return out
+
+
+def bench_fourstep(log2n, steps, warmup):
+    """one sharded forward NTT per step across all ranks of the default process group"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    fs = FourStepNTT(log2n)
+    rng = np.random.default_rng(1000 + rank)
+    loc = torch.from_numpy((rng.integers(0, 2**63, size=fs.per_rank, dtype=np.uint64)).view(np.int64)).cuda()
+    send, recv, out = torch.empty_like(loc), torch.empty_like(loc), torch.empty_like(loc)
+    for _ in range(warmup):
+        fs.transform(loc, send, recv, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fs.transform(loc, send, recv, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n = 1 << log2n
+    return {"metric": "sharded four-step forward NTTs/s, degree 2^%d" % log2n, "value": steps / dt, "unit": "NTT/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "four-step NTT n = 2^%d sharded over %d GPUs, RCCL all-to-all transpose" % (log2n, world)},
+            "roofline": {"bound": "hbm", "achieved": 16.0 * n / world / (dt / steps) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": 16.0 * n / world / (dt / steps) / 1e9 / 8000.0, "traffic": None}}

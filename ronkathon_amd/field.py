@@ -1,0 +1,125 @@
+"""Host mirror of ronkathon's `Field` / `FiniteField` traits and `PrimeField<P>`
+(reference src/algebra/field/mod.rs:17-84, src/algebra/field/prime/mod.rs:39-140,
+src/algebra/field/prime/arithmetic.rs:3-71).
+
+`PrimeField(P)` returns the class of residues mod P (the const-generic `PrimeField<P>`);
+`GoldilocksField` is the new 64-bit implementor (explicit PRIMITIVE_ELEMENT = 7) that the
+reference's `usize` arithmetic cannot represent.
+
+A single element is host data, exactly like the Rust value type: scalar operators are plain
+integer arithmetic on the canonical residue (this is the trait surface, not the data path).
+Everything that touches ARRAYS of elements -- `Polynomial` and the `vec_*` class methods
+below -- goes through the C ABI into the HIP kernels.
+"""
+import numpy as np
+
+from . import _lib as L
+
+_classes = {}
+
+
+def PrimeField(P):
+    """`PrimeField<const P: usize>` (prime/mod.rs:39-42).  Non-prime P panics (prime/mod.rs:92-100)."""
+    P = int(P)
+    if P in _classes:
+        return _classes[P]
+    L.check(L.lib.ronk_check_prime(P))          # const fn is_prime(P)
+    g = L.out_scalar(L.lib.ronk_primitive_element, P)
+
+    class _F(_Element):
+        ORDER = P
+        _G = g
+
+    _F.__name__ = _F.__qualname__ = "PrimeField<%d>" % P
+    _F.ZERO, _F.ONE = _F(0), _F(1)
+    _F.PRIMITIVE_ELEMENT = _F(g)                 # prime/mod.rs:87-90
+    _classes[P] = _F
+    return _F
+
+
+class _Element:
+    __slots__ = ("value",)
+    ORDER = None
+
+    def __init__(self, value=0):                 # PrimeField::new: value % P (prime/mod.rs:48-51)
+        self.value = int(value) % self.ORDER
+
+    # --- Field trait (field/mod.rs:17-51)
+    def inverse(self):                           # prime/mod.rs:62-72: None for zero
+        if self.value == 0:
+            return None
+        return self.pow(self.ORDER - 2)
+
+    def pow(self, power):                        # prime/mod.rs:74-84 (value of the recursion)
+        return type(self)(pow(self.value, int(power), self.ORDER) if power else 1)
+
+    # --- FiniteField trait (field/mod.rs:54-76)
+    @classmethod
+    def primitive_root_of_unity(cls, n):
+        return cls(L.out_scalar(L.lib.ronk_root_of_unity, cls.ORDER, cls._G, int(n)))  # panics: n must divide p^q - 1
+
+    # --- operator impls (prime/arithmetic.rs:3-71)
+    def _coerce(self, o):
+        return o if isinstance(o, type(self)) else type(self)(o)
+
+    def __add__(self, o): return type(self)(self.value + self._coerce(o).value)
+    def __sub__(self, o): return type(self)(self.value - self._coerce(o).value)
+    def __mul__(self, o): return type(self)(self.value * self._coerce(o).value)
+    def __neg__(self): return type(self)(-self.value)
+
+    def __truediv__(self, o):                    # self * rhs.inverse().unwrap()
+        inv = self._coerce(o).inverse()
+        if inv is None:
+            raise L.RonkPanic(L.ERR_ZERO_INVERSE)
+        return self * inv
+
+    def __mod__(self, o):                        # Rem: self - (self / rhs) * rhs
+        o = self._coerce(o)
+        return self - (self / o) * o
+
+    __radd__ = __add__
+    __rmul__ = __mul__
+    def __eq__(self, o): return isinstance(o, _Element) and o.ORDER == self.ORDER and o.value == self.value
+    def __hash__(self): return hash((self.ORDER, self.value))
+    def __int__(self): return self.value
+    def __index__(self): return self.value
+    def __repr__(self): return "%d" % self.value  # Display (prime/mod.rs:125-127)
+
+    # --- array forms of the operators: these run on the GPU through the C ABI
+    @classmethod
+    def _v(cls, fn, a, b):
+        a, b = L.arr(a), L.arr(b)
+        out = np.empty_like(a)
+        L.check(fn(cls.ORDER, L.ptr(a), L.ptr(b), L.ptr(out), a.size))
+        return out
+
+    @classmethod
+    def vec_add(cls, a, b): return cls._v(L.lib.ronk_vec_add, a, b)
+    @classmethod
+    def vec_sub(cls, a, b): return cls._v(L.lib.ronk_vec_sub, a, b)
+    @classmethod
+    def vec_mul(cls, a, b): return cls._v(L.lib.ronk_vec_mul, a, b)
+
+    @classmethod
+    def vec_neg(cls, a):
+        a = L.arr(a); out = np.empty_like(a)
+        L.check(L.lib.ronk_vec_neg(cls.ORDER, L.ptr(a), L.ptr(out), a.size))
+        return out
+
+    @classmethod
+    def vec_inv(cls, a):
+        a = L.arr(a); out = np.empty_like(a)
+        L.check(L.lib.ronk_vec_inv(cls.ORDER, L.ptr(a), L.ptr(out), a.size))
+        return out
+
+    @classmethod
+    def vec_pow(cls, a, e):
+        a = L.arr(a); out = np.empty_like(a)
+        L.check(L.lib.ronk_vec_pow(cls.ORDER, L.ptr(a), int(e), L.ptr(out), a.size))
+        return out
+
+
+PlutoBaseField = PrimeField(101)     # prime/mod.rs:26
+PlutoScalarField = PrimeField(17)    # prime/mod.rs:30
+AESField = PrimeField(2)             # prime/mod.rs:34
+GoldilocksField = PrimeField(L.GOLDILOCKS_P)

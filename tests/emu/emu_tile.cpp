@@ -1,0 +1,188 @@
+// emu_tile.cpp -- HOST EMULATOR of the HIP tile kernel (TEST INFRASTRUCTURE ONLY).
+//
+// Runs the very same ronk::tile_body<> template that ronk_ntt.hip launches on the GPU,
+// but on ucontext fibers (one fiber per work-item, barrier = yield), so the plan algebra
+// (strides, digit maps, twiddle exponents, LDS swizzle) can be checked against the oracle
+// in the CPU-only container.  It is built and run by tests/test_emu_kernel.py only; the
+// product library never contains or calls it.
+//
+// usage: emu_tile <log2n> <batch> <inverse 0|1> <max_logc>   (prints OK or the first mismatch)
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <vector>
+
+#include "../../oracle/ronk_oracle.h"
+#include "../../ronkathon_amd/csrc/plan.h"
+
+using namespace ronk;
+
+static ucontext_t g_sched;
+static std::vector<ucontext_t> g_ctx;
+static std::vector<char> g_stacks;
+static std::vector<char> g_done;
+static int g_cur;
+
+struct FiberArgs {
+  const TileArgs* a; u64* lds; u32 bid; int logr; bool inv;
+};
+static FiberArgs g_fa;
+
+static void fiber_barrier() { swapcontext(&g_ctx[g_cur], &g_sched); }
+
+template <int LOGR, bool INV>
+static void run_body(u32 tid) { tile_body<LOGR, INV>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); }
+
+template <bool INV>
+static void dispatch(int logr, u32 tid) {
+  switch (logr) {
+    case 4: run_body<4, INV>(tid); break;
+    case 5: run_body<5, INV>(tid); break;
+    case 6: run_body<6, INV>(tid); break;
+    case 7: run_body<7, INV>(tid); break;
+    case 8: run_body<8, INV>(tid); break;
+    case 9: run_body<9, INV>(tid); break;
+    case 10: run_body<10, INV>(tid); break;
+    case 11: run_body<11, INV>(tid); break;
+    case 12: run_body<12, INV>(tid); break;
+    default: abort();
+  }
+}
+
+static void fiber_main(int tid) {
+  if (g_fa.inv) dispatch<true>(g_fa.logr, (u32)tid); else dispatch<false>(g_fa.logr, (u32)tid);
+  g_done[tid] = 1;
+  swapcontext(&g_ctx[tid], &g_sched);
+}
+
+static void run_block(u32 T) {
+  const size_t STK = 64 * 1024;
+  if (g_ctx.size() < T) { g_ctx.resize(T); g_stacks.resize((size_t)T * STK); g_done.resize(T); }
+  for (u32 t = 0; t < T; t++) {
+    getcontext(&g_ctx[t]);
+    g_ctx[t].uc_stack.ss_sp = &g_stacks[(size_t)t * STK];
+    g_ctx[t].uc_stack.ss_size = STK;
+    g_ctx[t].uc_link = &g_sched;
+    makecontext(&g_ctx[t], (void (*)())fiber_main, 1, (int)t);
+    g_done[t] = 0;
+  }
+  for (;;) {
+    bool any = false;
+    for (u32 t = 0; t < T; t++) {
+      if (g_done[t]) continue;
+      any = true;
+      g_cur = (int)t;
+      swapcontext(&g_sched, &g_ctx[t]);
+    }
+    if (!any) break;
+  }
+}
+
+static u64 splitmix(u64& s) {
+  s += 0x9E3779B97F4A7C15ull;
+  u64 z = s;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64* tmp) {
+  std::vector<u64> lds;
+  for (auto& p : pd.passes) {
+    TileArgs a = p.args;
+    const u64* bufs_in[3] = {in, out, tmp};
+    u64* bufs_out[3] = {nullptr, out, tmp};
+    a.in = bufs_in[p.in_buf];
+    a.out = bufs_out[p.out_buf];
+    a.wr = pd.wr[p.wr_id].data();
+    if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
+    lds.assign(p.lds_bytes / 8 + 1, 0);
+    for (u32 bid = 0; bid < p.grid; bid++) {
+      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
+      run_block(p.block);
+    }
+  }
+}
+
+// dist mode: simulate all W ranks of the four-step in one process (the all-to-all is a memcpy)
+static int dist_main(int log2n, int world, bool inv) {
+  DistShape sh;
+  if (!dist_shape(log2n, world, &sh)) { printf("bad dist shape\n"); return 2; }
+  const u64 n = sh.n, per = n / sh.W;
+  std::vector<u64> x(n), ref(n), got(n);
+  u64 s = 0x5EED0005ull + log2n;
+  for (auto& v : x) { do v = splitmix(s); while (v >= gl64::P); }
+  std::vector<std::vector<u64>> loc(world), snd(world), rcv(world), res(world), tmp(world);
+  for (int g = 0; g < world; g++) {
+    loc[g].resize(per); snd[g].assign(per, 1); rcv[g].resize(per); res[g].assign(per, 2); tmp[g].assign(per, 3);
+    for (u64 r = 0; r < sh.R; r++)
+      for (u64 cl = 0; cl < sh.Cw; cl++) loc[g][r * sh.Cw + cl] = x[r * sh.C + g * sh.Cw + cl];
+    PlanDesc p1 = build_dist_phase1(log2n, inv, g, world);
+    run_plan(p1, inv, loc[g].data(), snd[g].data(), tmp[g].data());
+  }
+  const u64 blk = sh.Rw * sh.Cw;
+  for (int g = 0; g < world; g++)
+    for (int h = 0; h < world; h++) memcpy(&rcv[h][g * blk], &snd[g][h * blk], blk * 8);  // all_to_all_single
+  for (int h = 0; h < world; h++) {
+    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world);
+    run_plan(p2, inv, rcv[h].data(), res[h].data(), tmp[h].data());
+    for (u64 k2 = 0; k2 < sh.C; k2++)
+      for (u64 k1l = 0; k1l < sh.Rw; k1l++) got[(h * sh.Rw + k1l) + sh.R * k2] = res[h][k2 * sh.Rw + k1l];
+  }
+  int rc = inv ? orc_ifft(gl64::P, 7, x.data(), ref.data(), n) : orc_fft(gl64::P, 7, x.data(), ref.data(), n);
+  if (rc) return 1;
+  for (u64 i = 0; i < n; i++)
+    if (got[i] != ref[i]) { printf("DIST MISMATCH at %llu\n", (unsigned long long)i); return 1; }
+  printf("OK dist log2n=%d world=%d inv=%d\n", log2n, world, (int)inv);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 5 && !strcmp(argv[1], "dist")) return dist_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0);
+  if (argc < 5) { fprintf(stderr, "usage: emu_tile log2n batch inverse max_logc\n"); return 2; }
+  int log2n = atoi(argv[1]);
+  u64 batch = strtoull(argv[2], 0, 10);
+  bool inv = atoi(argv[3]) != 0;
+  int max_logc = atoi(argv[4]);
+  u64 n = (u64)1 << log2n;
+  PlanDesc pd = build_plan(log2n, batch, inv, max_logc);
+
+  std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
+  u64 s = 0x5EED0000ull + log2n;
+  for (auto& v : in) { do v = splitmix(s); while (v >= gl64::P); }
+  // adversarial corners
+  in[0] = gl64::P - 1; if (n > 1) in[n - 1] = gl64::P - 1; if (n > 2) in[1] = 0;
+
+  std::vector<u64> lds;
+  for (auto& p : pd.passes) {
+    TileArgs a = p.args;
+    const u64* bufs_in[3] = {in.data(), out.data(), tmp.data()};
+    u64* bufs_out[3] = {nullptr, out.data(), tmp.data()};
+    a.in = bufs_in[p.in_buf];
+    a.out = bufs_out[p.out_buf];
+    a.wr = pd.wr[p.wr_id].data();
+    if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
+    lds.assign(p.lds_bytes / 8 + 1, 0);
+    printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu\n", p.logr, a.logc, a.tiles,
+           a.nb1, a.nb2, p.grid, p.block, p.lds_bytes);
+    for (u32 bid = 0; bid < p.grid; bid++) {
+      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
+      run_block(p.block);
+    }
+  }
+  for (u64 b = 0; b < batch; b++) {
+    int rc = inv ? orc_ifft(gl64::P, 7, &in[b * n], &ref[b * n], n) : orc_fft(gl64::P, 7, &in[b * n], &ref[b * n], n);
+    if (rc) { printf("oracle rc %d\n", rc); return 1; }
+  }
+  for (u64 i = 0; i < n * batch; i++)
+    if (out[i] != ref[i]) {
+      printf("MISMATCH at %llu (poly %llu, k %llu): got %llu want %llu\n", (unsigned long long)i,
+             (unsigned long long)(i / n), (unsigned long long)(i % n), (unsigned long long)out[i],
+             (unsigned long long)ref[i]);
+      return 1;
+    }
+  printf("OK log2n=%d batch=%llu inv=%d\n", log2n, (unsigned long long)batch, (int)inv);
+  return 0;
+}

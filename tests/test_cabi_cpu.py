@@ -1,0 +1,98 @@
+"""CPU-side checks of the boundary: the library loads, exports every symbol include/ronk_ntt.h
+declares, its host-side integer logic agrees with the oracle, and without a GPU every compute
+entry point fails loudly (no CPU fallback).  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header():
+    from ronkathon_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "ronk_ntt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ronk_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = C.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libronk_ntt.so does not export %s" % name
+    assert declared == L.EXPORTS, "ctypes table and header disagree: %s" % (set(declared) ^ set(L.EXPORTS))
+
+
+def test_host_logic_matches_oracle():
+    from ronkathon_amd import _lib as L
+    for p in (2, 3, 5, 17, 101, 127, 257, 65537, 3 * 2**30 + 1, L.GOLDILOCKS_P):
+        assert L.lib.ronk_check_prime(p) == 0
+        try:
+            g = L.out_scalar(L.lib.ronk_primitive_element, p)
+        except L.RonkPanic as e:
+            # the reference's heuristic panics "generator not found" for P = 3 (its loop never runs)
+            assert e.code == L.ERR_NO_GENERATOR
+            with pytest.raises(orc.OraclePanic):
+                orc.find_primitive_element(p)
+            continue
+        if p == L.GOLDILOCKS_P:
+            assert g == 7
+        elif p == 2:
+            assert g == 1
+        else:
+            assert g == orc.find_primitive_element(p)
+        for n in (1, 2, 3, 4, 5, 8, 16, 64, 2**16):
+            if (p - 1) % n == 0:
+                assert L.out_scalar(L.lib.ronk_root_of_unity, p, g, n) == orc.primitive_root_of_unity(p, g, n)
+            else:
+                with pytest.raises(L.RonkPanic) as e:
+                    L.out_scalar(L.lib.ronk_root_of_unity, p, g, n)
+                assert e.value.code == L.ERR_NO_ROOT
+    for p in (100, 4, 9, 2**32 + 1 + 0, 0xFFFFFFFF00000001 - 2):
+        assert (L.lib.ronk_check_prime(p) == 0) == orc.is_prime(p)
+    assert L.lib.ronk_strerror(-1) == b"n must divide p^q - 1"
+    assert L.lib.ronk_strerror(-4) == b"input is not a prime number"
+
+
+def test_no_cpu_fallback():
+    from ronkathon_amd import _lib as L
+    if L.device_count() > 0:
+        pytest.skip("a GPU is present")
+    a = np.arange(4, dtype=np.uint64)
+    out = np.empty_like(a)
+    assert L.lib.ronk_vec_add(101, L.ptr(a), L.ptr(a), L.ptr(out), 4) == L.ERR_NO_DEVICE
+    assert L.lib.ronk_dft(101, 2, L.ptr(a), L.ptr(out), 4) == L.ERR_NO_DEVICE
+    h = C.c_void_p()
+    assert L.lib.ronk_plan_create(C.byref(h), L.GOLDILOCKS_P, 7, 10, 1, -1) == L.ERR_NO_DEVICE
+    # argument errors are reported before the device is needed, with the reference's panic condition
+    assert L.lib.ronk_plan_create(C.byref(h), 101, 2, 3, 1, -1) == L.ERR_NO_ROOT
+    assert L.lib.ronk_plan_create(C.byref(h), 100, 2, 1, 1, -1) == L.ERR_NOT_PRIME
+    import ronkathon_amd as R
+    with pytest.raises(R.RonkPanic) as e:
+        R.Polynomial.new(R.PlutoBaseField, [1, 2, 3, 4]).fft()
+    assert e.value.code == L.ERR_NO_DEVICE
+
+
+def test_host_mirror_scalar_surface(refvec):
+    import ronkathon_amd as R
+    for name, op in (("field_add", "__add__"), ("field_sub", "__sub__"), ("field_mul", "__mul__")):
+        for p, a, b, r in refvec[name]["cases"]:
+            F = R.PrimeField(p)
+            assert getattr(F(a), op)(F(b)) == F(r)
+    for p, a, e, r in refvec["field_pow"]["cases"]:
+        assert R.PrimeField(p)(a).pow(e) == R.PrimeField(p)(r)
+    for p, a, r in refvec["field_inverse"]["cases"]:
+        assert R.PrimeField(p)(a).inverse() == R.PrimeField(p)(r)
+    assert R.PlutoBaseField(0).inverse() is None
+    with pytest.raises(R.RonkPanic):
+        R.PlutoBaseField(3) / R.PlutoBaseField(0)
+    for p, a, r in refvec["field_halve"]["cases"]:
+        assert R.PrimeField(p)(a) / R.PrimeField(p)(2) == R.PrimeField(p)(r)
+    with pytest.raises(R.RonkPanic):
+        R.PrimeField(100)
+    assert [int(R.PrimeField(p).PRIMITIVE_ELEMENT) for p in (101, 17, 127)] == [2, 14, 3]
+    assert int(R.GoldilocksField.PRIMITIVE_ELEMENT) == 7
+    for p, n, w in refvec["roots_of_unity"]["cases"]:
+        assert int(R.PrimeField(p).primitive_root_of_unity(n)) == w

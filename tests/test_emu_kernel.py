@@ -1,0 +1,44 @@
+"""Runs the HIP tile kernel's source (ronkathon_amd/csrc/ntt_tile.h + plan.h) under the host
+fiber emulator (tests/emu/emu_tile.cpp) against the oracle.  Checks the plan algebra -- strides,
+digit maps, twiddle exponents, LDS swizzle, the multi-GPU phase split -- on the CPU.  The
+emulator is test infrastructure: the product library does not contain it."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build", "emu_tile")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    srcs = [os.path.join(ROOT, "tests", "emu", "emu_tile.cpp")]
+    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "plan.h", "gl64.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
+        obj = os.path.join(ROOT, "build", "orc_emu.o")
+        subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", EXE, srcs[0], obj])
+    return EXE
+
+
+def run(emu, *args):
+    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("OK"), out.stdout[-400:] + out.stderr[-400:]
+
+
+@pytest.mark.parametrize("k", [4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_single_pass(emu, k):
+    run(emu, k, 3, 0, 4)
+    run(emu, k, 2, 1, 4)
+
+
+@pytest.mark.parametrize("k,batch,inv,logc", [(13, 2, 0, 4), (16, 1, 1, 4), (17, 1, 0, 3), (20, 1, 0, 4), (22, 1, 0, 4)])
+def test_two_pass(emu, k, batch, inv, logc):
+    run(emu, k, batch, inv, logc)
+
+
+def test_dist_phases(emu):
+    for k, w, inv in ((12, 1, 0), (13, 2, 0), (16, 4, 1), (20, 8, 0)):
+        run(emu, "dist", k, w, inv)

@@ -1,0 +1,292 @@
+"""Parity of the HIP path (through the C ABI) against the oracle, the reference's golden vectors
+and size-independent properties.  Bit-exact: all integer work.  Needs a real MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from conftest import splitmix_field
+
+pytestmark = pytest.mark.gpu
+
+GP, GG = 0xFFFFFFFF00000001, 7
+
+
+@pytest.fixture(scope="module")
+def R():
+    import ronkathon_amd as R
+    assert R.device_count() >= 1
+    return R
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import oracle
+    return oracle
+
+
+def adversarial(n):
+    """all-zero, all-(p-1), single 1 at index 0 / n-1"""
+    z = np.zeros(n, dtype=np.uint64)
+    m = np.full(n, GP - 1, dtype=np.uint64)
+    e0 = z.copy(); e0[0] = 1
+    e1 = z.copy(); e1[n - 1] = 1
+    return [z, m, e0, e1]
+
+
+# ---------------------------------------------------------------- reference golden vectors on the GPU path
+def test_field_kats_on_gpu(R, refvec):
+    for name, fn in (("field_add", "vec_add"), ("field_sub", "vec_sub"), ("field_mul", "vec_mul")):
+        for p in (17, 101):
+            F = R.PrimeField(p)
+            cases = [c for c in refvec[name]["cases"] if c[0] == p]
+            a = [c[1] % p for c in cases]; b = [c[2] % p for c in cases]
+            assert getattr(F, fn)(a, b).tolist() == [c[3] for c in cases]
+    for p, a, e, r in refvec["field_pow"]["cases"]:
+        assert R.PrimeField(p).vec_pow([a], e).tolist() == [r]
+    for p in (17, 101):
+        F = R.PrimeField(p)
+        cases = [c for c in refvec["field_inverse"]["cases"] if c[0] == p]
+        assert F.vec_inv([c[1] for c in cases]).tolist() == [c[2] for c in cases]
+        with pytest.raises(R.RonkPanic) as e:
+            F.vec_inv([1, 0, 2])
+        assert e.value.code == -2
+        halves = [c for c in refvec["field_halve"]["cases"] if c[0] == p]
+        inv2 = int(F.vec_inv([2])[0])
+        assert F.vec_mul([c[1] for c in halves], [inv2] * len(halves)).tolist() == [c[2] for c in halves]
+        # exhaustive identities (prime/mod.rs:346-384)
+        allv = np.arange(p, dtype=np.uint64)
+        assert np.array_equal(F.vec_add(allv, F.vec_neg(allv)), np.zeros(p, dtype=np.uint64))
+        nz = allv[1:]
+        assert np.array_equal(F.vec_inv(F.vec_inv(nz)), nz)
+        assert np.array_equal(F.vec_mul(nz, F.vec_inv(nz)), np.ones(p - 1, dtype=np.uint64))
+
+
+def test_polynomial_kats_on_gpu(R, refvec):
+    F = R.PlutoBaseField
+    v = refvec
+    P = R.Polynomial
+    poly = P.new(F, [1, 2, 3, 4])
+    for p, c, x, y in v["poly_eval"]["cases"]:
+        assert P.new(R.PrimeField(p), c).evaluate(x) == R.PrimeField(p)(y)
+    assert poly.dft().coefficients.tolist() == v["poly_dft"]["out"]
+    assert poly.fft().coefficients.tolist() == v["poly_fft"]["out"]
+    assert poly.fft().ifft() == poly
+    assert poly.dft().basis.nodes.tolist() == [1, 10, 100, 91]
+    assert poly.dft().evaluate(v["lagrange_eval"]["x"]) == F(v["lagrange_eval"]["y"])
+    assert poly.degree() == 3 and poly.leading_coefficient() == F(4)
+    assert poly.pow_mult(2, 5).coefficients.tolist() == v["pow_mult"]["out"]
+    a, b = P.new(F, [1, 2, 3, 4]), P.new(F, [5, 6, 7, 8, 9])
+    assert (b + a).coefficients.tolist() == v["poly_add"]["out"]
+    for x, y, r in v["poly_sub"]["cases"]:
+        assert (P.new(F, x) - P.new(F, y)).coefficients.tolist() == r
+    assert (-a).coefficients.tolist() == v["poly_neg"]["out"]
+    for x, y, q in v["poly_div"]["cases"]:
+        assert (P.new(F, x) / P.new(F, y)).coefficients.tolist() == q
+    for x, y, r in v["poly_rem"]["cases"]:
+        assert (P.new(F, x) % P.new(F, y)).coefficients.tolist() == r
+    for x, y, c in v["poly_mul"]["cases"]:
+        assert (P.new(F, x) * P.new(F, y)).coefficients.tolist() == c
+    # no roots of unity => panic (polynomial/tests.rs:46-55)
+    with pytest.raises(R.RonkPanic) as e:
+        P.new(F, [1, 2, 3]).dft()
+    assert e.value.code == -1
+    with pytest.raises(R.RonkPanic) as e:
+        P.new(R.PrimeField(127), [1, 2, 3]).fft()
+    assert e.value.code == -3
+    with pytest.raises(R.RonkPanic) as e:
+        P.new(F, list(range(8))).fft()
+    assert e.value.code == -1
+
+
+def test_callers_on_gpu(R, refvec, orc):
+    from ronkathon_amd.callers import Message, kzg_open_quotient
+    d = refvec["rs_encode"]
+    xs, ys = Message(R.PrimeField(d["p"]), d["msg"]).encode(d["n"])
+    assert xs.tolist() == d["x"] and ys.tolist() == d["y"]
+    xs, ys = Message(R.PrimeField(127), [1, 2, 3]).encode(7)
+    ox, oy = orc.rs_encode(127, 3, [1, 2, 3], 7)
+    assert xs.tolist() == ox.tolist() and ys.tolist() == oy.tolist()
+    d = refvec["kzg_open_quotient"]
+    assert kzg_open_quotient(R.PrimeField(d["p"]), d["coeffs"], d["z"]).tolist() == d["quot"]
+    # reference quirks (oracle header): untrimmed-length loop guard, zero divisor panic, Lagrange eval at a node
+    F = R.PlutoBaseField
+    q, r = R.Polynomial.new(F, [1, 2, 3]).quotient_and_remainder(R.Polynomial.new(F, [1, 1, 0, 0]))
+    assert q.coefficients.tolist() == [0, 0, 0] and r.coefficients.tolist() == [1, 2, 3]
+    with pytest.raises(R.RonkPanic) as e:
+        R.Polynomial.new(F, [1, 2, 3]) / R.Polynomial.new(F, [0, 0])
+    assert e.value.code == -6
+    lag = R.Polynomial.new(F, [1, 2, 3, 4]).dft()
+    assert lag.evaluate(10) == F(0)
+
+
+def test_divrem_eval_random_vs_oracle(R, orc):
+    for p, g in ((101, 2), (GP, GG)):
+        F = R.PrimeField(p)
+        for d, d2, seed in ((40, 7, 1), (300, 300, 2), (513, 2, 3), (64, 65, 4)):
+            a = splitmix_field(seed, d, p); b = splitmix_field(seed + 100, d2, p)
+            if b[-1] == 0:
+                b[-1] = 1
+            q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+            oq, orr = orc.poly_divrem(p, a, b)
+            assert np.array_equal(q.coefficients, oq) and np.array_equal(r.coefficients, orr)
+            x = int(splitmix_field(seed + 7, 1, p)[0])
+            assert int(R.Polynomial.new(F, a).evaluate(x)) == orc.poly_eval(p, a, x)
+    a = splitmix_field(11, 100000)
+    assert int(R.Polynomial.new(R.GoldilocksField, a).evaluate(12345)) == orc.poly_eval(GP, a, 12345)
+
+
+# ---------------------------------------------------------------- Goldilocks: derived vectors and the oracle
+def test_goldilocks_derived(R, glvec):
+    F = R.GoldilocksField
+    v = glvec
+    assert F.PRIMITIVE_ELEMENT == F(7)
+    for k, w in v["roots"].items():
+        assert int(F.primitive_root_of_unity(1 << int(k))) == w
+    e = v["field_edge"]; vals = e["values"]
+    A = np.repeat(np.array(vals, dtype=np.uint64), len(vals)); B = np.tile(np.array(vals, dtype=np.uint64), len(vals))
+    assert F.vec_add(A, B).tolist() == [x for row in e["add"] for x in row]
+    assert F.vec_sub(A, B).tolist() == [x for row in e["sub"] for x in row]
+    assert F.vec_mul(A, B).tolist() == [x for row in e["mul"] for x in row]
+    nzv = [x for x in vals if x]
+    assert F.vec_inv(nzv).tolist() == [x for x in e["inv"] if x is not None]
+    assert R.Polynomial.new(F, [1, 2, 3, 4]).fft().coefficients.tolist() == v["dft_1234"]
+    for case in v["dft_random"] + v["dft_non_pow2"]:
+        assert R.Polynomial.new(F, case["in"]).dft().coefficients.tolist() == case["out"]
+    for case in v["dft_random"]:
+        assert R.Polynomial.new(F, case["in"]).fft().coefficients.tolist() == case["out"]
+        assert R.Polynomial.new_lagrange(F, case["out"]).ifft().coefficients.tolist() == case["in"]
+    for case in v["mul_random"]:
+        assert (R.Polynomial.new(F, case["a"]) * R.Polynomial.new(F, case["b"])).coefficients.tolist() == case["out"]
+
+
+@pytest.mark.parametrize("k", list(range(0, 21)))
+def test_ntt_vs_oracle_all_sizes(R, orc, k):
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    plan = L.Plan(GP, GG, k)
+    cases = [splitmix_field(0x5EED0000 + k, n)] + (adversarial(n) if k in (4, 8, 11, 13, 16) else [])
+    for x in cases:
+        y = plan.forward(x)
+        assert np.array_equal(y, orc.fft(GP, GG, x)), "forward 2^%d" % k
+        assert np.array_equal(plan.inverse(y), x), "roundtrip 2^%d" % k
+        assert np.array_equal(plan.inverse(x), orc.ifft(GP, GG, x)), "inverse 2^%d" % k
+    plan.close()
+
+
+@pytest.mark.parametrize("k,batch", [(4, 1000), (6, 33), (8, 64), (10, 7), (12, 17), (13, 5), (16, 3)])
+def test_batched_ragged_vs_oracle(R, orc, k, batch):
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    plan = L.Plan(GP, GG, k, batch)
+    x = splitmix_field(77 + k, n * batch)
+    y = plan.forward(x)
+    for b in range(batch):
+        assert np.array_equal(y[b * n:(b + 1) * n], orc.fft(GP, GG, x[b * n:(b + 1) * n])), (k, b)
+    assert np.array_equal(plan.inverse(y), x)
+    plan.close()
+
+
+def test_config2_roundtrip_2_16(R, orc):
+    """BASELINE configs[1]: forward+inverse NTT, degree 2^16, bit-exact round trip"""
+    from ronkathon_amd import _lib as L
+    x = splitmix_field(0x5EED0002, 1 << 16)
+    plan = L.Plan(GP, GG, 16)
+    y, nodes = plan.forward(x, nodes=True)
+    assert np.array_equal(y, orc.fft(GP, GG, x))
+    assert np.array_equal(nodes, orc.lagrange_nodes(GP, GG, 1 << 16))
+    assert np.array_equal(plan.inverse(y), x)
+    plan.close()
+
+
+def test_config3_full_size_2_22(R, orc):
+    """BASELINE configs[2] at full size: NTT 2^22 vs the oracle, and polynomial multiply with NTT size
+    2^22 checked through size-independent properties (evaluation homomorphism, linearity)."""
+    from ronkathon_amd import _lib as L
+    n = 1 << 22
+    x = splitmix_field(0x5EED0003, n)
+    plan = L.Plan(GP, GG, 22)
+    y = plan.forward(x)
+    assert np.array_equal(y, orc.fft(GP, GG, x))
+    assert np.array_equal(plan.inverse(y), x)
+    # linearity: NTT(a + b) == NTT(a) + NTT(b)
+    b = splitmix_field(0x5EED0033, n)
+    F = R.GoldilocksField
+    assert np.array_equal(plan.forward(F.vec_add(x, b)), F.vec_add(y, plan.forward(b)))
+    plan.close()
+    a, c = x[: n // 2], b[: n // 2]
+    prod = (R.Polynomial.new(F, a) * R.Polynomial.new(F, c)).coefficients
+    assert prod.size == n - 1
+    for pt in (2, 0xDEADBEEFCAFE, GP - 1):
+        lhs = orc.poly_eval(GP, prod, pt)
+        assert lhs == orc.mul(GP, orc.poly_eval(GP, a, pt), orc.poly_eval(GP, c, pt))
+    # schoolbook cross-check of the low and high ends (exact): c_0, c_1, c_{m-1}
+    assert int(prod[0]) == orc.mul(GP, int(a[0]), int(c[0]))
+    assert int(prod[-1]) == orc.mul(GP, int(a[-1]), int(c[-1]))
+    assert int(prod[1]) == orc.add(GP, orc.mul(GP, int(a[0]), int(c[1])), orc.mul(GP, int(a[1]), int(c[0])))
+
+
+def test_poly_mul_vs_schoolbook(R, orc):
+    F = R.GoldilocksField
+    for d, d2 in ((1, 1), (17, 17), (64, 1), (100, 157), (1000, 3000), (5000, 5000)):
+        a = splitmix_field(d, d); b = splitmix_field(d2 + 1, d2)
+        got = (R.Polynomial.new(F, a) * R.Polynomial.new(F, b)).coefficients
+        assert np.array_equal(got, orc.poly_mul(GP, a, b)), (d, d2)
+    # config 1: F_101, 17 x 17 coefficients (degree 16 x 16) -- schoolbook kernel
+    a = splitmix_field(5, 17, 101); b = splitmix_field(6, 17, 101)
+    got = (R.Polynomial.new(R.PlutoBaseField, a) * R.Polynomial.new(R.PlutoBaseField, b)).coefficients
+    assert got.size == 33 and np.array_equal(got, orc.poly_mul(101, a, b))
+
+
+def test_config4_batched_1024_x_2_16(R, orc):
+    """BASELINE configs[3]: 1024 polynomials x 2^16; spot-check rows against the oracle, round-trip all"""
+    from ronkathon_amd import _lib as L
+    n, batch = 1 << 16, 1024
+    x = splitmix_field(0x5EED0004, n * batch)
+    plan = L.Plan(GP, GG, 16, batch)
+    y = plan.forward(x)
+    for b in (0, 1, 511, 1023):
+        assert np.array_equal(y[b * n:(b + 1) * n], orc.fft(GP, GG, x[b * n:(b + 1) * n]))
+    assert np.array_equal(plan.inverse(y), x)
+    plan.close()
+
+
+def test_generic_prime_pow2_ntt(R, orc):
+    """a generic odd prime with 2-adicity: p = 3*2^30+1 (Montgomery radix-2 path), and Goldilocks with g != 7"""
+    from ronkathon_amd import _lib as L
+    p = 3 * 2**30 + 1
+    g = orc.find_primitive_element(p)
+    for k in (0, 1, 3, 10, 14):
+        x = splitmix_field(k, 1 << k, p)
+        plan = L.Plan(p, g, k)
+        y = plan.forward(x)
+        assert np.array_equal(y, orc.fft(p, g, x))
+        assert np.array_equal(plan.inverse(y), x)
+        plan.close()
+    x = splitmix_field(3, 1 << 12)
+    plan = L.Plan(GP, 3, 12)   # the reference's heuristic "generator" for Goldilocks
+    assert np.array_equal(plan.forward(x), orc.fft(GP, 3, x))
+    plan.close()
+    with pytest.raises(R.RonkPanic) as e:
+        L.Plan(101, 2, 3)      # 8 does not divide 100
+    assert e.value.code == -1
+    with pytest.raises(R.RonkPanic) as e:
+        L.Plan(100, 2, 1)
+    assert e.value.code == -4
+
+
+def test_dist_fourstep_single_gpu(R, orc):
+    """multi-GPU four-step phases executed rank by rank on ONE GPU (the exchange is a host copy)"""
+    from ronkathon_amd.dist import fourstep_single_process
+    for log2n, world, inv in ((12, 1, False), (16, 2, False), (18, 4, True), (20, 8, False), (26, 8, False)):
+        x = splitmix_field(0x5EED0005 + log2n, 1 << log2n)
+        got = fourstep_single_process(x, world, inverse=inv)
+        ref = orc.ifft(GP, GG, x) if inv else orc.fft(GP, GG, x)
+        assert np.array_equal(got, ref), (log2n, world, inv)
+
+
+def test_determinism(R):
+    from ronkathon_amd import _lib as L
+    x = splitmix_field(1234, 1 << 20)
+    plan = L.Plan(GP, GG, 20)
+    a = plan.forward(x); b = plan.forward(x)
+    assert np.array_equal(a, b)
+    plan.close()
