@@ -100,7 +100,7 @@ RONK_HD u64 mul_2exp(u64 x) {
   constexpr int q = K / 32, s = K % 32;
   u32 x0 = (u32)x, x1 = (u32)(x >> 32);
   u32 y0, y1, y2;
-  if (s == 0) {
+  if constexpr (s == 0) {
     y0 = x0; y1 = x1; y2 = 0;
   } else {
     y0 = x0 << s;

@@ -115,7 +115,10 @@ RONK_HD u32 swz_row(u32 row) { return row ^ ((row >> 4) & 15u); }
 // ---- the tile body --------------------------------------------------------------------
 //
 // LOGR = 4*(Q-1) + LOGLAST, Q rounds; radices 16,..,16,2^LOGLAST.
-template <int LOGR, bool INV, class Barrier>
+// ABL: ablation mask for tools/ubench only (wrong results by design; 0 in the product):
+//   1 no inter-pass twiddle   2 no round twiddles   4 no butterflies   8 no LDS exchange
+//   16 no global loads        32 no global stores
+template <int LOGR, bool INV, int ABL = 0, class Barrier>
 RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
   constexpr int R = 1 << LOGR;
   constexpr int Q = (LOGR + 3) / 4;              // rounds
@@ -129,70 +132,94 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   const u32 c = tid & (C - 1);
   const u32 m = tid >> logc;  // [0, M)
 
-  // block -> (tile, b1, b2)
-  u32 t = bid % a.tiles;
-  u32 bb = bid / a.tiles;
-  u32 b1 = bb % a.nb1, b2 = bb / a.nb1;
-  const u64 col = (u64)t * C + c;
-  const u64* in = a.in + b1 * a.in_sb1 + b2 * a.in_sb2 + (i64)col * a.in_sc;
-  u64* out = a.out + b1 * a.out_sb1 + b2 * a.out_sb2 + (i64)col * a.out_sc;
+  // block -> (tile, b1, b2).  Everything that depends only on the block is wave-uniform (SGPRs);
+  // per-lane addressing is a 32-bit element offset from that base (a sub-problem has < 2^32 elements).
+  const u32 t = bid % a.tiles;
+  const u32 bb = bid / a.tiles;
+  const u32 b1 = bb % a.nb1, b2 = bb / a.nb1;
+  const u32 col0 = t << logc;
+  const u32 col = col0 + c;
+  const u64* in = a.in + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)col0 * a.in_sc;
+  u64* out = a.out + (i64)b1 * a.out_sb1 + (i64)b2 * a.out_sb2 + (i64)col0 * a.out_sc;
+  const u32 in_sj = (u32)a.in_sj, out_sk = (u32)a.out_sk;
+  const u32 in_lane = c * (u32)a.in_sc, out_lane = c * (u32)a.out_sc;
 
   const bool live = col < a.ncols;  // ragged last tile: dead columns compute on zeros
 
   u64 x[16];
 
   // ---- round 1: j = j1*M + m, straight from HBM
-  const u32 jmask = (1u << a.js_log) - 1;
-  i64 joff[16];
+  u32 joff[16];
+  if (a.js_log < 31) {  // blocked rows (multi-GPU receive buffer)
+    const u32 jmask = (1u << a.js_log) - 1, hi = (u32)a.in_sj_hi;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const u32 j = i * M + m;
-    joff[i] = (i64)(j >> a.js_log) * a.in_sj_hi + (i64)(j & jmask) * a.in_sj;
+    for (int i = 0; i < 16; i++) {
+      const u32 j = i * M + m;
+      joff[i] = in_lane + (j >> a.js_log) * hi + (j & jmask) * in_sj;
+    }
+  } else {
+    const u32 j0 = in_lane + m * in_sj, step = M * in_sj;
+#pragma unroll
+    for (int i = 0; i < 16; i++) joff[i] = j0 + i * step;
   }
+  if (ABL & 16) {
 #pragma unroll
-  for (int i = 0; i < 16; i++) x[i] = live ? in[joff[i]] : 0;
+    for (int i = 0; i < 16; i++) x[i] = (u64)(tid * 16 + i);
+  } else if (live) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = in[joff[i]];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = 0;
+  }
   if (a.in2 && live) {
-    const u64* in2 = a.in2 + b1 * a.in_sb1 + b2 * a.in_sb2 + (i64)col * a.in_sc;
+    const u64* in2 = a.in2 + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)col0 * a.in_sc;
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], in2[joff[i]]);
   }
-  Dif<16, INV>::run(x);
+  if (!(ABL & 4)) Dif<16, INV>::run(x);
 
-  u32 klow[16];  // natural output row of register i, minus the last digit's contribution
+  u32 klow[16];  // natural output row of register i
   if (Q == 1) {
 #pragma unroll
     for (int i = 0; i < 16; i++) klow[i] = brev(i, 4);
   } else {
+    u64* const lc = lds + c;
     // twiddle omega_R^{m*k1}, then park at row k1*M + m
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1) x[i] = gl64::mul(x[i], a.wr[m * k1]);
-      lds[((u64)swz_row(k1 * M + m) << logc) + c] = x[i];
+      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], a.wr[m * k1]);
+      if (!(ABL & 8)) lc[swz_row(k1 * M + m) << logc] = x[i];
     }
-    barrier();
+    if (!(ABL & 8)) barrier();
 
     if (Q == 3) {
       // ---- round 2: thread (d1, d3) = (m / RLAST, m % RLAST), register digit d2
       const u32 d1 = m >> LOGLAST, d3 = m & (RLAST - 1);
       const u32 base = d1 * (16 * RLAST) + d3;
 #pragma unroll
-      for (int i = 0; i < 16; i++) x[i] = lds[((u64)swz_row(base + i * RLAST) << logc) + c];
-      Dif<16, INV>::run(x);
+      for (int i = 0; i < 16; i++)
+        if (!(ABL & 8)) x[i] = lc[swz_row(base + i * RLAST) << logc];
+      if (!(ABL & 4)) Dif<16, INV>::run(x);
+      const u32 tstep = 16 * d3;  // omega_{R/16}^{d3*k2} = omega_R^{16*d3*k2}
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
-        if (k2) x[i] = gl64::mul(x[i], a.wr[16 * d3 * k2]);  // omega_{R/16}^{d3*k2}
-        lds[((u64)swz_row(base + k2 * RLAST) << logc) + c] = x[i];
+        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], a.wr[tstep * k2]);
+        if (!(ABL & 8)) lc[swz_row(base + k2 * RLAST) << logc] = x[i];
       }
-      barrier();
+      if (!(ABL & 8)) barrier();
     }
 
     // ---- last round: thread m owns rows 16m .. 16m+15; row = v*RLAST + d_last
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = lds[((u64)swz_row(16 * m + i) << logc) + c];
+    for (int i = 0; i < 16; i++)
+      if (!(ABL & 8)) x[i] = lc[swz_row(16 * m + i) << logc];
+    if (!(ABL & 4)) {
 #pragma unroll
-    for (int g = 0; g < 16 / RLAST; g++) Dif<RLAST, INV>::run(x + g * RLAST);
+      for (int g = 0; g < 16 / RLAST; g++) Dif<RLAST, INV>::run(x + g * RLAST);
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 v = m * (16 / RLAST) + (i >> LOGLAST);           // (d1[,d2]) pair index
@@ -202,14 +229,16 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   }
 
   // ---- output: optional inter-pass twiddle, optional scale, store at natural row k
-  if (a.tw_log) {
-    const u64 X = a.xc * col + a.xb1 * b1 + a.xb2 * b2 + a.x0;
-    const u64 Yb = a.yb1 * b1 + a.yb2 * b2 + a.y0;
-    const u64 nmask = ((u64)1 << a.tw_log) - 1;
-    const u64 lmask = ((u64)1 << a.tw_lo_bits) - 1;
+  if (a.tw_log && !(ABL & 1)) {
+    // exponent (X*Y) mod 2^tw_log with tw_log <= 32: the low 32 bits of a 32-bit product suffice
+    const u32 X = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
+    const u32 Yb = (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0;
+    const u32 yk = (u32)a.yk;
+    const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
+    const u32 lmask = (1u << a.tw_lo_bits) - 1;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      const u64 e = (X * (a.yk * klow[i] + Yb)) & nmask;
+      const u32 e = (X * (yk * klow[i] + Yb)) & nmask;
       const u64 w = gl64::mul(a.tw_lo[e & lmask], a.tw_hi[e >> a.tw_lo_bits]);
       x[i] = gl64::mul(x[i], w);
     }
@@ -218,9 +247,14 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], a.scale);
   }
-  if (live) {
+  if (ABL & 32) {
+    u64 acc = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) out[(i64)klow[i] * a.out_sk] = x[i];
+    for (int i = 0; i < 16; i++) acc ^= x[i];
+    if (acc == 0x123456789ull) out[0] = acc;  // keeps x live, never true in practice
+  } else if (live) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[out_lane + klow[i] * out_sk] = x[i];
   }
 }
 

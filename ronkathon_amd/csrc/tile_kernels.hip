@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(1024) ntt_tile_kernel(const TileArgs a) {
   const u32 nb = gridDim.x, b = blockIdx.x;
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tile_body<LOGR, INV>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+  tile_body<LOGR, INV, 0>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
 }
 
 template <int LOGR, bool INV>

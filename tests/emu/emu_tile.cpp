@@ -33,7 +33,7 @@ static FiberArgs g_fa;
 static void fiber_barrier() { swapcontext(&g_ctx[g_cur], &g_sched); }
 
 template <int LOGR, bool INV>
-static void run_body(u32 tid) { tile_body<LOGR, INV>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); }
+static void run_body(u32 tid) { tile_body<LOGR, INV, 0>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); }
 
 template <bool INV>
 static void dispatch(int logr, u32 tid) {

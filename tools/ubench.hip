@@ -1,0 +1,158 @@
+// tools/ubench.hip -- developer micro-benchmarks (not part of the product library).
+//   * ablation timings of the 2^22 plan's two tile passes (ntt_tile.h ABL masks)
+//   * raw field-op issue rates (mul / add / sub / shift-mul) and memory-pattern floors
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/ubench.hip -o build/ubench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <functional>
+#include <vector>
+
+#include "../ronkathon_amd/csrc/plan.h"
+
+using namespace ronk;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <int LOGR, bool INV, int ABL>
+__global__ void __launch_bounds__(1024) abl_kernel(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u32 nb = gridDim.x, b = blockIdx.x;
+  const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+  const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  tile_body<LOGR, INV, ABL>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) mul_rate_kernel(u64* out, u64 w, int iters) {
+  u64 x[K];
+  for (int k = 0; k < K; k++) x[k] = threadIdx.x * 7919 + blockIdx.x + k + 1;
+  for (int i = 0; i < iters; i++)
+#pragma unroll
+    for (int k = 0; k < K; k++) x[k] = gl64::mul(x[k], w);
+  u64 acc = 0;
+  for (int k = 0; k < K; k++) acc ^= x[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+template <int K, int MODE>
+__global__ void __launch_bounds__(256) op_rate_kernel(u64* out, u64 w, int iters) {
+  u64 x[K];
+  for (int k = 0; k < K; k++) x[k] = (threadIdx.x * 7919 + blockIdx.x + k + 1) % gl64::P;
+  for (int i = 0; i < iters; i++)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (MODE == 0) x[k] = gl64::add(x[k], w);
+      else if (MODE == 1) x[k] = gl64::sub(x[k], w);
+      else if (MODE == 2) x[k] = gl64::mul_2exp<60>(x[k]);
+      else if (MODE == 3) x[k] = gl64::mul_2exp<24>(x[k]);
+      else if (MODE == 4) x[k] = gl64::mul_2exp<84>(x[k]);
+    }
+  u64 acc = 0;
+  for (int k = 0; k < K; k++) acc ^= x[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) copy16_kernel(const ulonglong2* in, ulonglong2* out, size_t n16) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) copy8_kernel(const u64* in, u64* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+static float time_launch(std::function<void()> f, int iters) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; i++) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; i++) f();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  return ms * 1e3f / iters;  // us
+}
+
+template <int ABL>
+static void run_abl(const PlanDesc& pd, int pass, TileArgs a, const char* label) {
+  const PassDesc& ps = pd.passes[pass];
+  static bool attr = false;
+  (void)attr;
+  CK(hipFuncSetAttribute((const void*)abl_kernel<11, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  float us = time_launch([&] { hipLaunchKernelGGL((abl_kernel<11, false, ABL>), dim3(ps.grid), dim3(ps.block), ps.lds_bytes, 0, a); }, 50);
+  printf("  pass %d  ABL=%2d  %-42s %8.2f us\n", pass, ABL, label, us);
+}
+
+int main(int argc, char** argv) {
+  int max_logc = argc > 1 ? atoi(argv[1]) : 4;
+  const int log2n = 22;
+  const size_t n = (size_t)1 << log2n;
+  PlanDesc pd = build_plan(log2n, 1, false, max_logc);
+  std::vector<u64> h(n);
+  u64 s = 12345;
+  for (auto& v : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = s % gl64::P; }
+  u64 *d_in, *d_tmp, *d_out;
+  CK(hipMalloc(&d_in, n * 8)); CK(hipMalloc(&d_tmp, n * 8)); CK(hipMalloc(&d_out, n * 8));
+  CK(hipMemcpy(d_in, h.data(), n * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_tmp, h.data(), n * 8, hipMemcpyHostToDevice));
+  std::vector<u64*> d_wr;
+  for (auto& t : pd.wr) { u64* d; CK(hipMalloc(&d, t.size() * 8)); CK(hipMemcpy(d, t.data(), t.size() * 8, hipMemcpyHostToDevice)); d_wr.push_back(d); }
+  std::vector<std::pair<u64*, u64*>> d_tw;
+  for (auto& t : pd.tw) {
+    u64 *lo, *hi;
+    CK(hipMalloc(&lo, t.lo.size() * 8)); CK(hipMemcpy(lo, t.lo.data(), t.lo.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&hi, t.hi.size() * 8)); CK(hipMemcpy(hi, t.hi.data(), t.hi.size() * 8, hipMemcpyHostToDevice));
+    d_tw.push_back({lo, hi});
+  }
+  printf("== ablation, n = 2^22, logc = %u / %u, grid %u x %u threads, lds %zu B\n", pd.passes[0].args.logc,
+         pd.passes[1].args.logc, pd.passes[0].grid, pd.passes[0].block, pd.passes[0].lds_bytes);
+  for (int pass = 0; pass < 2; pass++) {
+    const PassDesc& ps = pd.passes[pass];
+    TileArgs a = ps.args;
+    a.in = pass == 0 ? d_in : d_tmp;
+    a.out = pass == 0 ? d_tmp : d_out;
+    a.wr = d_wr[ps.wr_id];
+    if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
+    run_abl<0>(pd, pass, a, "full");
+    run_abl<1>(pd, pass, a, "- inter-pass twiddle");
+    run_abl<2>(pd, pass, a, "- round twiddles");
+    run_abl<3>(pd, pass, a, "- all twiddles");
+    run_abl<4>(pd, pass, a, "- butterflies");
+    run_abl<7>(pd, pass, a, "- all math (loads, LDS, stores only)");
+    run_abl<8>(pd, pass, a, "- LDS exchange");
+    run_abl<15>(pd, pass, a, "- math - LDS (global loads+stores only)");
+    run_abl<16>(pd, pass, a, "- global loads");
+    run_abl<32>(pd, pass, a, "- global stores");
+    run_abl<48>(pd, pass, a, "- global loads - stores (compute+LDS only)");
+    run_abl<47>(pd, pass, a, "loads only");
+    run_abl<31>(pd, pass, a, "stores only");
+    run_abl<56>(pd, pass, a, "math only (no mem, no LDS)");
+  }
+  // ---- raw op rates
+  u64* d_scr;
+  CK(hipMalloc(&d_scr, 256 * 2048 * 8));
+  const int iters = 512;
+  const double lanes = 256.0 * 2048;
+  auto rate = [&](const char* name, float us, int K) {
+    double ops = lanes * K * iters;
+    printf("  %-28s %8.2f us  %8.1f Gop/s  (%.2f cycles/op/lane-slot at 2.4 GHz x 256 CU x 128 lanes/clk)\n", name, us, ops / us * 1e-3,
+           256.0 * 128 * 2.4e9 / (ops / (us * 1e-6)));
+  };
+  printf("== op rates (8 independent chains per work-item)\n");
+  rate("gl64::mul", time_launch([&] { hipLaunchKernelGGL((mul_rate_kernel<8>), dim3(2048), dim3(256), 0, 0, d_scr, (u64)0x123456789abcdefull, iters); }, 10), 8);
+  rate("gl64::add", time_launch([&] { hipLaunchKernelGGL((op_rate_kernel<8, 0>), dim3(2048), dim3(256), 0, 0, d_scr, (u64)0x123456789abcdefull, iters); }, 10), 8);
+  rate("gl64::sub", time_launch([&] { hipLaunchKernelGGL((op_rate_kernel<8, 1>), dim3(2048), dim3(256), 0, 0, d_scr, (u64)0x123456789abcdefull, iters); }, 10), 8);
+  rate("mul_2exp<60>", time_launch([&] { hipLaunchKernelGGL((op_rate_kernel<8, 2>), dim3(2048), dim3(256), 0, 0, d_scr, (u64)1, iters); }, 10), 8);
+  rate("mul_2exp<24>", time_launch([&] { hipLaunchKernelGGL((op_rate_kernel<8, 3>), dim3(2048), dim3(256), 0, 0, d_scr, (u64)1, iters); }, 10), 8);
+  rate("mul_2exp<84>", time_launch([&] { hipLaunchKernelGGL((op_rate_kernel<8, 4>), dim3(2048), dim3(256), 0, 0, d_scr, (u64)1, iters); }, 10), 8);
+  // ---- memory floors (32 MiB in -> 32 MiB out, cache-resident after the first iteration)
+  printf("== copy 32 MiB -> 32 MiB\n");
+  for (int g : {1024, 2048, 4096, 8192}) {
+    float us = time_launch([&] { hipLaunchKernelGGL(copy16_kernel, dim3(g), dim3(256), 0, 0, (const ulonglong2*)d_in, (ulonglong2*)d_out, n / 2); }, 20);
+    printf("  copy16 grid %5d  %8.2f us  %7.1f GB/s\n", g, us, 2.0 * n * 8 / us * 1e-3);
+    us = time_launch([&] { hipLaunchKernelGGL(copy8_kernel, dim3(g), dim3(256), 0, 0, d_in, d_out, n); }, 20);
+    printf("  copy8  grid %5d  %8.2f us  %7.1f GB/s\n", g, us, 2.0 * n * 8 / us * 1e-3);
+  }
+  return 0;
+}
