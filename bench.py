@@ -164,8 +164,21 @@ def main():
     alg_bytes_step = 16.0 * n * ntts_per_step                       # 16*n bytes per n-point NTT
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
     achieved = alg_bytes_step / step_s / 1e9
+    # HBM bytes per launch from the PMC passes of the same command under rocprofv3 (tools/rocprof_summary.py;
+    # FETCH_SIZE x2 gfx950 correction, calibrated on this kernel's known byte count); bench.py cannot
+    # read PMCs itself, so it reports the committed measurement of the dominant kernel, or null.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_pmc_ntt22.json")) as f:
+            for kname, c in json.load(f)["counters"].items():
+                if "ntt_tile_kernel<11, false>" in kname and "_hbm_bytes_per_launch" in c and wl == "ntt22":
+                    traffic = c["_hbm_bytes_per_launch"]["total"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_note": "HBM bytes per kernel launch (rocprofv3 PMC, profiles/latest_pmc_ntt22.json); "
+                                "algorithmic bytes per launch = %d (each of the 2 launches reads and writes the whole vector once)" % (16 * n) if traffic else None,
                 "kernel": "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "note": "achieved/frac are per transform on ONE stream (kernel durations); value uses %d streams" % S,
