@@ -178,7 +178,9 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_note": "HBM bytes per kernel launch (rocprofv3 PMC, profiles/latest_pmc_ntt22.json); "
-                                "algorithmic bytes per launch = %d (each of the 2 launches reads and writes the whole vector once)" % (16 * n) if traffic else None,
+                                "algorithmic bytes = %d per transform (16*n), i.e. %d per launch of the 2-launch plan; each launch reads and "
+                                "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
+                                "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n) if traffic else None,
                 "kernel": "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "note": "achieved/frac are per transform on ONE stream (kernel durations); value uses %d streams" % S,

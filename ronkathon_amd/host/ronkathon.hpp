@@ -1,0 +1,187 @@
+// ronkathon.hpp -- C++ host mirror of ronkathon's field / polynomial surface over the C ABI.
+//
+// The reference is Rust (nightly) and no Rust toolchain exists in this image, so the host side
+// above include/ronk_ntt.h is written in C++ with the SAME names, argument meaning and error
+// behaviour as the reference, so that tests read like the reference's own:
+//   PrimeField<P>            src/algebra/field/prime/mod.rs:39-140, prime/arithmetic.rs:3-71
+//   Field / FiniteField      src/algebra/field/mod.rs:17-76   (ZERO, ONE, inverse, pow, PRIMITIVE_ELEMENT,
+//                                                              primitive_root_of_unity)
+//   Polynomial<B, F, D>      src/polynomial/mod.rs:34-515, src/polynomial/arithmetic.rs:16-146
+// A reference panic becomes a thrown ronkathon::Panic carrying the same message.
+// Scalars are host values (like the Rust value type); every array operation goes to the GPU
+// through libronk_ntt.so -- there is no CPU implementation behind this header.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ronk_ntt.h"
+
+namespace ronkathon {
+
+struct Panic : std::runtime_error {
+  int code;
+  explicit Panic(int c) : std::runtime_error(ronk_strerror(c)), code(c) {}
+};
+inline void check(int rc) { if (rc != RONK_OK) throw Panic(rc); }
+
+// ---- PrimeField<P>: #[repr(transparent)]-like wrapper of the canonical residue
+template <uint64_t P>
+struct PrimeField {
+  uint64_t value = 0;
+  static constexpr uint64_t ORDER = P;                       // Finite::ORDER, src/algebra/mod.rs:8-13
+  constexpr PrimeField() = default;
+  static PrimeField new_(uint64_t v) {                       // prime/mod.rs:48-51 (asserts primality)
+    check(ronk_check_prime(P));
+    PrimeField f; f.value = v % P; return f;
+  }
+  PrimeField(uint64_t v) { *this = new_(v); }                // From<usize>
+  static PrimeField ZERO() { PrimeField f; f.value = 0; return f; }
+  static PrimeField ONE() { PrimeField f; f.value = 1 % P; return f; }
+  static PrimeField PRIMITIVE_ELEMENT() {                    // prime/mod.rs:87-90
+    uint64_t g; check(ronk_primitive_element(P, &g)); PrimeField f; f.value = g; return f;
+  }
+  static PrimeField primitive_root_of_unity(uint64_t n) {    // field/mod.rs:70-75
+    uint64_t w; check(ronk_root_of_unity(P, PRIMITIVE_ELEMENT().value, n, &w)); PrimeField f; f.value = w; return f;
+  }
+  PrimeField pow(uint64_t e) const {                         // prime/mod.rs:74-84
+    unsigned __int128 r = 1 % P, b = value;
+    while (e) { if (e & 1) r = r * b % P; b = b * b % P; e >>= 1; }
+    PrimeField f; f.value = (uint64_t)r; return f;
+  }
+  std::optional<PrimeField> inverse() const {                // prime/mod.rs:62-72
+    if (value == 0) return std::nullopt;
+    return pow(P - 2);
+  }
+  friend PrimeField operator+(PrimeField a, PrimeField b) { PrimeField f; f.value = (uint64_t)(((unsigned __int128)a.value + b.value) % P); return f; }
+  friend PrimeField operator-(PrimeField a, PrimeField b) { PrimeField f; f.value = a.value >= b.value ? a.value - b.value : a.value - b.value + P; return f; }
+  friend PrimeField operator*(PrimeField a, PrimeField b) { PrimeField f; f.value = (uint64_t)((unsigned __int128)a.value * b.value % P); return f; }
+  friend PrimeField operator/(PrimeField a, PrimeField b) {  // self * rhs.inverse().unwrap()
+    auto i = b.inverse(); if (!i) throw Panic(RONK_ERR_ZERO_INVERSE); return a * *i;
+  }
+  PrimeField operator-() const { return ZERO() - *this; }
+  friend bool operator==(PrimeField a, PrimeField b) { return a.value == b.value; }
+  friend bool operator!=(PrimeField a, PrimeField b) { return a.value != b.value; }
+};
+static_assert(sizeof(PrimeField<101>) == sizeof(uint64_t), "PrimeField must be layout-compatible with u64");
+
+using PlutoBaseField = PrimeField<101>;                       // prime/mod.rs:26
+using PlutoScalarField = PrimeField<17>;                      // prime/mod.rs:30
+using GoldilocksField = PrimeField<RONK_GOLDILOCKS_P>;        // the new 64-bit FiniteField implementor
+
+// ---- bases (polynomial/mod.rs:48-72)
+struct Monomial { friend bool operator==(Monomial, Monomial) { return true; } };
+template <class F> struct Lagrange {
+  std::vector<F> nodes;
+  friend bool operator==(const Lagrange& a, const Lagrange& b) { return a.nodes == b.nodes; }
+};
+
+template <class B, class F, size_t D> struct Polynomial;
+
+template <class F, size_t D>
+struct Polynomial<Lagrange<F>, F, D> {
+  std::array<F, D> coefficients;
+  Lagrange<F> basis;
+  // Polynomial::<Lagrange<F>,F,D>::new (mod.rs:358-365): assert_eq!((ORDER - 1) % n, 0); nodes = [w^i]
+  static Polynomial new_(const std::array<F, D>& c) {
+    Polynomial p; p.coefficients = c; p.basis.nodes.resize(D);
+    check(ronk_lagrange_nodes(F::ORDER, F::PRIMITIVE_ELEMENT().value, reinterpret_cast<uint64_t*>(p.basis.nodes.data()), D));
+    return p;
+  }
+  size_t num_terms() const { return D; }
+  Polynomial<Monomial, F, D> ifft() const;                   // mod.rs:430-453
+  friend bool operator==(const Polynomial& a, const Polynomial& b) { return a.coefficients == b.coefficients && a.basis == b.basis; }
+};
+
+template <class F, size_t D>
+struct Polynomial<Monomial, F, D> {
+  std::array<F, D> coefficients;
+  Monomial basis;
+  static Polynomial new_(const std::array<F, D>& c) { Polynomial p; p.coefficients = c; return p; }   // mod.rs:98
+  template <size_t N> static Polynomial from(const std::array<F, N>& c) {                              // mod.rs:503-515
+    Polynomial p; p.coefficients.fill(F::ZERO());
+    for (size_t i = 0; i < (N < D ? N : D); i++) p.coefficients[i] = c[i];
+    return p;
+  }
+  const uint64_t* raw() const { return reinterpret_cast<const uint64_t*>(coefficients.data()); }
+  uint64_t* raw() { return reinterpret_cast<uint64_t*>(coefficients.data()); }
+  size_t num_terms() const { return D; }
+  size_t degree() const { for (size_t i = D; i-- > 0;) if (coefficients[i] != F::ZERO()) return i; return 0; }   // mod.rs:113-115
+  F leading_coefficient() const { for (size_t i = D; i-- > 0;) if (coefficients[i] != F::ZERO()) return coefficients[i]; return F::ZERO(); }
+  F evaluate(F x) const { F r; check(ronk_poly_eval(F::ORDER, raw(), D, x.value, &r.value)); return r; }        // mod.rs:133-139
+  template <size_t D2> Polynomial<Monomial, F, D + D2> pow_mult(F coeff) const {                                  // mod.rs:153-157
+    Polynomial<Monomial, F, D + D2> r; r.coefficients.fill(F::ZERO());
+    std::array<F, D> c; c.fill(coeff);
+    check(ronk_vec_mul(F::ORDER, raw(), reinterpret_cast<const uint64_t*>(c.data()), r.raw() + D2, D));
+    return r;
+  }
+  Polynomial<Lagrange<F>, F, D> dft() const {                 // mod.rs:240-258: any D | ORDER-1
+    std::array<F, D> out;
+    check(ronk_dft(F::ORDER, F::PRIMITIVE_ELEMENT().value, raw(), reinterpret_cast<uint64_t*>(out.data()), D));
+    return Polynomial<Lagrange<F>, F, D>::new_(out);
+  }
+  Polynomial<Lagrange<F>, F, D> fft() const {                 // mod.rs:273-292
+    static_assert(D != 0 && (D & (D - 1)) == 0, "fft: D must be a power of two");  // [(); D.is_power_of_two() as usize - 1]:
+    unsigned k = 0; while ((size_t(1) << k) < D) k++;
+    ronk_plan* plan = nullptr;
+    check(ronk_plan_create(&plan, F::ORDER, F::PRIMITIVE_ELEMENT().value, k, 1, -1));
+    Polynomial<Lagrange<F>, F, D> r; r.basis.nodes.resize(D);
+    int rc = ronk_ntt_forward(plan, raw(), reinterpret_cast<uint64_t*>(r.coefficients.data()),
+                              reinterpret_cast<uint64_t*>(r.basis.nodes.data()));
+    ronk_plan_destroy(plan);
+    check(rc);
+    return r;
+  }
+  std::pair<Polynomial, Polynomial> quotient_and_remainder_dyn(const uint64_t* b, size_t d2) const {  // mod.rs:170-225
+    std::pair<Polynomial, Polynomial> qr;
+    check(ronk_poly_divrem(F::ORDER, raw(), D, b, d2, qr.first.raw(), qr.second.raw()));
+    return qr;
+  }
+  friend bool operator==(const Polynomial& a, const Polynomial& b) { return a.coefficients == b.coefficients; }
+  Polynomial operator-() const { Polynomial r; check(ronk_vec_neg(F::ORDER, raw(), r.raw(), D)); return r; }   // arithmetic.rs:77-95
+};
+
+template <class F, size_t D>
+Polynomial<Monomial, F, D> Polynomial<Lagrange<F>, F, D>::ifft() const {
+  static_assert(D != 0 && (D & (D - 1)) == 0, "ifft: D must be a power of two");
+  unsigned k = 0; while ((size_t(1) << k) < D) k++;
+  ronk_plan* plan = nullptr;
+  check(ronk_plan_create(&plan, F::ORDER, F::PRIMITIVE_ELEMENT().value, k, 1, -1));
+  Polynomial<Monomial, F, D> r;
+  int rc = ronk_ntt_inverse(plan, reinterpret_cast<const uint64_t*>(coefficients.data()), r.raw());
+  ronk_plan_destroy(plan);
+  check(rc);
+  return r;
+}
+
+// impl Add / Sub (arithmetic.rs:16-68): result has len(lhs) coefficients
+template <class F, size_t D, size_t D2>
+Polynomial<Monomial, F, D> operator+(const Polynomial<Monomial, F, D>& a, const Polynomial<Monomial, F, D2>& b) {
+  Polynomial<Monomial, F, D> r; check(ronk_poly_add(F::ORDER, a.raw(), D, b.raw(), D2, r.raw())); return r;
+}
+template <class F, size_t D, size_t D2>
+Polynomial<Monomial, F, D> operator-(const Polynomial<Monomial, F, D>& a, const Polynomial<Monomial, F, D2>& b) {
+  Polynomial<Monomial, F, D> r; check(ronk_poly_sub(F::ORDER, a.raw(), D, b.raw(), D2, r.raw())); return r;
+}
+// impl Mul (arithmetic.rs:97-119): D + D2 - 1 coefficients
+template <class F, size_t D, size_t D2>
+Polynomial<Monomial, F, D + D2 - 1> operator*(const Polynomial<Monomial, F, D>& a, const Polynomial<Monomial, F, D2>& b) {
+  Polynomial<Monomial, F, D + D2 - 1> r;
+  check(ronk_poly_mul(F::ORDER, F::PRIMITIVE_ELEMENT().value, a.raw(), D, b.raw(), D2, r.raw()));
+  return r;
+}
+// impl Div / Rem (arithmetic.rs:121-146)
+template <class F, size_t D, size_t D2>
+Polynomial<Monomial, F, D> operator/(const Polynomial<Monomial, F, D>& a, const Polynomial<Monomial, F, D2>& b) {
+  return a.quotient_and_remainder_dyn(b.raw(), D2).first;
+}
+template <class F, size_t D, size_t D2>
+Polynomial<Monomial, F, D> operator%(const Polynomial<Monomial, F, D>& a, const Polynomial<Monomial, F, D2>& b) {
+  return a.quotient_and_remainder_dyn(b.raw(), D2).second;
+}
+
+}  // namespace ronkathon

@@ -1,0 +1,71 @@
+// Reads like the reference's own tests (src/polynomial/tests.rs, src/polynomial/arithmetic.rs tests,
+// src/algebra/field/prime tests) but runs every array operation on the GPU through the C ABI.
+// Built and run by tests/test_cpp_host_mirror.py (-m gpu).
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+
+#include "../../ronkathon_amd/host/ronkathon.hpp"
+
+using namespace ronkathon;
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+template <class Fn> static bool panics(Fn f, int code) { try { f(); } catch (const Panic& p) { return p.code == code; } return false; }
+template <class F, size_t D> static std::array<F, D> arr(std::initializer_list<uint64_t> v) {
+  std::array<F, D> a; size_t i = 0; for (auto x : v) a[i++] = F::new_(x); return a;
+}
+using B = PlutoBaseField;
+
+int main() {
+  // fixture poly(): 1 + 2x + 3x^2 + 4x^3 over F_101 (polynomial/tests.rs:3-11)
+  auto poly = Polynomial<Monomial, B, 4>::new_(arr<B, 4>({1, 2, 3, 4}));
+  CHECK(poly.evaluate(B::new_(2)) == B::new_(49));                                  // evaluation
+  CHECK((Polynomial<Monomial, B, 3>::new_(arr<B, 3>({1, 0, 3})).evaluate(B::new_(0)) == B::new_(1)));  // evaluation_with_zero
+  CHECK(panics([] { Polynomial<Monomial, B, 3>::new_(arr<B, 3>({1, 2, 3})).dft(); }, RONK_ERR_NO_ROOT));  // no_roots_of_unity
+  CHECK((poly.dft().coefficients == arr<B, 4>({10, 79, 99, 18})));                  // check_coefficients / dft
+  CHECK((poly.fft().coefficients == arr<B, 4>({10, 79, 99, 18})));                  // fft
+  CHECK(poly.fft().ifft() == poly);                                                 // ifft round trip
+  CHECK(poly.fft() == poly.dft());                                                  // same Lagrange nodes too
+  CHECK(poly.degree() == 3);
+  CHECK(poly.leading_coefficient() == B::new_(4));
+  CHECK((poly.pow_mult<2>(B::new_(5)).coefficients == arr<B, 6>({0, 0, 5, 10, 15, 20})));
+  // arithmetic.rs tests
+  auto a = Polynomial<Monomial, B, 4>::new_(arr<B, 4>({1, 2, 3, 4}));
+  auto b = Polynomial<Monomial, B, 5>::new_(arr<B, 5>({5, 6, 7, 8, 9}));
+  CHECK(((b + a).coefficients == arr<B, 5>({6, 8, 10, 12, 9})));
+  CHECK(((a - b).coefficients == arr<B, 4>({97, 97, 97, 97})));
+  CHECK(((b - a).coefficients == arr<B, 5>({4, 4, 4, 4, 9})));
+  CHECK(((-a).coefficients == arr<B, 4>({100, 99, 98, 97})));
+  CHECK(((a / b).coefficients == arr<B, 4>({0, 0, 0, 0})));
+  CHECK(((b / a).coefficients == arr<B, 5>({95, 78, 0, 0, 0})));
+  CHECK(((a % b).coefficients == a.coefficients));
+  CHECK(((b % a).coefficients == arr<B, 5>({11, 41, 71, 0, 0})));
+  CHECK(((a * b).coefficients == arr<B, 8>({5, 16, 34, 60, 70, 70, 59, 36})));
+  auto c = Polynomial<Monomial, B, 2>::new_(arr<B, 2>({1, 2}));
+  auto d = Polynomial<Monomial, B, 2>::new_(arr<B, 2>({3, 4}));
+  CHECK(((c * d).coefficients == arr<B, 3>({3, 10, 8})));
+  // prime field surface
+  CHECK(B::new_(40) * B::new_(61) == B::new_(16));
+  CHECK(*B::new_(15).inverse() == B::new_(27));
+  CHECK(!B::new_(0).inverse().has_value());
+  CHECK(panics([] { (void)(B::new_(3) / B::new_(0)); }, RONK_ERR_ZERO_INVERSE));
+  CHECK(B::PRIMITIVE_ELEMENT() == B::new_(2) && PlutoScalarField::PRIMITIVE_ELEMENT() == PlutoScalarField::new_(14));
+  CHECK(panics([] { PlutoScalarField::primitive_root_of_unity(3); }, RONK_ERR_NO_ROOT));   // not_primitive_root_of_unity
+  CHECK(panics([] { PrimeField<100>::new_(0); }, RONK_ERR_NOT_PRIME));                     // non_prime_is_not_finite_field
+  // the 64-bit field: derived vector and a 2^16 round trip (too big for the stack -> heap)
+  using G = GoldilocksField;
+  CHECK(G::PRIMITIVE_ELEMENT() == G::new_(7));
+  auto g4 = Polynomial<Monomial, G, 4>::new_(arr<G, 4>({1, 2, 3, 4}));
+  CHECK((g4.fft().coefficients == arr<G, 4>({10, 18446181119461163007ull, 18446744069414584319ull, 562949953421310ull})));
+  constexpr size_t N = 1 << 16;
+  auto big = std::make_unique<Polynomial<Monomial, G, N>>();
+  uint64_t s = 0x5EED0002;
+  for (auto& v : big->coefficients) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = G::new_(s); }
+  auto lag = std::make_unique<Polynomial<Lagrange<G>, G, N>>(big->fft());
+  auto back = std::make_unique<Polynomial<Monomial, G, N>>(lag->ifft());
+  CHECK(*back == *big);
+  CHECK(lag->basis.nodes[1] == G::primitive_root_of_unity(N));
+  CHECK(lag->coefficients[0] == [&] { G acc = G::ZERO(); for (auto& v : big->coefficients) acc = acc + v; return acc; }());  // X[0] = sum x_j
+  printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}
