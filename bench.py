@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--workload", default="ntt22")
     ap.add_argument("--log2n", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="independent transforms in flight (HIP streams)")
+    ap.add_argument("--streams", type=int, default=2, help="independent transforms in flight (HIP streams)")
     args = ap.parse_args()
 
     import torch

@@ -105,6 +105,12 @@ int ronk_ntt_inverse_dev(ronk_plan* plan, const uint64_t* d_in, uint64_t* d_out,
 /* Lagrange::<F>::new's node table [omega^i], i < n (polynomial/mod.rs:358-365) */
 int ronk_lagrange_nodes(uint64_t p, uint64_t g, uint64_t* nodes, size_t n);
 
+/* One-shot host-pointer forms of the two calls above for a single polynomial, the direct analogues of
+ * `poly.fft()` / `lagrange.ifft()`: plans (twiddles, scratch) are kept in an internal LRU cache.
+ * n not a power of two -> RONK_ERR_NOT_POW2; n does not divide p-1 -> RONK_ERR_NO_ROOT. */
+int ronk_fft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, uint64_t* nodes, size_t n);
+int ronk_ifft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n);
+
 /* Polynomial::dft() for ANY n dividing p-1 (polynomial/mod.rs:240-258), e.g. n = 3, 5, 7, 25.
  * Direct O(n^2) kernel; power-of-two n >= 16 over Goldilocks is routed to the NTT. n <= 2^16. */
 int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n);

@@ -60,6 +60,8 @@ _SIG = {
     "ronk_ntt_forward_dev": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_ntt_inverse_dev": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_lagrange_nodes": (_int, [_u64, _u64, _vp, _sz]),
+    "ronk_fft": (_int, [_u64, _u64, _vp, _vp, _vp, _sz]),
+    "ronk_ifft": (_int, [_u64, _u64, _vp, _vp, _sz]),
     "ronk_dft": (_int, [_u64, _u64, _vp, _vp, _sz]),
     "ronk_plan_num_passes": (_int, [_vp]),
     "ronk_plan_time_passes": (_int, [_vp, _vp, _vp, _int, _int, C.POINTER(C.c_float), _vp]),

@@ -6,6 +6,7 @@
 // every entry point that would compute returns RONK_ERR_NO_DEVICE without a HIP device.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -350,8 +351,10 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
   if (rc) { delete pl; return rc; }
   pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4);
   if (pl->fast) {
-    rc = pl->fwd.compile(build_plan((int)log2n, batch, false));
-    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true));
+    int max_logc = 4;  // tuning knob (columns per tile = 2^max_logc at most); RONK_MAX_LOGC overrides
+    if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) max_logc = v; }
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc));
   } else {
     pl->w_f = h_powmod(pl->g, (p - 1) / n, p);
     pl->w_i = h_powmod(pl->w_f, p - 2, p);                     // root.inverse().unwrap(), mod.rs:433
@@ -501,22 +504,91 @@ extern "C" int ronk_plan_time_passes(ronk_plan* pl, const uint64_t* d_in, uint64
   return RONK_OK;
 }
 
-// ------------------------------------------------------------------------------ dft (any n | p-1)
+// ------------------------------------------------------------------------------ plan cache
+// One-shot entry points (ronk_fft/ronk_ifft/ronk_dft/ronk_poly_mul*) reuse plans -- twiddle tables and
+// scratch stay resident in HBM -- through a small LRU cache guarded by one lock (the reference is
+// stateless; `cargo test` calls in from many threads).  An entry also owns two padded operand
+// buffers for the multiply; an event orders successive uses of an entry across streams.
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 static int ilog2(size_t n) { int k = 0; while (((size_t)1 << k) < n) k++; return k; }
+
+struct CacheEntry {
+  ronk_plan* pl = nullptr;
+  u64 *fa = nullptr, *fb = nullptr;  // poly_mul operands, n elements each (lazy)
+  hipEvent_t done = nullptr;
+  uint64_t stamp = 0;
+};
+static std::mutex g_cache_mu;
+static std::vector<CacheEntry> g_cache;
+static uint64_t g_cache_clock = 0;
+
+static void cache_entry_free(CacheEntry& e) {
+  if (e.pl) ronk_plan_destroy(e.pl);
+  if (e.fa) (void)hipFree(e.fa);
+  if (e.fb) (void)hipFree(e.fb);
+  if (e.done) (void)hipEventDestroy(e.done);
+  e = CacheEntry();
+}
+// caller holds g_cache_mu
+static int cache_get(u64 p, u64 g, u32 log2n, CacheEntry** out) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  for (auto& e : g_cache)
+    if (e.pl && e.pl->p == p && e.pl->g == g % p && e.pl->log2n == log2n && e.pl->batch == 1 && e.pl->device == dev) {
+      e.stamp = ++g_cache_clock;
+      *out = &e;
+      return RONK_OK;
+    }
+  if (g_cache.size() >= 8) {  // evict the least recently used entry (its work must have drained)
+    size_t lru = 0;
+    for (size_t i = 1; i < g_cache.size(); i++) if (g_cache[i].stamp < g_cache[lru].stamp) lru = i;
+    if (g_cache[lru].done) (void)hipEventSynchronize(g_cache[lru].done);
+    cache_entry_free(g_cache[lru]);
+    g_cache.erase(g_cache.begin() + lru);
+  }
+  CacheEntry e;
+  RCHK(ronk_plan_create(&e.pl, p, g, log2n, 1, -1));
+  hipError_t he = hipEventCreateWithFlags(&e.done, hipEventDisableTiming);
+  if (he != hipSuccess) { cache_entry_free(e); return hip_fail(he, "hipEventCreate"); }
+  e.stamp = ++g_cache_clock;
+  g_cache.push_back(e);
+  *out = &g_cache.back();
+  return RONK_OK;
+}
+
+// Polynomial::fft / ifft one-shot forms (polynomial/mod.rs:273-292, :430-453) on host pointers
+static int fft_oneshot(bool inverse, u64 p, u64 g, const u64* in, u64* out, u64* nodes, size_t n) {
+  if (!in || !out || n == 0) return RONK_ERR_INVALID;
+  if (!is_pow2(n)) return RONK_ERR_NOT_POW2;  // `[(); D.is_power_of_two() as usize - 1]:`
+  RCHK(ronk_check_prime(p));
+  if (p < 2) return RONK_ERR_INVALID;
+  if ((p - 1) % n != 0) return RONK_ERR_NO_ROOT;
+  RCHK(need_device());
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CacheEntry* e = nullptr;
+    RCHK(cache_get(p, g, (u32)ilog2(n), &e));
+    RCHK(inverse ? ronk_ntt_inverse(e->pl, in, out) : ronk_ntt_forward(e->pl, in, out, nullptr));
+  }
+  if (nodes) RCHK(ronk_lagrange_nodes(p, g, nodes, n));
+  return RONK_OK;
+}
+extern "C" int ronk_fft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, uint64_t* nodes, size_t n) {
+  return fft_oneshot(false, p, g, in, out, nodes, n);
+}
+extern "C" int ronk_ifft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n) {
+  return fft_oneshot(true, p, g, in, out, nullptr, n);
+}
+
+// ------------------------------------------------------------------------------ dft (any n | p-1)
 
 extern "C" int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n) {
   if (!in || !out || n == 0) return RONK_ERR_INVALID;
   u64 w;
   RCHK(ronk_root_of_unity(p, g % p, n, &w));
   RCHK(need_device());
-  if (is_pow2(n) && p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 16) {
-    ronk_plan* pl = nullptr;
-    RCHK(ronk_plan_create(&pl, p, g, (u32)ilog2(n), 1, -1));
-    int rc = ronk_ntt_forward(pl, in, out, nullptr);
-    ronk_plan_destroy(pl);
-    return rc;
-  }
+  if (is_pow2(n) && p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 16)
+    return fft_oneshot(false, p, g, in, out, nullptr, n);
   if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
   FieldCtx f;
   RCHK(make_field(p, &f));
@@ -551,26 +623,24 @@ extern "C" int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, si
   int k = ilog2(m);
   if (k < 4) k = 4;
   const size_t N = (size_t)1 << k;
-  ronk_plan* pl = nullptr;
-  RCHK(ronk_plan_create(&pl, p, g, (u32)k, 1, -1));
-  DevBuf fa, fb;
-  int rc = fa.alloc(N * 8);
-  if (!rc) rc = fb.alloc(N * 8);
-  auto body = [&]() -> int {
-    HIPCHK(hipMemsetAsync(fa.p, 0, N * 8, s));
-    HIPCHK(hipMemsetAsync(fb.p, 0, N * 8, s));
-    HIPCHK(hipMemcpyAsync(fa.p, d_a, d * 8, hipMemcpyDeviceToDevice, s));   // From<[F;N]> zero-pad, mod.rs:503-515
-    HIPCHK(hipMemcpyAsync(fb.p, d_b, d2 * 8, hipMemcpyDeviceToDevice, s));
-    RCHK(transform_dev(pl, false, fa.u(), nullptr, fa.u(), s));
-    RCHK(transform_dev(pl, false, fb.u(), nullptr, fb.u(), s));
-    RCHK(transform_dev(pl, true, fa.u(), fb.u(), fa.u(), s));               // pointwise product fused into the load
-    HIPCHK(hipMemcpyAsync(d_out, fa.p, m * 8, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));                                        // scratch is freed below
-    return RONK_OK;
-  };
-  if (!rc) rc = body();
-  ronk_plan_destroy(pl);
-  return rc;
+  RCHK(need_device());
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  CacheEntry* e = nullptr;
+  RCHK(cache_get(p, g, (u32)k, &e));
+  if (!e->fa) HIPCHK(hipMalloc((void**)&e->fa, N * 8));
+  if (!e->fb) HIPCHK(hipMalloc((void**)&e->fb, N * 8));
+  ronk_plan* pl = e->pl;
+  HIPCHK(hipStreamWaitEvent(s, e->done, 0));                                // previous use of this entry's scratch
+  if (d < N) HIPCHK(hipMemsetAsync(e->fa + d, 0, (N - d) * 8, s));           // From<[F;N]> zero-pad, mod.rs:503-515
+  if (d2 < N) HIPCHK(hipMemsetAsync(e->fb + d2, 0, (N - d2) * 8, s));
+  HIPCHK(hipMemcpyAsync(e->fa, d_a, d * 8, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->fb, d_b, d2 * 8, hipMemcpyDeviceToDevice, s));
+  RCHK(transform_dev(pl, false, e->fa, nullptr, e->fa, s));
+  RCHK(transform_dev(pl, false, e->fb, nullptr, e->fb, s));
+  RCHK(transform_dev(pl, true, e->fa, e->fb, e->fa, s));                    // pointwise product fused into the load
+  HIPCHK(hipMemcpyAsync(d_out, e->fa, m * 8, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipEventRecord(e->done, s));
+  return RONK_OK;
 }
 extern "C" int ronk_poly_mul(uint64_t p, uint64_t g, const uint64_t* a, size_t d, const uint64_t* b, size_t d2,
                              uint64_t* out) {

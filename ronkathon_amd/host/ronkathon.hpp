@@ -126,14 +126,9 @@ struct Polynomial<Monomial, F, D> {
   }
   Polynomial<Lagrange<F>, F, D> fft() const {                 // mod.rs:273-292
     static_assert(D != 0 && (D & (D - 1)) == 0, "fft: D must be a power of two");  // [(); D.is_power_of_two() as usize - 1]:
-    unsigned k = 0; while ((size_t(1) << k) < D) k++;
-    ronk_plan* plan = nullptr;
-    check(ronk_plan_create(&plan, F::ORDER, F::PRIMITIVE_ELEMENT().value, k, 1, -1));
     Polynomial<Lagrange<F>, F, D> r; r.basis.nodes.resize(D);
-    int rc = ronk_ntt_forward(plan, raw(), reinterpret_cast<uint64_t*>(r.coefficients.data()),
-                              reinterpret_cast<uint64_t*>(r.basis.nodes.data()));
-    ronk_plan_destroy(plan);
-    check(rc);
+    check(ronk_fft(F::ORDER, F::PRIMITIVE_ELEMENT().value, raw(), reinterpret_cast<uint64_t*>(r.coefficients.data()),
+                   reinterpret_cast<uint64_t*>(r.basis.nodes.data()), D));
     return r;
   }
   std::pair<Polynomial, Polynomial> quotient_and_remainder_dyn(const uint64_t* b, size_t d2) const {  // mod.rs:170-225
@@ -148,13 +143,8 @@ struct Polynomial<Monomial, F, D> {
 template <class F, size_t D>
 Polynomial<Monomial, F, D> Polynomial<Lagrange<F>, F, D>::ifft() const {
   static_assert(D != 0 && (D & (D - 1)) == 0, "ifft: D must be a power of two");
-  unsigned k = 0; while ((size_t(1) << k) < D) k++;
-  ronk_plan* plan = nullptr;
-  check(ronk_plan_create(&plan, F::ORDER, F::PRIMITIVE_ELEMENT().value, k, 1, -1));
   Polynomial<Monomial, F, D> r;
-  int rc = ronk_ntt_inverse(plan, reinterpret_cast<const uint64_t*>(coefficients.data()), r.raw());
-  ronk_plan_destroy(plan);
-  check(rc);
+  check(ronk_ifft(F::ORDER, F::PRIMITIVE_ELEMENT().value, reinterpret_cast<const uint64_t*>(coefficients.data()), r.raw(), D));
   return r;
 }
 

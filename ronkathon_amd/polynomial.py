@@ -171,31 +171,18 @@ class Polynomial:
         L.check(L.lib.ronk_dft(self.field.ORDER, self.field._G, L.ptr(self.coefficients), L.ptr(out), self.D))
         return Polynomial.new_lagrange(self.field, out)
 
-    def _pow2(self):
-        D = self.D
-        if D == 0 or D & (D - 1):
-            raise L.RonkPanic(L.ERR_NOT_POW2)     # `[(); D.is_power_of_two() as usize - 1]:` (mod.rs:274)
-        return D.bit_length() - 1
-
     def fft(self):
-        """Polynomial::fft (mod.rs:273-292): D a power of two dividing ORDER - 1."""
+        """Polynomial::fft (mod.rs:273-292): D a power of two dividing ORDER - 1 (else the reference's panics)."""
         self._mono()
-        k = self._pow2()
-        plan = L.Plan(self.field.ORDER, self.field._G, k)
-        try:
-            out, nodes = plan.forward(self.coefficients, nodes=True)
-        finally:
-            plan.close()
+        out = np.empty(self.D, dtype=np.uint64)
+        nodes = np.empty(self.D, dtype=np.uint64)
+        L.check(L.lib.ronk_fft(self.field.ORDER, self.field._G, L.ptr(self.coefficients), L.ptr(out), L.ptr(nodes), self.D))
         return Polynomial(self.field, out, Lagrange(nodes))
 
     def ifft(self):
         """Polynomial::<Lagrange>::ifft (mod.rs:430-453), including the D^-1 scale."""
         if not isinstance(self.basis, Lagrange):
             raise TypeError("ifft is defined on the Lagrange basis")
-        k = self._pow2()
-        plan = L.Plan(self.field.ORDER, self.field._G, k)
-        try:
-            out = plan.inverse(self.coefficients)
-        finally:
-            plan.close()
+        out = np.empty(self.D, dtype=np.uint64)
+        L.check(L.lib.ronk_ifft(self.field.ORDER, self.field._G, L.ptr(self.coefficients), L.ptr(out), self.D))
         return Polynomial(self.field, out, Monomial())

@@ -290,3 +290,71 @@ def test_determinism(R):
     a = plan.forward(x); b = plan.forward(x)
     assert np.array_equal(a, b)
     plan.close()
+
+
+def test_device_pointer_api_inplace_and_streams(R, orc):
+    """_dev entry points on caller-owned device memory: out-of-place, in-place, on a side stream"""
+    import torch
+    from ronkathon_amd import _lib as L
+    for k, batch in ((10, 5), (16, 2), (20, 1)):
+        n = 1 << k
+        x = splitmix_field(900 + k, n * batch)
+        ref = np.concatenate([orc.fft(GP, GG, x[b * n:(b + 1) * n]) for b in range(batch)])
+        plan = L.Plan(GP, GG, k, batch)
+        dx = torch.from_numpy(x.view(np.int64)).cuda()
+        dy = torch.empty_like(dx)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            plan.forward_dev(dx.data_ptr(), dy.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        assert np.array_equal(dy.cpu().numpy().view(np.uint64), ref)
+        plan.forward_dev(dx.data_ptr(), dx.data_ptr(), 0)          # in place
+        torch.cuda.synchronize()
+        assert np.array_equal(dx.cpu().numpy().view(np.uint64), ref)
+        plan.inverse_dev(dx.data_ptr(), dx.data_ptr(), 0)          # in place back
+        torch.cuda.synchronize()
+        assert np.array_equal(dx.cpu().numpy().view(np.uint64), x)
+        plan.close()
+    # device-resident multiply, repeated (plan cache + event ordering of the cached scratch)
+    a = splitmix_field(31, 3000); b = splitmix_field(32, 5000)
+    da = torch.from_numpy(a.view(np.int64)).cuda(); db = torch.from_numpy(b.view(np.int64)).cuda()
+    dout = torch.empty(a.size + b.size - 1, dtype=torch.int64, device="cuda")
+    ref = orc.poly_mul(GP, a, b)
+    for _ in range(3):
+        L.check(L.lib.ronk_poly_mul_dev(GP, GG, da.data_ptr(), a.size, db.data_ptr(), b.size, dout.data_ptr(), 0))
+    torch.cuda.synchronize()
+    assert np.array_equal(dout.cpu().numpy().view(np.uint64), ref)
+    F = R.GoldilocksField
+    dz = torch.empty_like(da)
+    L.check(L.lib.ronk_vec_mul_dev(GP, da.data_ptr(), da.data_ptr(), dz.data_ptr(), a.size, 0))
+    torch.cuda.synchronize()
+    assert np.array_equal(dz.cpu().numpy().view(np.uint64), orc.vec_mul(GP, a, a))
+
+
+def test_plan_cache_eviction_and_threads(R, orc):
+    """more distinct one-shot sizes than cache entries, then concurrent callers (the reference's
+    `cargo test` runs tests on parallel threads; the library must be re-entrant)"""
+    import threading
+    F = R.GoldilocksField
+    for k in range(4, 16):
+        x = splitmix_field(40 + k, 1 << k)
+        p = R.Polynomial.new(F, x)
+        assert np.array_equal(p.fft().coefficients, orc.fft(GP, GG, x))
+    errs = []
+
+    def worker(seed):
+        try:
+            for k in (6, 9, 12, 13):
+                x = splitmix_field(seed * 100 + k, 1 << k)
+                y = R.Polynomial.new(F, x).fft()
+                assert np.array_equal(y.coefficients, orc.fft(GP, GG, x))
+                assert np.array_equal(y.ifft().coefficients, x)
+                a = splitmix_field(seed, 200); b = splitmix_field(seed + 1, 300)
+                assert np.array_equal((R.Polynomial.new(F, a) * R.Polynomial.new(F, b)).coefficients, orc.poly_mul(GP, a, b))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
