@@ -55,6 +55,10 @@ struct TileArgs {
   u32 tw_log, tw_lo_bits;
   const u64* tw_lo;
   const u64* tw_hi;
+  // ... or, when the whole twiddle matrix is affordable, ONE coalesced load instead of two gathers and a
+  // multiply: w = tw_full[k*tf_sk + (t*C + c)*tf_sc + b2*tf_sb2] (laid out like the pass's own output tile)
+  const u64* tw_full;
+  u32 tf_sk, tf_sc, tf_sb2;
   u64 xc, xb1, xb2, x0;  // X = xc*(t*C + c) + xb1*b1 + xb2*b2 + x0
   u64 yk, yb1, yb2, y0;  // Y = yk*k + yb1*b1 + yb2*b2 + y0
   u64 scale;             // 1 = none
@@ -229,7 +233,14 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   }
 
   // ---- output: optional inter-pass twiddle, optional scale, store at natural row k
-  if (a.tw_log && !(ABL & 1)) {
+  if (a.tw_full && !(ABL & 1)) {
+    const u64* tf = a.tw_full + (col * a.tf_sc + b2 * a.tf_sb2);
+    u64 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = live ? tf[klow[i] * a.tf_sk] : 1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], w[i]);
+  } else if (a.tw_log && !(ABL & 1)) {
     // exponent (X*Y) mod 2^tw_log with tw_log <= 32: the low 32 bits of a 32-bit product suffice
     const u32 X = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
     const u32 Yb = (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0;

@@ -31,6 +31,7 @@ struct PassDesc {
   Buf in_buf, out_buf;
   int wr_id;          // index into PlanDesc::wr (round twiddles for 2^logr)
   int tw_id;          // index into PlanDesc::tw, or -1
+  int twf_id;         // index into PlanDesc::twf (full twiddle matrix), or -1
   u32 grid, block;
   size_t lds_bytes;
 };
@@ -48,6 +49,7 @@ struct PlanDesc {
   std::vector<std::vector<u64>> wr;  // one table per distinct logr
   std::vector<int> wr_logr;
   std::vector<TwTable> tw;
+  std::vector<std::vector<u64>> twf;  // full inter-pass twiddle matrices (one coalesced load per coefficient)
   bool needs_tmp = false;
 };
 
@@ -118,18 +120,53 @@ struct PlanBuilder {
     p.wr_id = wr_table(logr);
     p.args.wr = nullptr;
     p.tw_id = -1;
+    p.twf_id = -1;
+    p.args.tw_full = nullptr; p.args.tf_sk = p.args.tf_sc = p.args.tf_sb2 = 0;
     p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
     p.block = (u32)((((u64)1 << logr) * C) / 16);
     p.lds_bytes = logr > 4 ? ((size_t)8 << logr) * C : 0;
     d.passes.push_back(p);
     return d.passes.back();
   }
-  void finish(PassDesc& p) { p.grid = p.args.tiles * p.args.nb1 * p.args.nb2; }
+  int twf_max_log = 0;  // build the full twiddle matrix of a pass when it has at most 2^twf_max_log entries
+
+  // Full matrix of the pass's output twiddle, T[k*tf_sk + col*tf_sc + b2*tf_sb2] = omega_N^{X*Y}, strides chosen
+  // like the pass's own output so the load is the same coalesced tile pattern.  Only the indices the
+  // exponent depends on get a stride (a batch index it ignores shares the table).
+  void maybe_full_table(PassDesc& p) {
+    const TileArgs& a = p.args;
+    if (!a.tw_log || a.xb1 || a.yb1) return;
+    const u64 R = (u64)1 << p.logr;
+    const bool dep_c = a.xc != 0, dep_b2 = a.xb2 != 0 || a.yb2 != 0;
+    const u64 nc = dep_c ? a.ncols : 1, nb2 = dep_b2 ? a.nb2 : 1;
+    const u64 entries = R * nc * nb2;
+    if (twf_max_log <= 0 || entries > ((u64)1 << twf_max_log)) return;
+    // dense layout [k][b2][col] restricted to the dependent indices
+    const u32 sc = dep_c ? 1 : 0, sb2 = dep_b2 ? (u32)nc : 0, sk = (u32)(nc * nb2);
+    const TwTable& t = d.tw[p.tw_id];
+    const u64 nmask = a.tw_log >= 64 ? ~(u64)0 : (((u64)1 << a.tw_log) - 1), lmask = ((u64)1 << t.lo_bits) - 1;
+    std::vector<u64> T(entries);
+    for (u64 k = 0; k < R; k++)
+      for (u64 b2 = 0; b2 < nb2; b2++)
+        for (u64 c = 0; c < nc; c++) {
+          const u64 X = a.xc * c + a.xb2 * b2 + a.x0, Y = a.yk * k + a.yb2 * b2 + a.y0;
+          const u64 e = (X * Y) & nmask;
+          T[k * sk + b2 * sb2 + c * sc] = gl64::mul(t.lo[e & lmask], t.hi[e >> t.lo_bits]);
+        }
+    d.twf.push_back(std::move(T));
+    p.twf_id = (int)d.twf.size() - 1;
+    p.args.tf_sk = sk; p.args.tf_sc = sc; p.args.tf_sb2 = sb2;
+  }
+  void finish(PassDesc& p) {
+    p.grid = p.args.tiles * p.args.nb1 * p.args.nb2;
+    maybe_full_table(p);
+  }
 };
 
 // max_logc: widest tile (log2 columns) the builder may pick; 4 = 128-byte segments.
-inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4) {
+inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0) {
   PlanBuilder b;
+  b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.batch = batch; b.d.inverse = inverse;
   const u64 n = (u64)1 << log2n;
   const u64 scale = inverse ? gl64::inv(n % gl64::P) : 1;  // F::from(D).inverse(), mod.rs:442
@@ -222,9 +259,10 @@ inline bool dist_shape(int log2n, int world, DistShape* s) {
   return true;
 }
 
-inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, int max_logc = 4) {
+inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0) {
   DistShape sh;
   PlanBuilder b;
+  b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.inverse = inverse;
   if (!dist_shape(log2n, world, &sh)) return b.d;
   const u64 Cw = sh.Cw, g0 = (u64)rank * Cw;
@@ -264,10 +302,11 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
   return b.d;
 }
 
-inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, int max_logc = 4) {
+inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0) {
   (void)rank;
   DistShape sh;
   PlanBuilder b;
+  b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.inverse = inverse;
   if (!dist_shape(log2n, world, &sh)) return b.d;
   const u64 Cw = sh.Cw, Rw = sh.Rw, C = sh.C;

@@ -98,6 +98,7 @@ static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64*
     a.out = bufs_out[p.out_buf];
     a.wr = pd.wr[p.wr_id].data();
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
+    if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
     lds.assign(p.lds_bytes / 8 + 1, 0);
     for (u32 bid = 0; bid < p.grid; bid++) {
       g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
@@ -107,6 +108,7 @@ static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64*
 }
 
 // dist mode: simulate all W ranks of the four-step in one process (the all-to-all is a memcpy)
+static int g_twf = 0;
 static int dist_main(int log2n, int world, bool inv) {
   DistShape sh;
   if (!dist_shape(log2n, world, &sh)) { printf("bad dist shape\n"); return 2; }
@@ -119,14 +121,14 @@ static int dist_main(int log2n, int world, bool inv) {
     loc[g].resize(per); snd[g].assign(per, 1); rcv[g].resize(per); res[g].assign(per, 2); tmp[g].assign(per, 3);
     for (u64 r = 0; r < sh.R; r++)
       for (u64 cl = 0; cl < sh.Cw; cl++) loc[g][r * sh.Cw + cl] = x[r * sh.C + g * sh.Cw + cl];
-    PlanDesc p1 = build_dist_phase1(log2n, inv, g, world);
+    PlanDesc p1 = build_dist_phase1(log2n, inv, g, world, 4, g_twf);
     run_plan(p1, inv, loc[g].data(), snd[g].data(), tmp[g].data());
   }
   const u64 blk = sh.Rw * sh.Cw;
   for (int g = 0; g < world; g++)
     for (int h = 0; h < world; h++) memcpy(&rcv[h][g * blk], &snd[g][h * blk], blk * 8);  // all_to_all_single
   for (int h = 0; h < world; h++) {
-    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world);
+    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world, 4, g_twf);
     run_plan(p2, inv, rcv[h].data(), res[h].data(), tmp[h].data());
     for (u64 k2 = 0; k2 < sh.C; k2++)
       for (u64 k1l = 0; k1l < sh.Rw; k1l++) got[(h * sh.Rw + k1l) + sh.R * k2] = res[h][k2 * sh.Rw + k1l];
@@ -140,6 +142,7 @@ static int dist_main(int log2n, int world, bool inv) {
 }
 
 int main(int argc, char** argv) {
+  if (argc >= 6 && !strcmp(argv[1], "dist")) g_twf = atoi(argv[5]);
   if (argc >= 5 && !strcmp(argv[1], "dist")) return dist_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0);
   if (argc < 5) { fprintf(stderr, "usage: emu_tile log2n batch inverse max_logc\n"); return 2; }
   int log2n = atoi(argv[1]);
@@ -147,7 +150,8 @@ int main(int argc, char** argv) {
   bool inv = atoi(argv[3]) != 0;
   int max_logc = atoi(argv[4]);
   u64 n = (u64)1 << log2n;
-  PlanDesc pd = build_plan(log2n, batch, inv, max_logc);
+  int twf = argc > 5 ? atoi(argv[5]) : 0;
+  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
   u64 s = 0x5EED0000ull + log2n;
@@ -164,6 +168,7 @@ int main(int argc, char** argv) {
     a.out = bufs_out[p.out_buf];
     a.wr = pd.wr[p.wr_id].data();
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
+    if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
     lds.assign(p.lds_bytes / 8 + 1, 0);
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes);

@@ -39,6 +39,13 @@ def test_two_pass(emu, k, batch, inv, logc):
     run(emu, k, batch, inv, logc)
 
 
+@pytest.mark.parametrize("k,batch,inv", [(13, 2, 0), (16, 2, 1), (18, 1, 0)])
+def test_two_pass_full_twiddle_matrix(emu, k, batch, inv):
+    """plans whose inter-pass twiddle is the full matrix laid out like the output tile (plan.h maybe_full_table)"""
+    run(emu, k, batch, inv, 4, 24)
+
+
 def test_dist_phases(emu):
     for k, w, inv in ((12, 1, 0), (13, 2, 0), (16, 4, 1), (20, 8, 0)):
         run(emu, "dist", k, w, inv)
+    run(emu, "dist", 16, 4, 0, 24)
