@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="ntt22")
     ap.add_argument("--log2n", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="polynomials per launch (default: 1, batch16: 1024)")
     ap.add_argument("--streams", type=int, default=2, help="independent transforms in flight (HIP streams)")
     args = ap.parse_args()
 
@@ -93,7 +94,7 @@ def main():
         return
 
     log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16}[wl]
-    batch = 1024 if wl == "batch16" else 1
+    batch = args.batch or (1024 if wl == "batch16" else 1)
     n = 1 << log2n
     if wl == "batch16":
         args.streams = 1
@@ -154,13 +155,15 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
 
     units_per_step = batch if wl != "roundtrip16" else 1
+    if wl == "ntt22":
+        pass
     value = world * args.steps * units_per_step / dt
 
     # per-kernel device time (hipEvents on the launch stream) for the roofline of the dominant kernel
     pass_ms = None
     if wl in ("ntt22", "batch16"):
         pass_ms = plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
-    ntts_per_step = {"ntt22": 1, "batch16": batch, "mul22": 3, "roundtrip16": 2}[wl]
+    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2}[wl]
     alg_bytes_step = 16.0 * n * ntts_per_step                       # 16*n bytes per n-point NTT
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
     achieved = alg_bytes_step / step_s / 1e9
