@@ -693,6 +693,31 @@ extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const u
   RCHK(need_device());
   FieldCtx f;
   RCHK(make_field(p, &f));
+  // kzg::open shape (src/kzg/setup.rs:63-78): a linear divisor b0 + b1*x with b1 != 0, b0 != 0 -> parallel scan
+  if (d2 == 2 && d >= 2 && b[1] % p != 0 && b[0] % p != 0 && d <= (size_t)SCAN_CHUNK * 4096 && p > 2) {
+    const u64 b0 = b[0] % p, b1 = b[1] % p;
+    const u64 b1inv = h_powmod(b1, p - 2, p);
+    const u64 z = h_mulmod(p - b0, b1inv, p);          // -b0 / b1
+    const u64 zinv = h_powmod(z, p - 2, p);
+    const size_t nchunks = (d + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    DevBuf dc, dt, dsum, dtot, dqq;
+    RCHK(dc.alloc(d * 8)); RCHK(dt.alloc(d * 8)); RCHK(dsum.alloc(nchunks * 8)); RCHK(dtot.alloc(8)); RCHK(dqq.alloc(d * 8));
+    HIPCHK(hipMemcpy(dc.p, a, d * 8, hipMemcpyHostToDevice));
+    FIELD_DISPATCH(f, {
+      hipLaunchKernelGGL((lindiv_scale_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, 0, ops, dc.u(), d, b1inv, z,
+                         dt.u(), dsum.u());
+      hipLaunchKernelGGL((lindiv_chunk_scan_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, 0, ops, dsum.u(), nchunks, dtot.u());
+      hipLaunchKernelGGL((lindiv_finish_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, 0, ops, dt.u(), d, zinv,
+                         dsum.u(), dqq.u());
+    });
+    HIPCHK(hipGetLastError());
+    u64 s0 = 0;
+    HIPCHK(hipMemcpy(&s0, dtot.p, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(quot, dqq.p, d * 8, hipMemcpyDeviceToHost));
+    memset(rem, 0, d * 8);
+    rem[0] = h_mulmod(s0, b1, p);                      // remainder = p(z) = b1 * S_0
+    return RONK_OK;
+  }
   DevBuf drem, db, dq, dst;
   RCHK(drem.alloc(d * 8)); RCHK(db.alloc(d2 * 8)); RCHK(dq.alloc(d * 8)); RCHK(dst.alloc(4));
   HIPCHK(hipMemcpy(drem.p, a, d * 8, hipMemcpyHostToDevice));

@@ -358,3 +358,43 @@ def test_plan_cache_eviction_and_threads(R, orc):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_linear_divisor_scan_vs_oracle(R, orc):
+    """kzg::open shape: poly / (b0 + b1 x) through the parallel-scan kernels, against the oracle's long division"""
+    for p in (101, 17, GP):
+        F = R.PrimeField(p)
+        for d, seed in ((2, 1), (3, 2), (17, 3), (4095, 4), (4096, 5), (4097, 6), (12289, 7)):
+            if p != GP and d > 5000:
+                continue
+            a = splitmix_field(seed, d, p)
+            for b in ([int(splitmix_field(seed + 50, 1, p)[0]) or 1, 1],                 # x - z (monic, kzg::open)
+                      [int(splitmix_field(seed + 60, 1, p)[0]) or 2, int(splitmix_field(seed + 70, 1, p)[0]) or 3]):
+                q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+                oq, orr = orc.poly_divrem(p, a, b)
+                assert np.array_equal(q.coefficients, oq), (p, d, b)
+                assert np.array_equal(r.coefficients, orr), (p, d, b)
+        if p == GP:
+            # full size through a size-independent property: a(x) == q(x) * (b0 + b1 x) + r at random points
+            d = 1 << 22
+            a = splitmix_field(99, d, p)
+            b = [123456789, 987654321]
+            q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+            assert not r.coefficients[1:].any() and q.coefficients[-1] == 0
+            for x in (3, 0xDEADBEEF12345, GP - 2):
+                lhs = orc.poly_eval(p, a, x)
+                rhs = orc.add(p, orc.mul(p, orc.poly_eval(p, q.coefficients, x), orc.add(p, b[0], orc.mul(p, b[1], x))),
+                              int(r.coefficients[0]))
+                assert lhs == rhs
+        # leading zeros in the dividend, zero dividend, x itself as divisor (generic kernel path)
+        for a in ([1, 2, 3, 0, 0], [0, 0, 0, 0], [5, 0, 0, 7]):
+            for b in ([3, 1], [0, 1], [4, 0]):
+                try:
+                    oq, orr = orc.poly_divrem(p, a, b)
+                except orc.OraclePanic as e:      # e.g. [4, 0]: the reference indexes out of bounds -> both must panic
+                    with pytest.raises(R.RonkPanic) as g:
+                        R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+                    assert g.value.code == e.code, (p, a, b)
+                    continue
+                q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+                assert q.coefficients.tolist() == oq.tolist() and r.coefficients.tolist() == orr.tolist(), (p, a, b)
