@@ -8,6 +8,10 @@
 // v_mad_u64_u32 and reduced with 2^64 = 2^32 - 1, 2^96 = -1 (mod p).
 //
 // All functions take and return CANONICAL values unless the name says otherwise.
+// The forms below are chosen by VALU instruction count on gfx950 (tools/instr_rate.hip,
+// tools/isa_loop_count.py): every 64-bit add / compare / select / v_mad_u64_u32 costs the
+// same ~1.6 issue slots, so "value + (cond ? EPS : 0)" (5 VALU per add) beats a 64-bit
+// select between two candidates (6), and a borrow chain beats subtract + compare for sub.
 // Plain C++ on uint32/uint64 only, so the same header also builds for the host-side
 // kernel emulator under tests/emu (test infrastructure; never part of the product .so).
 #pragma once
@@ -30,34 +34,43 @@ static constexpr u64 P = 0xFFFFFFFF00000001ull;
 static constexpr u64 EPS = 0xFFFFFFFFull;  // 2^64 mod p = 2^32 - 1
 static constexpr u64 GENERATOR = 7;        // explicit PRIMITIVE_ELEMENT
 
-// x < 2^64 arbitrary -> canonical
-RONK_HD u64 canon(u64 x) { return x >= P ? x - P : x; }
+// x < 2^64 arbitrary -> canonical  (x - p == x + EPS mod 2^64)
+RONK_HD u64 canon(u64 x) { return x + ((x >= P) ? EPS : 0); }
 
-// prime/arithmetic.rs:3-7
+// prime/arithmetic.rs:3-7.  a, b < p: a wrapped sum (s < a) or s >= p both mean "subtract p"
 RONK_HD u64 add(u64 a, u64 b) {
   u64 s = a + b;
-  // a, b < p: a wrapped sum (s < a) or s >= p both mean "subtract p", and s - p == s + EPS mod 2^64
-  return (s < a || s >= P) ? s + EPS : s;
+  return s + ((s < a || s >= P) ? EPS : 0);
 }
 
-// prime/arithmetic.rs:19-28 (borrow -> + ORDER)
+// a - b, + p on borrow (prime/arithmetic.rs:19-28).  Also valid for ANY a < 2^64 and b <= p; the
+// result is then some representative in [0, 2^64).
 RONK_HD u64 sub(u64 a, u64 b) {
+#if defined(__clang__)
+  // borrow chain: the borrow of the 64-bit subtract comes out of v_subb_co_u32 for free
+  u32 b1, b2, b3, b4;
+  u32 lo = __builtin_subc((u32)a, (u32)b, 0u, &b1);
+  u32 hi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b1, &b2);
+  u32 e = 0u - b2;  // 0xFFFFFFFF on borrow: d + p == d - EPS (mod 2^64)
+  lo = __builtin_subc(lo, e, 0u, &b3);
+  hi = __builtin_subc(hi, 0u, b3, &b4);
+  return ((u64)hi << 32) | lo;
+#else
   u64 d = a - b;
-  return (a < b) ? d - EPS : d;  // d + p == d - EPS mod 2^64
+  return (a < b) ? d - EPS : d;
+#endif
 }
 
 // prime/arithmetic.rs:61-65
 RONK_HD u64 neg(u64 a) { return a ? P - a : 0; }
 
 // 128-bit value hi:lo -> canonical residue.  hi = hh*2^32 + hl:
-//   x = lo + hl*(2^32-1) - hh   (mod p)
+//   x = lo - hh + hl*(2^32-1)   (mod p)
 RONK_HD u64 reduce128(u64 lo, u64 hi) {
   u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-  u64 t0 = lo - hh;
-  if (lo < hh) t0 -= EPS;                  // borrow: + p
-  u64 t1 = ((u64)hl << 32) - hl;           // hl * EPS, < p
-  u64 r = t0 + t1;
-  if (r < t1) r += EPS;                    // carry: 2^64 = EPS; cannot carry twice
+  u64 t0 = sub(lo, (u64)hh);                  // any representative; borrow -> + p
+  u64 r = (u64)hl * 0xFFFFFFFFu + t0;         // one v_mad_u64_u32; hl*EPS < p, so at most one wrap
+  r += (r < t0) ? EPS : 0;                    // 2^64 = EPS; cannot wrap twice
   return canon(r);
 }
 
@@ -93,6 +106,7 @@ RONK_HD u64 inv(u64 a) { return pow(a, P - 2); }
 // inside a <=64-point sub-transform is +-2^K, i.e. shifts instead of multiplies.
 // With y = x << (K%32) as limbs (y2,y1,y0) placed K/32 limbs up:
 //   q=0: (y1:y0) + y2*EPS      q=1: (y0<<32) + y1*EPS - y2      q=2: y0*EPS - (y2:y1)
+// Input: canonical (any 64-bit value works); output canonical.
 template <int K>
 RONK_HD u64 mul_2exp(u64 x) {
   static_assert(K >= 0 && K < 96, "shift out of range");
@@ -103,24 +117,23 @@ RONK_HD u64 mul_2exp(u64 x) {
   if constexpr (s == 0) {
     y0 = x0; y1 = x1; y2 = 0;
   } else {
-    y0 = x0 << s;
-    y1 = (x1 << s) | (x0 >> (32 - s));
-    y2 = x1 >> (32 - s);
+    u64 p0 = (u64)x0 << s;
+    u64 p1 = ((u64)x1 << s) + (p0 >> 32);
+    y0 = (u32)p0; y1 = (u32)p1; y2 = (u32)(p1 >> 32);
   }
-  if (q == 0) {
-    u64 n = ((u64)y1 << 32) | y0;          // may be >= p
-    u64 t = ((u64)y2 << 32) - y2;          // y2 * EPS < p
-    u64 r = n + t;
-    if (r < t) r += EPS;
+  if constexpr (q == 0) {
+    u64 n = ((u64)y1 << 32) | y0;            // may be >= p
+    u64 r = (u64)y2 * 0xFFFFFFFFu + n;       // y2*EPS + n: one mad, at most one wrap
+    r += (r < n) ? EPS : 0;
     return canon(r);
-  } else if (q == 1) {
-    u64 n = (u64)y0 << 32;                 // < p
-    u64 t = ((u64)y1 << 32) - y1;          // < p
+  } else if constexpr (q == 1) {
+    u64 n = (u64)y0 << 32;                   // < p
+    u64 t = ((u64)y1 << 32) - y1;            // y1*EPS < p
     return sub(add(n, t), (u64)y2);
   } else {
-    u64 t = ((u64)y0 << 32) - y0;          // < p
-    u64 m = ((u64)y2 << 32) | y1;          // y2 < 2^31 -> < p
-    return sub(t, m);
+    u64 t = (u64)y0 * 0xFFFFFFFFu;           // y0*EPS < p
+    u64 m = ((u64)y2 << 32) | y1;            // y2 < 2^31 -> < p
+    return sub(t, m);                        // canonical: t, m < p
   }
 }
 

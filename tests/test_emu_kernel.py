@@ -49,3 +49,17 @@ def test_dist_phases(emu):
     for k, w, inv in ((12, 1, 0), (13, 2, 0), (16, 4, 1), (20, 8, 0)):
         run(emu, "dist", k, w, inv)
     run(emu, "dist", 16, 4, 0, 24)
+
+
+def test_gl64_field_arithmetic_edges():
+    """ronkathon_amd/csrc/gl64.h on the host against 128-bit arithmetic: every carry/borrow branch, all 96 shifts"""
+    src = os.path.join(ROOT, "tests", "emu", "test_gl64_host.cpp")
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    compilers = ["g++"]
+    if os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        compilers.append("/opt/rocm/lib/llvm/bin/clang++")   # exercises the __builtin_subc path of the device build
+    for i, cxx in enumerate(compilers):
+        exe = os.path.join(ROOT, "build", "test_gl64_host_%d" % i)
+        subprocess.check_call([cxx, "-O2", "-std=c++17", "-o", exe, src])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "ALL OK" in out.stdout, (cxx, out.stdout[-800:])
