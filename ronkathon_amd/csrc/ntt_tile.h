@@ -18,9 +18,12 @@
 // natural order in, natural order out, omega = g^((p-1)/n).  No MFMA: this is 64-bit
 // modular integer work, bounded by HBM traffic and the VALU integer-multiply rate.
 //
-// LDS image: row-major [R][C] u64 with rows XOR-swizzled, row' = row ^ ((row>>4)&15), so
-// that the strided accesses of the early rounds and the 16-consecutive-row accesses of the
-// last round are both bank-conflict free for ds_read_b64 / ds_write_b64.
+// LDS image: row-major [R + R/16][C] u64 -- one dummy row after every 16 rows (row' = row + (row>>4)).
+// The early rounds touch 8..16 consecutive rows per wave (contiguous, conflict free); in the last
+// round lane groups read rows 16u+t for consecutive u, and the dummy row shifts each u by one row
+// (64..128 B), so a half-wave covers all 64 banks once: 0 bank conflicts for ds_read_b64/ds_write_b64.
+// Unlike an XOR swizzle the map is additive, so every LDS address is one per-lane base plus a
+// wave-uniform constant (1 VALU per access).
 //
 // The body is plain C++ over (tid, bid, lds, barrier) so that tests/emu can run the very
 // same code on host threads to check the index algebra without a GPU.
@@ -114,7 +117,14 @@ struct Dif<1, INV> {
   static RONK_HD void run(u64*) {}
 };
 
-RONK_HD u32 swz_row(u32 row) { return row ^ ((row >> 4) & 15u); }
+// LDS row of tile row `row`: one dummy row after every 16 (see the header comment)
+RONK_HD u32 swz_row(u32 row) { return row + (row >> 4); }
+
+// table[idx] for a small twiddle table: wave-uniform base + 32-bit BYTE offset, so the load is the
+// `global_load ... v_off, s[base:base+1]` form (one VALU shift) instead of a 64-bit per-lane address
+RONK_HD u64 ld_tab(const u64* table, u32 idx) {
+  return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(table) + (u32)(idx << 3));
+}
 
 // ---- the tile body --------------------------------------------------------------------
 //
@@ -193,7 +203,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], a.wr[m * k1]);
+      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ld_tab(a.wr, m * k1));
       if (!(ABL & 8)) lc[swz_row(k1 * M + m) << logc] = x[i];
     }
     if (!(ABL & 8)) barrier();
@@ -210,7 +220,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
-        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], a.wr[tstep * k2]);
+        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ld_tab(a.wr, tstep * k2));
         if (!(ABL & 8)) lc[swz_row(base + k2 * RLAST) << logc] = x[i];
       }
       if (!(ABL & 8)) barrier();
@@ -235,11 +245,13 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   // ---- output: optional inter-pass twiddle, optional scale, store at natural row k
   if (a.tw_full && !(ABL & 1)) {
     const u64* tf = a.tw_full + (col * a.tf_sc + b2 * a.tf_sb2);
-    u64 w[16];
+    if (live) {  // one branch for the 16 loads (dead columns of a ragged tile hold zeros anyway)
+      u64 w[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = live ? tf[klow[i] * a.tf_sk] : 1;
+      for (int i = 0; i < 16; i++) w[i] = tf[klow[i] * a.tf_sk];
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], w[i]);
+      for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], w[i]);
+    }
   } else if (a.tw_log && !(ABL & 1)) {
     // exponent (X*Y) mod 2^tw_log with tw_log <= 32: the low 32 bits of a 32-bit product suffice
     const u32 X = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
@@ -250,7 +262,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 e = (X * (yk * klow[i] + Yb)) & nmask;
-      const u64 w = gl64::mul(a.tw_lo[e & lmask], a.tw_hi[e >> a.tw_lo_bits]);
+      const u64 w = gl64::mul(ld_tab(a.tw_lo, e & lmask), ld_tab(a.tw_hi, e >> a.tw_lo_bits));
       x[i] = gl64::mul(x[i], w);
     }
   }

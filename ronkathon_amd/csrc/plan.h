@@ -124,7 +124,7 @@ struct PlanBuilder {
     p.args.tw_full = nullptr; p.args.tf_sk = p.args.tf_sc = p.args.tf_sb2 = 0;
     p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
     p.block = (u32)((((u64)1 << logr) * C) / 16);
-    p.lds_bytes = logr > 4 ? ((size_t)8 << logr) * C : 0;
+    p.lds_bytes = logr > 4 ? ((((size_t)1 << logr) + ((size_t)1 << logr) / 16) * C * 8) : 0;  // +1 dummy row per 16
     d.passes.push_back(p);
     return d.passes.back();
   }
