@@ -164,7 +164,9 @@ struct PlanBuilder {
 };
 
 // max_logc: widest tile (log2 columns) the builder may pick; 4 = 128-byte segments.
-inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0) {
+// three_pass_from: smallest log2n that is split in three passes (25 = only when two do not fit).
+inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0,
+                           int three_pass_from = 25) {
   PlanBuilder b;
   b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.batch = batch; b.d.inverse = inverse;
@@ -177,7 +179,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     p.args.out_sk = 1; p.args.out_sc = (i64)n;
     p.args.scale = scale;
     b.finish(p);
-  } else if (log2n <= 24) {
+  } else if (log2n <= 24 && log2n < three_pass_from) {
     const int ka = (log2n + 1) / 2, kb = log2n - ka;
     const u64 A = (u64)1 << ka, B = (u64)1 << kb;
     {

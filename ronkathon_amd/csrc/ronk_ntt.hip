@@ -363,8 +363,10 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
     // n-element HBM read per transform (measured +4 % speed at 2^22 for +25 % traffic): left to RONK_TWF_MAX_LOG.
     int twf_max_log = 18;
     if (const char* e = getenv("RONK_TWF_MAX_LOG")) { int v = atoi(e); if (v >= 0 && v <= 26) twf_max_log = v; }
-    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log));
-    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log));
+    int three_from = 25;  // RONK_THREE_PASS_FROM: split smaller sizes in three passes too (experiment knob)
+    if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from));
   } else {
     pl->w_f = h_powmod(pl->g, (p - 1) / n, p);
     pl->w_i = h_powmod(pl->w_f, p - 2, p);                     // root.inverse().unwrap(), mod.rs:433

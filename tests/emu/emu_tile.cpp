@@ -151,7 +151,8 @@ int main(int argc, char** argv) {
   int max_logc = atoi(argv[4]);
   u64 n = (u64)1 << log2n;
   int twf = argc > 5 ? atoi(argv[5]) : 0;
-  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf);
+  int three_from = argc > 6 ? atoi(argv[6]) : 25;
+  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
   u64 s = 0x5EED0000ull + log2n;
