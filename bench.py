@@ -202,9 +202,24 @@ def main():
                "roofline": roofline}
         if not args.no_cpu and wl == "ntt22":
             res["cpu_baseline"] = cpu_baseline(log2n)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     for p_ in plans:
         p_.close()
+    # Multi-GPU extra (never part of the JSON line above, which is already out): the sharded four-step NTT of
+    # BASELINE config 5 (2^26 over the ranks, one RCCL all-to-all over xGMI per transform).  Result goes to
+    # stderr and gpurun_out/; any failure here is reported, not raised.  Opt-in (RONK_BENCH_FOURSTEP=1) so that the
+    # scaling run of the default benchmark never depends on a collective that was not asked for.
+    if world > 1 and wl == "ntt22" and os.environ.get("RONK_BENCH_FOURSTEP", "0") == "1":
+        try:
+            from ronkathon_amd import dist as rdist
+            fs = rdist.bench_fourstep(26, 20, 3)
+            if rank == 0:
+                sys.stderr.write("fourstep: " + json.dumps(fs) + "\n")
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "fourstep_w%d.json" % world), "w") as f:
+                    json.dump(fs, f)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("fourstep extra failed: %r\n" % (e,))
     if world > 1:
         dist.destroy_process_group()
 
