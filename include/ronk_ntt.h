@@ -137,6 +137,10 @@ int ronk_poly_sub(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, si
 
 /* Polynomial::<Monomial>::evaluate (polynomial/mod.rs:133-139): sum c_i x^i */
 int ronk_poly_eval(uint64_t p, const uint64_t* c, size_t d, uint64_t x, uint64_t* out);
+/* Polynomial::<Lagrange<F>>::evaluate (polynomial/mod.rs:382-415): barycentric evaluation at x from the
+ * values c[j] at nodes[j].  As in the reference, x equal to a node yields ZERO (its fold multiplies by
+ * l(x) = 0); coincident nodes -> RONK_ERR_ZERO_INVERSE.  n <= 2^16 (O(n^2) weights, like the reference). */
+int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, size_t n, uint64_t x, uint64_t* out);
 /* quotient_and_remainder (polynomial/mod.rs:170-225) behind impl Div / Rem (arithmetic.rs:121-146);
  * quot and rem both have d coefficients.  Used by kzg::open (src/kzg/setup.rs:63-78). */
 int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,

@@ -70,6 +70,7 @@ _SIG = {
     "ronk_poly_add": (_int, [_u64, _vp, _sz, _vp, _sz, _vp]),
     "ronk_poly_sub": (_int, [_u64, _vp, _sz, _vp, _sz, _vp]),
     "ronk_poly_eval": (_int, [_u64, _vp, _sz, _u64, _pu]),
+    "ronk_lagrange_eval": (_int, [_u64, _vp, _vp, _sz, _u64, _pu]),
     "ronk_poly_divrem": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp]),
     "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),

@@ -217,6 +217,74 @@ __global__ void __launch_bounds__(1024) poly_divrem_kernel(Ops ops, u64* __restr
   }
 }
 
+// ---- Polynomial::<Lagrange>::evaluate (polynomial/mod.rs:382-415), barycentric form --------------------
+//   w_j = prod_{m != j} 1/(x_j - x_m),  l(x) = prod_i (x - x_i),  L(x) = l(x) * sum_j c_j w_j / (x - x_j)
+// One work-item per node j: den_j = (x - x_j) * prod_{m != j} (x_j - x_m) with the nodes staged through LDS,
+// term_j = c_j / den_j (ONE inversion per node instead of the reference's n), then block reductions of the
+// sum of terms and of the product of (x - x_j).  If x is a node, l(x) == 0 and the reference's fold returns
+// l(x) * (...) == ZERO (its `return c` only replaces the accumulator): den_j == 0 there is inverted to 0, no
+// panic, result 0 -- same value.  Coincident nodes make the reference panic (ONE.div(ZERO)): flag -> -2.
+template <class Ops>
+__global__ void __launch_bounds__(256) lagrange_terms_kernel(Ops ops, const u64* __restrict__ c, const u64* __restrict__ nodes,
+                                                              size_t n, u64 x, u64* __restrict__ part_sum,
+                                                              u64* __restrict__ part_prod, int* flag) {
+  __shared__ u64 chunk[256];
+  __shared__ u64 rs[256];
+  __shared__ u64 rp[256];
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const u64 xj = j < n ? nodes[j] : 0;
+  u64 den = 1;
+  for (size_t m0 = 0; m0 < n; m0 += 256) {
+    __syncthreads();
+    if (m0 + threadIdx.x < n) chunk[threadIdx.x] = nodes[m0 + threadIdx.x];
+    __syncthreads();
+    const size_t lim = n - m0 < 256 ? n - m0 : 256;
+    if (j < n)
+      for (size_t m = 0; m < lim; m++)
+        if (m0 + m != j) {
+          const u64 d = ops.sub(xj, chunk[m]);
+          if (d == 0) *flag = 1;
+          den = ops.mul(den, d);
+        }
+  }
+  u64 term = 0, fac = 1;
+  if (j < n) {
+    fac = ops.sub(x, xj);
+    den = ops.mul(den, fac);
+    term = ops.mul(c[j], ops.pow(den, ops.order() - 2));
+  }
+  rs[threadIdx.x] = term;
+  rp[threadIdx.x] = fac;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      rs[threadIdx.x] = ops.add(rs[threadIdx.x], rs[threadIdx.x + s]);
+      rp[threadIdx.x] = ops.mul(rp[threadIdx.x], rp[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_sum[blockIdx.x] = rs[0]; part_prod[blockIdx.x] = rp[0]; }
+}
+template <class Ops>
+__global__ void __launch_bounds__(256) lagrange_finish_kernel(Ops ops, const u64* __restrict__ part_sum,
+                                                               const u64* __restrict__ part_prod, size_t nparts, u64* out) {
+  __shared__ u64 rs[256];
+  __shared__ u64 rp[256];
+  u64 s = 0, p = 1;
+  for (size_t i = threadIdx.x; i < nparts; i += 256) { s = ops.add(s, part_sum[i]); p = ops.mul(p, part_prod[i]); }
+  rs[threadIdx.x] = s;
+  rp[threadIdx.x] = p;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      rs[threadIdx.x] = ops.add(rs[threadIdx.x], rs[threadIdx.x + st]);
+      rp[threadIdx.x] = ops.mul(rp[threadIdx.x], rp[threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = ops.mul(rp[0], rs[0]);
+}
+
 // ---- division by a LINEAR divisor b0 + b1*x (kzg::open, src/kzg/setup.rs:63-78) as a parallel scan --
 // With z = -b0/b1 and c' = c/b1:  q_j = sum_{i>j} c'_i z^(i-j-1) = z^-(j+1) * S_(j+1),  S_j = sum_{i>=j} c'_i z^i,
 // remainder = p(z) = b1 * S_0.  Same polynomials as the reference's long division (mod.rs:170-225) for a

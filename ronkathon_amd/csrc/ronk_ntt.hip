@@ -689,6 +689,34 @@ extern "C" int ronk_poly_eval(uint64_t p, const uint64_t* c, size_t d, uint64_t 
   return RONK_OK;
 }
 
+// Polynomial::<Lagrange<F>,F,D>::evaluate (polynomial/mod.rs:382-415)
+extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, size_t n, uint64_t x, uint64_t* out) {
+  if (!c || !nodes || !out || n == 0) return RONK_ERR_INVALID;
+  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;  // O(n^2) weights, as in the reference
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  const u32 blocks = (u32)((n + 255) / 256);
+  DevBuf dc, dn, ds, dp, dres, dflag;
+  RCHK(dc.alloc(n * 8)); RCHK(dn.alloc(n * 8)); RCHK(ds.alloc(blocks * 8)); RCHK(dp.alloc(blocks * 8));
+  RCHK(dres.alloc(8)); RCHK(dflag.alloc(4));
+  HIPCHK(hipMemcpy(dc.p, c, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dn.p, nodes, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dflag.p, 0, 4));
+  FIELD_DISPATCH(f, {
+    hipLaunchKernelGGL((lagrange_terms_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, 0, ops, dc.u(), dn.u(), n, x % p,
+                       ds.u(), dp.u(), (int*)dflag.p);
+    hipLaunchKernelGGL((lagrange_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, 0, ops, ds.u(), dp.u(), (size_t)blocks,
+                       dres.u());
+  });
+  HIPCHK(hipGetLastError());
+  int hflag = 0;
+  HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
+  if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: F::ONE.div(ZERO) -> unwrap on None
+  HIPCHK(hipMemcpy(out, dres.p, 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+
 extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,
                                 uint64_t* rem) {
   if (!a || !b || !quot || !rem || d == 0 || d2 == 0) return RONK_ERR_INVALID;

@@ -93,6 +93,11 @@ struct Polynomial<Lagrange<F>, F, D> {
     return p;
   }
   size_t num_terms() const { return D; }
+  F evaluate(F x) const {                                    // mod.rs:382-415 (barycentric)
+    F r; check(ronk_lagrange_eval(F::ORDER, reinterpret_cast<const uint64_t*>(coefficients.data()),
+                                  reinterpret_cast<const uint64_t*>(basis.nodes.data()), D, x.value, &r.value));
+    return r;
+  }
   Polynomial<Monomial, F, D> ifft() const;                   // mod.rs:430-453
   friend bool operator==(const Polynomial& a, const Polynomial& b) { return a.coefficients == b.coefficients && a.basis == b.basis; }
 };

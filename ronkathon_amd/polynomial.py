@@ -92,35 +92,8 @@ class Polynomial:
         x = int(x) % self.field.ORDER
         if isinstance(self.basis, Monomial):
             return self.field(L.out_scalar(L.lib.ronk_poly_eval, self.field.ORDER, L.ptr(self.coefficients), self.D, x))
-        return self._lagrange_evaluate(x)
-
-    def _lagrange_evaluate(self, x):
-        # mod.rs:382-415 with the field kernels: weights w_j = prod_{m != j} 1/(x_j - x_m),
-        # l(x) = prod (x - x_i), fold acc + c*w/(x - n) with the fold's `return c` quirk.
-        F, n, nodes = self.field, self.D, self.basis.nodes
-        xi = np.repeat(nodes, n)          # x_j
-        xm = np.tile(nodes, n)            # x_m
-        diff = F.vec_sub(xi, xm).reshape(n, n)
-        np.fill_diagonal(diff, 1)         # skip m == j
-        inv = F.vec_inv(diff.reshape(-1)).reshape(n, n)
-        w = inv[:, 0].copy()
-        for m in range(1, n):             # product over a row: n-1 element-wise GPU products
-            w = F.vec_mul(w, inv[:, m].copy())
-        xs = np.full(n, x, dtype=np.uint64)
-        xd = F.vec_sub(xs, nodes)         # x - x_j
-        l = F.ONE
-        acc = F.ZERO
-        hit = np.flatnonzero(nodes == np.uint64(x))
-        safe = xd.copy()
-        safe[hit] = 1
-        terms = F.vec_mul(F.vec_mul(self.coefficients, w), F.vec_inv(safe))
-        for j in range(n):
-            l = l * F(int(xd[j]))
-            if nodes[j] == np.uint64(x):
-                acc = F(int(self.coefficients[j]))   # closure `return c` replaces the accumulator
-            else:
-                acc = acc + F(int(terms[j]))
-        return l * acc
+        return self.field(L.out_scalar(L.lib.ronk_lagrange_eval, self.field.ORDER, L.ptr(self.coefficients),
+                                       L.ptr(self.basis.nodes), self.D, x))
 
     # ---- arithmetic (arithmetic.rs)
     def _binary(self, fn, rhs):

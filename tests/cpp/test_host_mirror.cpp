@@ -26,6 +26,7 @@ int main() {
   CHECK((poly.fft().coefficients == arr<B, 4>({10, 79, 99, 18})));                  // fft
   CHECK(poly.fft().ifft() == poly);                                                 // ifft round trip
   CHECK(poly.fft() == poly.dft());                                                  // same Lagrange nodes too
+  CHECK(poly.dft().evaluate(B::new_(2)) == B::new_(49));                            // lagrange_evaluation
   CHECK(poly.degree() == 3);
   CHECK(poly.leading_coefficient() == B::new_(4));
   CHECK((poly.pow_mult<2>(B::new_(5)).coefficients == arr<B, 6>({0, 0, 5, 10, 15, 20})));

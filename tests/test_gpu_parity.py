@@ -398,3 +398,23 @@ def test_linear_divisor_scan_vs_oracle(R, orc):
                     continue
                 q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
                 assert q.coefficients.tolist() == oq.tolist() and r.coefficients.tolist() == orr.tolist(), (p, a, b)
+
+
+def test_lagrange_evaluate_vs_oracle(R, orc):
+    """Polynomial::<Lagrange>::evaluate on the GPU (ronk_lagrange_eval) vs the oracle's step-by-step fold"""
+    for p, g, ns in ((101, 2, (1, 2, 4, 5, 10, 20, 25)), (17, 14, (1, 2, 4, 8, 16)), (GP, GG, (1, 3, 8, 15, 64, 96, 1024))):
+        F = R.PrimeField(p)
+        for n in ns:
+            c = splitmix_field(n + 7, n, p)
+            lag = R.Polynomial.new_lagrange(F, c)
+            nodes = orc.lagrange_nodes(p, g, n)
+            assert np.array_equal(lag.basis.nodes, nodes)
+            for x in [int(v) for v in splitmix_field(n + 99, 3, p)] + [int(nodes[n // 2]), 0]:
+                assert int(lag.evaluate(x)) == orc.lagrange_eval(p, c, nodes, x), (p, n, x)
+    # coincident nodes: the reference panics on ONE.div(ZERO)
+    bad = R.Polynomial(R.PlutoBaseField, [1, 2, 3], R.Lagrange([5, 7, 5]))
+    with pytest.raises(R.RonkPanic) as e:
+        bad.evaluate(3)
+    assert e.value.code == -2
+    with pytest.raises(orc.OraclePanic):
+        orc.lagrange_eval(101, [1, 2, 3], [5, 7, 5], 3)
