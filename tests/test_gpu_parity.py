@@ -418,3 +418,19 @@ def test_lagrange_evaluate_vs_oracle(R, orc):
     assert e.value.code == -2
     with pytest.raises(orc.OraclePanic):
         orc.lagrange_eval(101, [1, 2, 3], [5, 7, 5], 3)
+
+
+@pytest.mark.parametrize("k", [24, 25])
+def test_large_plans_spot_and_roundtrip(R, orc, k):
+    """largest two-pass plan (2^24) and a three-pass plan (2^25): outputs spot-checked against the DEFINITION
+    X[i] = sum_j x[j] w^(i j) (one O(n) Horner evaluation per checked output), plus the bit-exact round trip"""
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    x = splitmix_field(0x5EED0100 + k, n)
+    plan = L.Plan(GP, GG, k)
+    y = plan.forward(x)
+    w = orc.primitive_root_of_unity(GP, GG, n)
+    for i in (0, 1, 2, 12345, n // 2 + 1, n - 1):
+        assert int(y[i]) == orc.poly_eval(GP, x, orc.pow_(GP, w, i)), (k, i)
+    assert np.array_equal(plan.inverse(y), x)
+    plan.close()
