@@ -354,7 +354,10 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
   pl->p = p; pl->g = g % p; pl->log2n = log2n; pl->n = n; pl->batch = batch; pl->device = device;
   int rc = make_field(p, &pl->field);
   if (rc) { delete pl; return rc; }
-  pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4);
+  // tile path: Goldilocks with the reference generator, 16 <= n <= 2^30 (32-bit lane offsets inside a tile,
+  // grids below 2^31 workgroups); anything else takes the generic radix-2 path
+  pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4 && log2n <= 30 &&
+              batch < ((u64)1 << 31) && (double)batch * (double)n / 2048.0 < 2.0e9);
   if (pl->fast) {
     int max_logc = 4;  // tuning knob (columns per tile = 2^max_logc at most); RONK_MAX_LOGC overrides
     if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) max_logc = v; }
@@ -367,6 +370,8 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
     rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from));
     if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from));
+    for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
+      if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
   } else {
     pl->w_f = h_powmod(pl->g, (p - 1) / n, p);
     pl->w_i = h_powmod(pl->w_f, p - 2, p);                     // root.inverse().unwrap(), mod.rs:433
