@@ -92,6 +92,12 @@ typedef struct ronk_plan ronk_plan;
  * back to back ([batch][n], row-major).  device < 0 = current device.
  * Errors: RONK_ERR_NO_ROOT if 2^log2n does not divide p-1; RONK_ERR_NOT_PRIME. */
 int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device);
+/* Same with planner tuning (-1 = default): tile_log2_columns = log2 of the widest tile (columns per workgroup;
+ * default 4 -> one 128 KiB-LDS workgroup per CU at 2^11 rows, best for one transform at a time; 2 -> two
+ * workgroups per CU, better when several transforms are in flight on different streams);
+ * twiddle_matrix_log2_max = largest full inter-pass twiddle matrix (default 18 = L2-resident only). */
+int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
+                           int tile_log2_columns, int twiddle_matrix_log2_max);
 int ronk_plan_destroy(ronk_plan* plan);
 
 /* Polynomial::<Monomial,F,D>::fft() (polynomial/mod.rs:273-323; same values as dft() :240-258).

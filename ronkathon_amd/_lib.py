@@ -54,6 +54,7 @@ _SIG = {
     "ronk_vec_sub_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
     "ronk_vec_mul_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
     "ronk_plan_create": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int]),
+    "ronk_plan_create_tuned": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int, _int, _int]),
     "ronk_plan_destroy": (_int, [_vp]),
     "ronk_ntt_forward": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_ntt_inverse": (_int, [_vp, _vp, _vp]),
@@ -119,10 +120,11 @@ def out_scalar(fn, *args):
 class Plan:
     """RAII wrapper of ronk_plan: (p, g, n = 2^log2n, batch) on one device."""
 
-    def __init__(self, p, g, log2n, batch=1, device=-1):
+    def __init__(self, p, g, log2n, batch=1, device=-1, tile_log2_columns=-1, twiddle_matrix_log2_max=-1):
         self.h = None
         h = _vp()
-        check(lib.ronk_plan_create(C.byref(h), p, g, log2n, batch, device))
+        check(lib.ronk_plan_create_tuned(C.byref(h), p, g, log2n, batch, device, tile_log2_columns,
+                                         twiddle_matrix_log2_max))
         self.h, self.p, self.g, self.log2n, self.n, self.batch = h, p, g, log2n, 1 << log2n, batch
 
     def close(self):

@@ -341,6 +341,11 @@ extern "C" int ronk_plan_destroy(ronk_plan* pl) {
 }
 
 extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device) {
+  return ronk_plan_create_tuned(out, p, g, log2n, batch, device, -1, -1);
+}
+
+extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
+                                      int tile_log2_columns, int twiddle_matrix_log2_max) {
   if (!out || batch == 0 || log2n > 36) return RONK_ERR_INVALID;
   *out = nullptr;
   RCHK(ronk_check_prime(p));                                   // PrimeField::new -> is_prime
@@ -359,13 +364,17 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
   pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4 && log2n <= 30 &&
               batch < ((u64)1 << 31) && (double)batch * (double)n / 2048.0 < 2.0e9);
   if (pl->fast) {
-    int max_logc = 4;  // tuning knob (columns per tile = 2^max_logc at most); RONK_MAX_LOGC overrides
+    // columns per tile = 2^max_logc at most (4 = 128-byte segments, 1 workgroup per CU at 2^11 rows; 2 = 32-byte
+    // segments but two workgroups per CU, better when several transforms are in flight); RONK_MAX_LOGC overrides
+    int max_logc = 4;
     if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) max_logc = v; }
+    if (tile_log2_columns >= 0 && tile_log2_columns <= 8) max_logc = tile_log2_columns;
     // Full inter-pass twiddle matrix (one coalesced load + one multiply instead of two gathers + two
     // multiplies) while it stays L2-resident: up to 2^18 entries = 2 MiB.  Larger matrices would add an
     // n-element HBM read per transform (measured +4 % speed at 2^22 for +25 % traffic): left to RONK_TWF_MAX_LOG.
     int twf_max_log = 18;
     if (const char* e = getenv("RONK_TWF_MAX_LOG")) { int v = atoi(e); if (v >= 0 && v <= 26) twf_max_log = v; }
+    if (twiddle_matrix_log2_max >= 0 && twiddle_matrix_log2_max <= 26) twf_max_log = twiddle_matrix_log2_max;
     int three_from = 25;  // RONK_THREE_PASS_FROM: split smaller sizes in three passes too (experiment knob)
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
     rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from));
