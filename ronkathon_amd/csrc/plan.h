@@ -117,6 +117,7 @@ struct PlanBuilder {
     p.args.xc = p.args.xb1 = p.args.xb2 = p.args.x0 = 0;
     p.args.yk = p.args.yb1 = p.args.yb2 = p.args.y0 = 0;
     p.args.scale = 1;
+    p.args.in_valid = p.args.out_valid = ~(u64)0;
     p.wr_id = wr_table(logr);
     p.args.wr = nullptr;
     p.tw_id = -1;

@@ -289,7 +289,9 @@ struct CompiledPlan {
     d_wr.clear(); d_tw.clear(); d_twf.clear();
   }
   // launch pass idx: BUF_IN -> in (and in2), BUF_OUT -> out, BUF_TMP -> tmp
-  int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s) const {
+  // in_valid / out_valid: implicit zero padding of the input / truncation of the output (TileArgs), ~0 = none
+  int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
+             u64 out_valid = ~(u64)0) const {
     const PassDesc& ps = pd.passes[idx];
     TileArgs a = ps.args;
     const u64* bufs_in[3] = {in, out, tmp};
@@ -297,6 +299,8 @@ struct CompiledPlan {
     a.in = bufs_in[ps.in_buf];
     a.in2 = (ps.in_buf == BUF_IN) ? in2 : nullptr;
     a.out = bufs_out[ps.out_buf];
+    if (ps.in_buf == BUF_IN) a.in_valid = in_valid;
+    if (ps.out_buf == BUF_OUT) a.out_valid = out_valid;
     a.wr = d_wr[ps.wr_id];
     if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
     if (ps.twf_id >= 0) a.tw_full = d_twf[ps.twf_id];
@@ -304,8 +308,9 @@ struct CompiledPlan {
     if (e != hipSuccess) return hip_fail(e, "launch_tile");
     return RONK_OK;
   }
-  int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s) const {
-    for (size_t i = 0; i < pd.passes.size(); i++) RCHK(launch(i, in, in2, out, tmp, s));
+  int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
+          u64 out_valid = ~(u64)0) const {
+    for (size_t i = 0; i < pd.passes.size(); i++) RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid));
     return RONK_OK;
   }
 };
@@ -434,14 +439,15 @@ static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* ou
   return RONK_OK;
 }
 
-static int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s) {
+static int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s,
+                         u64 in_valid = ~(u64)0, u64 out_valid = ~(u64)0) {
   if (!pl || !in || !out) return RONK_ERR_INVALID;
   if (pl->fast) {
     // in == out is safe: a single-pass plan rewrites exactly the tile it read; multi-pass plans
     // read BUF_IN only in pass 1 and write BUF_OUT only in the last pass.
-    return (inverse ? pl->inv : pl->fwd).run(in, in2, out, pl->d_tmp, s);
+    return (inverse ? pl->inv : pl->fwd).run(in, in2, out, pl->d_tmp, s, in_valid, out_valid);
   }
-  if (in2) return RONK_ERR_UNSUPPORTED;
+  if (in2 || in_valid != ~(u64)0 || out_valid != ~(u64)0) return RONK_ERR_UNSUPPORTED;
   if (pl->log2n == 0) {  // n = 1: fft/ifft are the identity (the recursion returns at n <= 1)
     if (in != out) HIPCHK(hipMemcpyAsync(out, in, pl->batch * 8, hipMemcpyDeviceToDevice, s));
     return RONK_OK;
@@ -657,14 +663,12 @@ extern "C" int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, si
   if (!e->fb) HIPCHK(hipMalloc((void**)&e->fb, N * 8));
   ronk_plan* pl = e->pl;
   HIPCHK(hipStreamWaitEvent(s, e->done, 0));                                // previous use of this entry's scratch
-  if (d < N) HIPCHK(hipMemsetAsync(e->fa + d, 0, (N - d) * 8, s));           // From<[F;N]> zero-pad, mod.rs:503-515
-  if (d2 < N) HIPCHK(hipMemsetAsync(e->fb + d2, 0, (N - d2) * 8, s));
-  HIPCHK(hipMemcpyAsync(e->fa, d_a, d * 8, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->fb, d_b, d2 * 8, hipMemcpyDeviceToDevice, s));
-  RCHK(transform_dev(pl, false, e->fa, nullptr, e->fa, s));
-  RCHK(transform_dev(pl, false, e->fb, nullptr, e->fb, s));
-  RCHK(transform_dev(pl, true, e->fa, e->fb, e->fa, s));                    // pointwise product fused into the load
-  HIPCHK(hipMemcpyAsync(d_out, e->fa, m * 8, hipMemcpyDeviceToDevice, s));
+  // From<[F;N]> zero padding (mod.rs:503-515) is implicit: the forward transforms read the operands in place and
+  // treat indices >= d (d2) as ZERO; the inverse loads NTT(a)*NTT(b) (pointwise product fused into the load) and
+  // stores only the d + d2 - 1 product coefficients, straight into the caller's buffer.  No memset, no copy.
+  RCHK(transform_dev(pl, false, d_a, nullptr, e->fa, s, (u64)d));
+  RCHK(transform_dev(pl, false, d_b, nullptr, e->fb, s, (u64)d2));
+  RCHK(transform_dev(pl, true, e->fa, e->fb, d_out, s, ~(u64)0, (u64)m));
   HIPCHK(hipEventRecord(e->done, s));
   return RONK_OK;
 }

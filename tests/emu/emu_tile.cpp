@@ -153,6 +153,7 @@ int main(int argc, char** argv) {
   int twf = argc > 5 ? atoi(argv[5]) : 0;
   int three_from = argc > 6 ? atoi(argv[6]) : 25;
   PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from);
+  u64 in_valid = argc > 7 ? strtoull(argv[7], 0, 10) : 0, out_valid = argc > 8 ? strtoull(argv[8], 0, 10) : 0;
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
   u64 s = 0x5EED0000ull + log2n;
@@ -170,6 +171,8 @@ int main(int argc, char** argv) {
     a.wr = pd.wr[p.wr_id].data();
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
+    if (in_valid && p.in_buf == BUF_IN) a.in_valid = in_valid;
+    if (out_valid && p.out_buf == BUF_OUT) a.out_valid = out_valid;
     lds.assign(p.lds_bytes / 8 + 1, 0);
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes);
@@ -178,12 +181,15 @@ int main(int argc, char** argv) {
       run_block(p.block);
     }
   }
+  if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
   for (u64 b = 0; b < batch; b++) {
     int rc = inv ? orc_ifft(gl64::P, 7, &in[b * n], &ref[b * n], n) : orc_fft(gl64::P, 7, &in[b * n], &ref[b * n], n);
     if (rc) { printf("oracle rc %d\n", rc); return 1; }
   }
   for (u64 i = 0; i < n * batch; i++)
-    if (out[i] != ref[i]) {
+    if (out_valid && (i % n) >= out_valid) {
+      if (out[i] != 0xDEADBEEFull) { printf("store beyond out_valid at %llu\n", (unsigned long long)i); return 1; }
+    } else if (out[i] != ref[i]) {
       printf("MISMATCH at %llu (poly %llu, k %llu): got %llu want %llu\n", (unsigned long long)i,
              (unsigned long long)(i / n), (unsigned long long)(i % n), (unsigned long long)out[i],
              (unsigned long long)ref[i]);

@@ -45,6 +45,13 @@ def test_two_pass_full_twiddle_matrix(emu, k, batch, inv):
     run(emu, k, batch, inv, 4, 24)
 
 
+@pytest.mark.parametrize("args", [(10, 1, 0, 4, 0, 25, 300, 0), (10, 1, 1, 4, 0, 25, 0, 777), (16, 1, 0, 4, 18, 25, 30000, 0),
+                                  (16, 1, 1, 4, 18, 25, 0, 65535), (13, 1, 0, 4, 18, 13, 5000, 8000)])
+def test_implicit_padding_and_truncation(emu, args):
+    """TileArgs::in_valid / out_valid (polynomial multiply: operands read in place as zero-padded, product truncated)"""
+    run(emu, *args)
+
+
 def test_dist_phases(emu):
     for k, w, inv in ((12, 1, 0), (13, 2, 0), (16, 4, 1), (20, 8, 0)):
         run(emu, "dist", k, w, inv)
