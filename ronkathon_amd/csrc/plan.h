@@ -76,14 +76,17 @@ struct PlanBuilder {
     d.wr.push_back(power_table(root_of_unity_pow2(logr, d.inverse), (size_t)1 << logr));
     return (int)d.wr.size() - 1;
   }
-  int tw_table(int log_n) {
+  // `fold` != 1 pre-multiplies the low-level table: every coefficient receives exactly one inter-pass twiddle,
+  // so the inverse transform's n^-1 (F::from(D).inverse(), polynomial/mod.rs:442) rides along for free.
+  int tw_table(int log_n, u64 fold = 1) {
     for (size_t i = 0; i < d.tw.size(); i++)
-      if (d.tw[i].log_n == log_n) return (int)i;
+      if (d.tw[i].log_n == log_n && fold == 1 && d.tw[i].lo[0] == 1) return (int)i;
     TwTable t;
     t.log_n = log_n;
     t.lo_bits = (log_n + 1) / 2;
     u64 w = root_of_unity_pow2(log_n, d.inverse);
     t.lo = power_table(w, (size_t)1 << t.lo_bits);
+    if (fold != 1) for (auto& v : t.lo) v = gl64::mul(v, fold);
     t.hi = power_table(gl64::pow(w, (u64)1 << t.lo_bits), (size_t)1 << (log_n - t.lo_bits));
     d.tw.push_back(t);
     return (int)d.tw.size() - 1;
@@ -187,7 +190,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
       PassDesc& p = b.add_pass(ka, B, max_logc);  // [A][B]: columns b, rows a
       p.args.in_sj = (i64)B; p.args.in_sc = 1; p.args.out_sk = (i64)B; p.args.out_sc = 1;
       p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
-      p.tw_id = b.tw_table(log2n);
+      p.tw_id = b.tw_table(log2n, scale);        // n^-1 of the inverse folded in
       p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
       p.args.xc = 1; p.args.yk = 1;              // omega_n^{b * ka}
       p.in_buf = BUF_IN; p.out_buf = BUF_TMP;
@@ -197,7 +200,6 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
       PassDesc& p = b.add_pass(kb, A, max_logc);  // rows ka are the columns of this pass
       p.args.in_sj = 1; p.args.in_sc = (i64)B; p.args.out_sk = (i64)A; p.args.out_sc = 1;
       p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
-      p.args.scale = scale;
       p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
       b.finish(p);
     }
@@ -209,7 +211,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
       PassDesc& p = b.add_pass(ka, BC, max_logc);  // [A][B*C]
       p.args.in_sj = (i64)BC; p.args.in_sc = 1; p.args.out_sk = (i64)BC; p.args.out_sc = 1;
       p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
-      p.tw_id = b.tw_table(log2n);
+      p.tw_id = b.tw_table(log2n, scale);        // n^-1 of the inverse folded in
       p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
       p.args.xc = 1; p.args.yk = 1;
       p.in_buf = BUF_IN; p.out_buf = BUF_TMP;
@@ -231,7 +233,6 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
       p.args.in_sj = 1; p.args.in_sc = (i64)BC; p.args.out_sk = (i64)(A * B); p.args.out_sc = 1;
       p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
       p.args.nb2 = (u32)B; p.args.in_sb2 = (i64)C; p.args.out_sb2 = (i64)A;
-      p.args.scale = scale;
       p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
       b.finish(p);
     }
@@ -269,10 +270,11 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
   b.d.log2n = log2n; b.d.inverse = inverse;
   if (!dist_shape(log2n, world, &sh)) return b.d;
   const u64 Cw = sh.Cw, g0 = (u64)rank * Cw;
+  const u64 scale = inverse ? gl64::inv(sh.n % gl64::P) : 1;   // folded into the global twiddle of phase 1
   if (sh.logR <= 12) {
     PassDesc& p = b.add_pass(sh.logR, Cw, max_logc);
     p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)Cw; p.args.out_sc = 1;
-    p.tw_id = b.tw_table(log2n);
+    p.tw_id = b.tw_table(log2n, scale);
     p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
     p.args.xc = 1; p.args.x0 = g0; p.args.yk = 1;            // omega_n^{(g0 + cl) * k1}
     p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
@@ -294,7 +296,7 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
       PassDesc& p = b.add_pass(kb, Cw, max_logc);             // B-point over b, batch ka; k1 = ka + A*kb
       p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)(A * Cw); p.args.out_sc = 1;
       p.args.nb2 = (u32)A; p.args.in_sb2 = (i64)(B * Cw); p.args.out_sb2 = (i64)Cw;
-      p.tw_id = b.tw_table(log2n);
+      p.tw_id = b.tw_table(log2n, scale);
       p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
       p.args.xc = 1; p.args.x0 = g0; p.args.yk = A; p.args.yb2 = 1;   // omega_n^{c * (ka + A*kb)}
       p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
@@ -313,7 +315,7 @@ inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, 
   b.d.log2n = log2n; b.d.inverse = inverse;
   if (!dist_shape(log2n, world, &sh)) return b.d;
   const u64 Cw = sh.Cw, Rw = sh.Rw, C = sh.C;
-  const u64 scale = inverse ? gl64::inv(sh.n % gl64::P) : 1;
+  const u64 scale = 1;  // the inverse's n^-1 is applied by phase 1 (folded into its global twiddle)
   if (sh.logC <= 12) {
     PassDesc& p = b.add_pass(sh.logC, Rw, max_logc);          // columns = local rows k1, rows j = c (blocked)
     p.args.in_sc = (i64)Cw; p.args.in_sj = 1;
