@@ -41,11 +41,13 @@ struct TileArgs {
   const u64* in2;  // optional second operand: x = in * in2 on load (fused pointwise product)
   u64* out;
   // element (j, c) of tile t in batch (b1, b2):
-  //   in [b1*in_sb1 + b2*in_sb2 + (t*C + c)*in_sc + j*in_sj]
-  //   out[b1*out_sb1 + b2*out_sb2 + (t*C + c)*out_sc + k*out_sk]
+  //   in [b1*in_sb1 + b2*in_sb2 + t*in_st + c*in_sc + j*in_sj]
+  //   out[b1*out_sb1 + b2*out_sb2 + t*out_st + c*out_sc + k*out_sk]
   // row j may be split in two levels (the multi-GPU receive buffer is a list of blocks):
   //   row offset = (j >> js_log)*in_sj_hi + (j & (2^js_log - 1))*in_sj      (js_log = 31: flat)
   i64 in_sj, in_sc, in_sb1, in_sb2;
+  i64 in_st, out_st;  // offset of tile t: t*in_st / t*out_st (C*in_sc for a plain matrix; the scratch buffer of a
+                      // two-pass plan is stored tile by tile instead, see plan.h)
   i64 in_sj_hi;
   u32 js_log;
   i64 out_sk, out_sc, out_sb1, out_sb2;
@@ -130,12 +132,27 @@ RONK_HD u64 ld_tab(const u64* table, u32 idx) {
   return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(table) + (u32)(idx << 3));
 }
 
+// Global store of one coefficient.  RONK_STORE_MODE: 0 plain (line stays dirty in the XCD's L2 and is written
+// back at the kernel boundary), 1 non-temporal, 2 write-through (sc1: a relaxed agent-scope atomic store).
+#ifndef RONK_STORE_MODE
+#define RONK_STORE_MODE 0
+#endif
+RONK_HD void st_out(u64* p, u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && RONK_STORE_MODE == 1
+  __builtin_nontemporal_store(v, p);
+#elif defined(__HIP_DEVICE_COMPILE__) && RONK_STORE_MODE == 2
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+
 // ---- the tile body --------------------------------------------------------------------
 //
 // LOGR = 4*(Q-1) + LOGLAST, Q rounds; radices 16,..,16,2^LOGLAST.
 // ABL: ablation mask for tools/ubench only (wrong results by design; 0 in the product):
 //   1 no inter-pass twiddle   2 no round twiddles   4 no butterflies   8 no LDS exchange
-//   16 no global loads        32 no global stores
+//   16 no global loads        32 no global stores        64 twiddle values without table loads
 template <int LOGR, bool INV, int ABL = 0, class Barrier>
 RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
   constexpr int R = 1 << LOGR;
@@ -157,8 +174,8 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   const u32 b1 = bb % a.nb1, b2 = bb / a.nb1;
   const u32 col0 = t << logc;
   const u32 col = col0 + c;
-  const u64* in = a.in + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)col0 * a.in_sc;
-  u64* out = a.out + (i64)b1 * a.out_sb1 + (i64)b2 * a.out_sb2 + (i64)col0 * a.out_sc;
+  const u64* in = a.in + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st;
+  u64* out = a.out + (i64)b1 * a.out_sb1 + (i64)b2 * a.out_sb2 + (i64)t * a.out_st;
   const u32 in_sj = (u32)a.in_sj, out_sk = (u32)a.out_sk;
   const u32 in_lane = c * (u32)a.in_sc, out_lane = c * (u32)a.out_sc;
 
@@ -184,7 +201,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = (u64)(tid * 16 + i);
   } else if (live && a.in_valid != ~(u64)0) {
-    const u64 lin0 = (u64)b2 * (u64)a.in_sb2 + (u64)col0 * (u64)a.in_sc;
+    const u64 lin0 = (u64)b2 * (u64)a.in_sb2 + (u64)t * (u64)a.in_st;
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = (lin0 + joff[i] < a.in_valid) ? in[joff[i]] : 0;
   } else if (live) {
@@ -195,23 +212,19 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
     for (int i = 0; i < 16; i++) x[i] = 0;
   }
   if (a.in2 && live) {
-    const u64* in2 = a.in2 + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)col0 * a.in_sc;
+    const u64* in2 = a.in2 + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st;
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], in2[joff[i]]);
   }
   if (!(ABL & 4)) Dif<16, INV>::run(x);
 
-  u32 klow[16];  // natural output row of register i
-  if (Q == 1) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) klow[i] = brev(i, 4);
-  } else {
+  if (Q > 1) {
     u64* const lc = lds + c;
     // twiddle omega_R^{m*k1}, then park at row k1*M + m
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ld_tab(a.wr, m * k1));
+      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, m * k1)));
       if (!(ABL & 8)) lc[swz_row(k1 * M + m) << logc] = x[i];
     }
     if (!(ABL & 8)) barrier();
@@ -228,7 +241,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
-        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ld_tab(a.wr, tstep * k2));
+        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, tstep * k2)));
         if (!(ABL & 8)) lc[swz_row(base + k2 * RLAST) << logc] = x[i];
       }
       if (!(ABL & 8)) barrier();
@@ -238,62 +251,72 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
     for (int i = 0; i < 16; i++)
       if (!(ABL & 8)) x[i] = lc[swz_row(16 * m + i) << logc];
-    if (!(ABL & 4)) {
-#pragma unroll
-      for (int g = 0; g < 16 / RLAST; g++) Dif<RLAST, INV>::run(x + g * RLAST);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 v = m * (16 / RLAST) + (i >> LOGLAST);           // (d1[,d2]) pair index
-      const u32 kl = (Q == 3) ? ((v >> 4) + 16 * (v & 15)) : v;  // k1 + 16 k2  |  k1
-      klow[i] = kl + (R / RLAST) * brev(i & (RLAST - 1), LOGLAST);
-    }
   }
 
-  // ---- output: optional inter-pass twiddle, optional scale, store at natural row k
-  if (a.tw_full && !(ABL & 1)) {
-    const u64* tf = a.tw_full + (col * a.tf_sc + b2 * a.tf_sb2);
-    if (live) {  // one branch for the 16 loads (dead columns of a ragged tile hold zeros anyway)
-      u64 w[16];
+  // ---- last sub-DFTs + output, one group of GSZ registers at a time (sub-DFT -> inter-pass twiddle -> scale ->
+  // store): the stores of a group are in flight while the next group is still being computed, instead of all
+  // 16 stores of every wave landing together at the very end of the workgroup.
+  constexpr int GSZ = (Q == 1) ? 16 : RLAST;
+  u64* __restrict__ const outp = out;
+  const u32 twX = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
+  const u32 twYb = (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0;
+  const u32 twyk = (u32)a.yk;
+  const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
+  const u32 lmask = (1u << a.tw_lo_bits) - 1;
+  const u64* const tf = a.tw_full ? a.tw_full + (col * a.tf_sc + b2 * a.tf_sb2) : nullptr;
+  const u64 lin_out0 = (u64)b2 * (u64)a.out_sb2 + (u64)t * (u64)a.out_st;
+  u64 keep = 0;
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = tf[klow[i] * a.tf_sk];
+  for (int g = 0; g < 16 / GSZ; g++) {
+    u64* xg = x + g * GSZ;
+    u32 kg[GSZ];  // natural output row of each register of the group
+    if (Q == 1) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], w[i]);
+      for (int i = 0; i < GSZ; i++) kg[i] = brev(i, 4);
+    } else {
+      if (!(ABL & 4)) Dif<RLAST, INV>::run(xg);
+      const u32 v = m * (16 / RLAST) + g;                          // (d1[,d2]) pair index of this group
+      const u32 kl = (Q == 3) ? ((v >> 4) + 16 * (v & 15)) : v;    // k1 + 16 k2  |  k1
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
-  } else if (a.tw_log && !(ABL & 1)) {
-    // exponent (X*Y) mod 2^tw_log with tw_log <= 32: the low 32 bits of a 32-bit product suffice
-    const u32 X = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
-    const u32 Yb = (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0;
-    const u32 yk = (u32)a.yk;
-    const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
-    const u32 lmask = (1u << a.tw_lo_bits) - 1;
+    if (tf && !(ABL & 1)) {
+      if (live) {  // dead columns of a ragged tile hold zeros anyway
+        u64 w[GSZ];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 e = (X * (yk * klow[i] + Yb)) & nmask;
-      const u64 w = gl64::mul(ld_tab(a.tw_lo, e & lmask), ld_tab(a.tw_hi, e >> a.tw_lo_bits));
-      x[i] = gl64::mul(x[i], w);
+        for (int i = 0; i < GSZ; i++) w[i] = tf[kg[i] * a.tf_sk];
+#pragma unroll
+        for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], w[i]);
+      }
+    } else if (a.tw_log && !(ABL & 1)) {
+      // exponent (X*Y) mod 2^tw_log with tw_log <= 32: the low 32 bits of a 32-bit product suffice
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) {
+        const u32 e = (twX * (twyk * kg[i] + twYb)) & nmask;
+        const u64 w = (ABL & 64) ? gl64::mul((u64)e * 0x9E3779B97F4A7C15ull >> 1, (u64)(e >> 3) * 0xC2B2AE3D27D4EB4Full >> 1)
+                                : gl64::mul(ld_tab(a.tw_lo, e & lmask), ld_tab(a.tw_hi, e >> a.tw_lo_bits));
+        xg[i] = gl64::mul(xg[i], w);
+      }
+    }
+    if (a.scale != 1) {
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], a.scale);
+    }
+    if (ABL & 32) {
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) keep ^= xg[i];
+    } else if (live && a.out_valid != ~(u64)0) {
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) {
+        const u32 off = out_lane + kg[i] * out_sk;
+        if (lin_out0 + off < a.out_valid) st_out(outp + off, xg[i]);
+      }
+    } else if (live) {
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) st_out(outp + (out_lane + kg[i] * out_sk), xg[i]);
     }
   }
-  if (a.scale != 1) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], a.scale);
-  }
-  if (ABL & 32) {
-    u64 acc = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc ^= x[i];
-    if (acc == 0x123456789ull) out[0] = acc;  // keeps x live, never true in practice
-  } else if (live && a.out_valid != ~(u64)0) {
-    const u64 lin0 = (u64)b2 * (u64)a.out_sb2 + (u64)col0 * (u64)a.out_sc;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 off = out_lane + klow[i] * out_sk;
-      if (lin0 + off < a.out_valid) out[off] = x[i];
-    }
-  } else if (live) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) out[out_lane + klow[i] * out_sk] = x[i];
-  }
+  if ((ABL & 32) && keep == 0x123456789ull) outp[0] = keep;  // keeps x live, never true in practice
 }
 
 }  // namespace ronk

@@ -115,6 +115,7 @@ struct PlanBuilder {
     p.args.nb1 = p.args.nb2 = 1;
     p.args.in_sb1 = p.args.in_sb2 = p.args.out_sb1 = p.args.out_sb2 = 0;
     p.args.in_sj_hi = 0; p.args.js_log = 31;
+    p.args.in_st = p.args.out_st = 0;
     p.args.tw_log = 0; p.args.tw_lo_bits = 0;
     p.args.tw_lo = p.args.tw_hi = nullptr;
     p.args.xc = p.args.xb1 = p.args.xb2 = p.args.x0 = 0;
@@ -162,6 +163,9 @@ struct PlanBuilder {
     p.args.tf_sk = sk; p.args.tf_sc = sc; p.args.tf_sb2 = sb2;
   }
   void finish(PassDesc& p) {
+    const i64 C = (i64)1 << p.args.logc;
+    if (p.args.in_st == 0) p.args.in_st = C * p.args.in_sc;     // plain matrix: tile t starts at column t*C
+    if (p.args.out_st == 0) p.args.out_st = C * p.args.out_sc;
     p.grid = p.args.tiles * p.args.nb1 * p.args.nb2;
     maybe_full_table(p);
   }
@@ -186,9 +190,18 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
   } else if (log2n <= 24 && log2n < three_pass_from) {
     const int ka = (log2n + 1) / 2, kb = log2n - ka;
     const u64 A = (u64)1 << ka, B = (u64)1 << kb;
+    // The scratch buffer between the two passes is stored TILE BY TILE: element (ka, b) lives at
+    //   (b / Cp)*(A*Cp) + ka*Cp + (b % Cp),     Cp = columns per pass-1 tile.
+    // Pass 1 then writes one contiguous A*Cp block per workgroup (adjacent 64-byte rows pair up into full
+    // 128-byte lines inside one workgroup), and pass 2 -- lanes over (ka, 8 consecutive b) -- reads fully
+    // contiguous 512-byte runs.  Only the two passes see this layout.
+    u32 logcp;
     {
       PassDesc& p = b.add_pass(ka, B, max_logc);  // [A][B]: columns b, rows a
-      p.args.in_sj = (i64)B; p.args.in_sc = 1; p.args.out_sk = (i64)B; p.args.out_sc = 1;
+      logcp = p.args.logc;
+      const i64 Cp = (i64)1 << logcp;
+      p.args.in_sj = (i64)B; p.args.in_sc = 1;
+      p.args.out_sk = Cp; p.args.out_sc = 1; p.args.out_st = (i64)A * Cp;
       p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
       p.tw_id = b.tw_table(log2n, scale);        // n^-1 of the inverse folded in
       p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
@@ -198,7 +211,11 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     }
     {
       PassDesc& p = b.add_pass(kb, A, max_logc);  // rows ka are the columns of this pass
-      p.args.in_sj = 1; p.args.in_sc = (i64)B; p.args.out_sk = (i64)A; p.args.out_sc = 1;
+      const i64 Cp = (i64)1 << logcp, C2 = (i64)1 << p.args.logc;
+      // j = b: (b >> logcp) selects the pass-1 tile, (b & (Cp-1)) the column inside it
+      p.args.in_sj = 1; p.args.js_log = logcp; p.args.in_sj_hi = (i64)A * Cp;
+      p.args.in_sc = Cp; p.args.in_st = C2 * Cp;
+      p.args.out_sk = (i64)A; p.args.out_sc = 1;
       p.args.nb1 = (u32)batch; p.args.in_sb1 = p.args.out_sb1 = (i64)n;
       p.in_buf = BUF_TMP; p.out_buf = BUF_OUT;
       b.finish(p);

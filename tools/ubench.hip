@@ -128,6 +128,8 @@ int main(int argc, char** argv) {
     run_abl<47>(pd, pass, a, "loads only");
     run_abl<31>(pd, pass, a, "stores only");
     run_abl<56>(pd, pass, a, "math only (no mem, no LDS)");
+    run_abl<64>(pd, pass, a, "full, twiddle values without table loads");
+    run_abl<120>(pd, pass, a, "math only, no twiddle loads");
   }
   // ---- raw op rates
   u64* d_scr;
