@@ -8,7 +8,8 @@ coefficients).  With N ranks every rank transforms its own polynomials (the path
 polynomial, no data-path collective): weak scaling, value = N*K / max-over-ranks time.
 Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 Other workloads (--workload): batch16 (1024 x 2^16), mul22 (polynomial multiply, NTT size 2^22),
-roundtrip16 (fwd+inv 2^16), fourstep (sharded four-step NTT with an RCCL all-to-all, N >= 1).
+roundtrip16 (fwd+inv 2^16), fourstep (sharded four-step NTT with an RCCL all-to-all, N >= 1),
+open22 (kzg::open's quotient: 2^22 coefficients / (x - z)), eval22 (Polynomial::evaluate, 2^22 coefficients).
 """
 import argparse
 import json
@@ -93,7 +94,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16}[wl]
+    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16, "open22": 22, "eval22": 22}[wl]
     batch = args.batch or (1024 if wl == "batch16" else 1)
     n = 1 << log2n
     if wl == "batch16":
@@ -114,10 +115,17 @@ def main():
         b = torch.from_numpy(synth(n // 2, 0x5EED1000 + rank).view(np.int64)).cuda()
         a = x[: n // 2].contiguous()
         out = torch.empty(n - 1, dtype=torch.int64, device="cuda")
+    if wl in ("open22", "eval22"):
+        zpt = 0x123456789ABCDEF1 % P                       # evaluation point z; divisor is x - z = [-z, 1]
+        scal = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     def step(i):
         if wl == "mul22":
             L.check(L.lib.ronk_poly_mul_dev(P, G, a.data_ptr(), n // 2, b.data_ptr(), n // 2, out.data_ptr(), stream))
+        elif wl == "open22":
+            L.check(L.lib.ronk_poly_div_linear_dev(P, x.data_ptr(), n, P - zpt, 1, y.data_ptr(), scal.data_ptr(), stream))
+        elif wl == "eval22":
+            L.check(L.lib.ronk_poly_eval_dev(P, x.data_ptr(), n, zpt, scal.data_ptr(), stream))
         elif wl == "roundtrip16":
             plan.forward_dev(x.data_ptr(), y.data_ptr(), stream)
             plan.inverse_dev(y.data_ptr(), y.data_ptr(), stream)
@@ -168,8 +176,9 @@ def main():
     pass_ms = None
     if wl in ("ntt22", "batch16"):
         pass_ms = lat_plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
-    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2}[wl]
-    alg_bytes_step = 16.0 * n * ntts_per_step                       # 16*n bytes per n-point NTT
+    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2, "open22": 1, "eval22": 0.5}[wl]
+    # 16*n bytes per n-point NTT; open22 reads n and writes n coefficients (16*n); eval22 reads n (8*n)
+    alg_bytes_step = 16.0 * n * ntts_per_step
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
     achieved = alg_bytes_step / step_s / 1e9
     # HBM bytes per launch from the PMC passes of the same command under rocprofv3 (tools/rocprof_summary.py;
@@ -189,7 +198,9 @@ def main():
                                 "algorithmic bytes = %d per transform (16*n), i.e. %d per launch of the 2-launch plan; each launch reads and "
                                 "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
                                 "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n) if traffic else None,
-                "kernel": "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes()),
+                "kernel": {"open22": "chunk_horner_kernel + chunk_carry_kernel + lindiv_apply_kernel (csrc/scan_kernels.h)",
+                           "eval22": "chunk_horner_kernel + chunk_carry_kernel (csrc/scan_kernels.h)"}.get(
+                               wl, "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes())),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "note": "achieved/frac: one transform at a time on ONE stream, default plan (kernel durations); "
                         "value: %d streams%s" % (S, ", plans tuned for concurrency (tile_log2_columns=2)" if tile_lc >= 0 else ""),

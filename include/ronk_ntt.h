@@ -143,6 +143,9 @@ int ronk_poly_sub(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, si
 
 /* Polynomial::<Monomial>::evaluate (polynomial/mod.rs:133-139): sum c_i x^i */
 int ronk_poly_eval(uint64_t p, const uint64_t* c, size_t d, uint64_t x, uint64_t* out);
+/* same, coefficients resident in HBM, result (ONE element) written to device memory, asynchronous on `stream`
+ * (a hipStream_t).  One 8 B/coefficient read of the array (chunked Horner, csrc/scan_kernels.h). */
+int ronk_poly_eval_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t x, uint64_t* d_out, void* stream);
 /* Polynomial::<Lagrange<F>>::evaluate (polynomial/mod.rs:382-415): barycentric evaluation at x from the
  * values c[j] at nodes[j].  As in the reference, x equal to a node yields ZERO (its fold multiplies by
  * l(x) = 0); coincident nodes -> RONK_ERR_ZERO_INVERSE.  n <= 2^16 (O(n^2) weights, like the reference). */
@@ -151,6 +154,12 @@ int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, siz
  * quot and rem both have d coefficients.  Used by kzg::open (src/kzg/setup.rs:63-78). */
 int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,
                      uint64_t* rem);
+/* kzg::open's polynomial step on device (src/kzg/setup.rs:63-78: `poly.div([-z, 1])`): division by the linear
+ * divisor b0 + b1*x, b1 != 0, as an affine suffix scan.  d_quot receives d coefficients (the top one ZERO, like the
+ * reference's D-long quotient); d_rem (may be NULL) receives ONE element, the remainder's constant coefficient (its
+ * other coefficients are ZERO).  Asynchronous on `stream`. */
+int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t b0, uint64_t b1, uint64_t* d_quot,
+                             uint64_t* d_rem, void* stream);
 /* Reed-Solomon Message::encode::<N> (src/codes/reed_solomon.rs:42-52): xs[i] = omega_N^i,
  * ys[i] = poly(omega_N^i) -- a size-N DFT of the zero-padded K-coefficient message. */
 int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t n, uint64_t* xs, uint64_t* ys);

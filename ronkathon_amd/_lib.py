@@ -8,6 +8,15 @@ import os
 
 import numpy as np
 
+# PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  In a process that uses both, torch's copy has to be
+# mapped BEFORE the system runtime this library links against (the other order leaves torch with "No HIP GPUs
+# are available" -- measured on ROCm 7.2 + torch 2.10/rocm7.0).  So: import torch first when it is installed.
+# The library itself never calls into torch; callers hand it raw device pointers and hipStream_t values.
+try:
+    import torch  # noqa: F401
+except Exception:  # noqa: BLE001  (no torch: nothing to order)
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libronk_ntt.so")
 
@@ -71,6 +80,8 @@ _SIG = {
     "ronk_poly_add": (_int, [_u64, _vp, _sz, _vp, _sz, _vp]),
     "ronk_poly_sub": (_int, [_u64, _vp, _sz, _vp, _sz, _vp]),
     "ronk_poly_eval": (_int, [_u64, _vp, _sz, _u64, _pu]),
+    "ronk_poly_eval_dev": (_int, [_u64, _vp, _sz, _u64, _vp, _vp]),
+    "ronk_poly_div_linear_dev": (_int, [_u64, _vp, _sz, _u64, _u64, _vp, _vp, _vp]),
     "ronk_lagrange_eval": (_int, [_u64, _vp, _vp, _sz, _u64, _pu]),
     "ronk_poly_divrem": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp]),
     "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),

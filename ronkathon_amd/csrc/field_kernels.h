@@ -125,40 +125,6 @@ __global__ void __launch_bounds__(256) poly_mul_schoolbook_kernel(Ops ops, const
   }
 }
 
-// Polynomial::evaluate (polynomial/mod.rs:133-139): sum c_i x^i.  Each work-item walks a strided
-// subsequence with a running power, a block tree-reduces in LDS, one partial per block.
-template <class Ops>
-__global__ void __launch_bounds__(256) poly_eval_partial_kernel(Ops ops, const u64* __restrict__ c, size_t d, u64 x,
-                                                                 u64* __restrict__ partial) {
-  __shared__ u64 red[256];
-  const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
-  u64 acc = 0;
-  if (i0 < d) {
-    u64 xi = ops.pow(x, i0), xs = ops.pow(x, step);
-    for (size_t i = i0; i < d; i += step) { acc = ops.add(acc, ops.mul(c[i], xi)); xi = ops.mul(xi, xs); }
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = ops.add(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-template <class Ops>
-__global__ void __launch_bounds__(256) sum_kernel(Ops ops, const u64* __restrict__ partial, size_t n, u64* out) {
-  __shared__ u64 red[256];
-  u64 acc = 0;
-  for (size_t i = threadIdx.x; i < n; i += 256) acc = ops.add(acc, partial[i]);
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = ops.add(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *out = red[0];
-}
-
 // quotient_and_remainder (polynomial/mod.rs:170-225), one workgroup, followed step by step:
 // the loop guard compares the remainder's TRIMMED length with the divisor's UNTRIMMED length d2,
 // the update walks all d2 divisor coefficients, a zero divisor or an out-of-range update is the
@@ -283,99 +249,6 @@ __global__ void __launch_bounds__(256) lagrange_finish_kernel(Ops ops, const u64
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = ops.mul(rp[0], rs[0]);
-}
-
-// ---- division by a LINEAR divisor b0 + b1*x (kzg::open, src/kzg/setup.rs:63-78) as a parallel scan --
-// With z = -b0/b1 and c' = c/b1:  q_j = sum_{i>j} c'_i z^(i-j-1) = z^-(j+1) * S_(j+1),  S_j = sum_{i>=j} c'_i z^i,
-// remainder = p(z) = b1 * S_0.  Same polynomials as the reference's long division (mod.rs:170-225) for a
-// divisor whose x-coefficient is non-zero.  Three launches over chunks of 4096 coefficients:
-//   1  t_i = c_i * b1inv * z^i, chunk sums        2  exclusive suffix scan of the chunk sums (one workgroup)
-//   3  in-chunk suffix scan + chunk offset, q_j = zinv^(j+1) * S_(j+1)
-// z == 0 (divisor b1*x) is handled by the caller as a shift.
-constexpr int SCAN_CHUNK = 4096;  // 256 work-items x 16
-
-template <class Ops>
-__global__ void __launch_bounds__(256) lindiv_scale_kernel(Ops ops, const u64* __restrict__ c, size_t d, u64 b1inv, u64 z,
-                                                            u64* __restrict__ t, u64* __restrict__ chunk_sum) {
-  __shared__ u64 red[256];
-  const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
-  u64 acc = 0;
-  // lane-strided inside the chunk: coalesced loads, running power z^256 per step
-  size_t i = base + threadIdx.x;
-  u64 zi = ops.mul(ops.pow(z, i), b1inv);
-  const u64 zstep = ops.pow(z, 256);
-  for (int r = 0; r < SCAN_CHUNK / 256; r++, i += 256) {
-    if (i < d) {
-      const u64 v = ops.mul(c[i], zi);
-      t[i] = v;
-      acc = ops.add(acc, v);
-    }
-    zi = ops.mul(zi, zstep);
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = ops.add(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = red[0];
-}
-
-// in place: chunk_sum[b] <- sum of chunk sums with index > b (exclusive suffix); total <- sum of all
-template <class Ops>
-__global__ void __launch_bounds__(1024) lindiv_chunk_scan_kernel(Ops ops, u64* __restrict__ chunk_sum, size_t nchunks,
-                                                                  u64* __restrict__ total) {
-  __shared__ u64 buf[4096];
-  const int tid = threadIdx.x;
-  for (size_t i = tid; i < 4096; i += 1024) buf[i] = i < nchunks ? chunk_sum[i] : 0;
-  __syncthreads();
-  // Hillis-Steele inclusive suffix scan over 4096 entries, 4 per work-item
-  for (int off = 1; off < 4096; off <<= 1) {
-    u64 v[4];
-    for (int k = 0; k < 4; k++) { int i = tid + k * 1024; v[k] = i + off < 4096 ? ops.add(buf[i], buf[i + off]) : buf[i]; }
-    __syncthreads();
-    for (int k = 0; k < 4; k++) buf[tid + k * 1024] = v[k];
-    __syncthreads();
-  }
-  if (tid == 0) *total = buf[0];
-  for (size_t i = tid; i < nchunks; i += 1024) chunk_sum[i] = i + 1 < 4096 ? buf[i + 1] : 0;
-}
-
-template <class Ops>
-__global__ void __launch_bounds__(256) lindiv_finish_kernel(Ops ops, const u64* __restrict__ t, size_t d, u64 zinv,
-                                                             const u64* __restrict__ chunk_off, u64* __restrict__ quot) {
-  __shared__ u64 buf[SCAN_CHUNK];
-  __shared__ u64 part[256];
-  const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
-  const int tid = threadIdx.x;
-  for (int r = 0; r < SCAN_CHUNK / 256; r++) { size_t i = base + tid + r * 256; buf[tid + r * 256] = i < d ? t[i] : 0; }
-  __syncthreads();
-  // each work-item owns 16 consecutive entries: local suffix sums, then a scan of the 256 partials
-  u64 loc[16], run = 0;
-  for (int k = 15; k >= 0; k--) { run = ops.add(run, buf[tid * 16 + k]); loc[k] = run; }
-  part[tid] = run;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    u64 v = tid + off < 256 ? ops.add(part[tid], part[tid + off]) : part[tid];
-    __syncthreads();
-    part[tid] = v;
-    __syncthreads();
-  }
-  const u64 after = ops.add(tid + 1 < 256 ? part[tid + 1] : 0, chunk_off[blockIdx.x]);  // everything above my 16
-  for (int k = 0; k < 16; k++) buf[tid * 16 + k] = ops.add(loc[k], after);                 // S_i for i in this chunk
-  __syncthreads();
-  // q_j = zinv^(j+1) * S_(j+1): S_(j+1) is buf[j+1-base], or the first S of the next chunk = chunk_off
-  size_t j = base + tid;
-  u64 zj = ops.pow(zinv, j + 1);
-  const u64 zstep = ops.pow(zinv, 256);
-  for (int r = 0; r < SCAN_CHUNK / 256; r++, j += 256) {
-    if (j < d) {
-      const size_t l = j + 1 - base;
-      const u64 S = j + 1 >= d ? 0 : (l < (size_t)SCAN_CHUNK ? buf[l] : chunk_off[blockIdx.x]);
-      quot[j] = ops.mul(S, zj);
-    }
-    zj = ops.mul(zj, zstep);
-  }
 }
 
 // ---- generic power-of-two NTT for fields without the Goldilocks fast path -------------------

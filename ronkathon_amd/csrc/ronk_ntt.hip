@@ -15,6 +15,7 @@
 
 #include "../../include/ronk_ntt.h"
 #include "field_kernels.h"
+#include "scan_kernels.h"
 #include "plan.h"
 #include "tile_launch.h"
 
@@ -687,23 +688,144 @@ extern "C" int ronk_poly_mul(uint64_t p, uint64_t g, const uint64_t* a, size_t d
 }
 
 // ------------------------------------------------------------------------------ evaluate / divrem / RS
+// Workspace pool for the scan entry points: hipMalloc'd buffers, each guarded by a completion event, so a call
+// never synchronises the device and never frees memory that queued work still uses.  A slot is reused when its
+// last work has completed or was queued on the same stream (stream order then protects it).  (hipMallocAsync /
+// hipFreeAsync were tried first and dropped: on ROCm 7.2 / gfx950 a kernel intermittently read stale data from
+// a pool block reused across calls -- 4 of 12 test runs -- while plain allocations never did.)
+struct WsSlot {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;   // ever had work queued
+  bool busy = false;   // leased right now
+};
+static std::mutex g_ws_mu;
+static std::vector<WsSlot*> g_ws;
+struct WsLease {
+  WsSlot* slot = nullptr;
+  hipStream_t s = nullptr;
+  ~WsLease() {
+    if (!slot) return;
+    (void)hipEventRecord(slot->done, s);
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    slot->last = s; slot->used = true; slot->busy = false;
+  }
+  int acquire(size_t bytes, hipStream_t st) {
+    s = st;
+    size_t need = 65536;
+    while (need < bytes) need <<= 1;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    size_t on_dev = 0;
+    WsSlot* waitable = nullptr;
+    for (WsSlot* w : g_ws) {
+      if (w->device != dev) continue;
+      on_dev++;
+      if (w->busy || w->bytes < need) continue;
+      if (!w->used || w->last == st || hipEventQuery(w->done) == hipSuccess) { slot = w; break; }
+      if (!waitable) waitable = w;
+    }
+    if (!slot && waitable && on_dev >= 32) {  // bound the pool: wait for an old slot instead of growing
+      (void)hipEventSynchronize(waitable->done);
+      slot = waitable;
+    }
+    if (!slot) {
+      WsSlot* w = new WsSlot();
+      hipError_t e = hipMalloc(&w->p, need);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+      if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); delete w; return hip_fail(e, "workspace"); }
+      w->bytes = need; w->device = dev;
+      g_ws.push_back(w);
+      slot = w;
+    }
+    slot->busy = true;
+    return RONK_OK;
+  }
+  u64* u() const { return (u64*)slot->p; }
+};
+static void make_horner_tab(u64 p, u64 z, u64 scale, HornerTab* t) {
+  u64 x = 1 % p;
+  for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
+  t->z256 = x;
+  u64 y = t->zt[16];
+  for (int s = 0; s < 8; s++) { t->z16p[s] = y; y = h_mulmod(y, y, p); }
+  y = h_powmod(z, HCHUNK, p);
+  for (int s = 0; s < 10; s++) { t->Zp[s] = y; y = h_mulmod(y, y, p); }
+  t->z = z % p;
+  t->scale = scale;
+}
+// chunk sums + carry scan shared by evaluate and the linear division: ws = [H: nchunks][carry: nchunks];
+// total (may be null) receives c(z) directly from the scan kernel
+static int horner_reduce_dev(const FieldCtx& f, const u64* d_c, size_t d, const HornerTab& tab, u64* ws, size_t nchunks,
+                             u64* total, hipStream_t s) {
+  u64* H = ws; u64* carry = ws + nchunks;
+  FIELD_DISPATCH(f, {
+    hipLaunchKernelGGL((chunk_horner_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, s, ops, d_c, d, tab, H);
+    hipLaunchKernelGGL((chunk_carry_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, s, ops, H, nchunks, tab, carry, total);
+  });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+static const size_t HORNER_MAX = (size_t)HCHUNK << 31;  // grid limit
+
+extern "C" int ronk_poly_eval_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t x, uint64_t* d_out, void* stream) {
+  if (!d_out || (!d_c && d)) return RONK_ERR_INVALID;
+  if (d > HORNER_MAX) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  hipStream_t s = (hipStream_t)stream;
+  if (d == 0) { HIPCHK(hipMemsetAsync(d_out, 0, 8, s)); return RONK_OK; }
+  const size_t nchunks = (d + HCHUNK - 1) / HCHUNK;
+  HornerTab tab;
+  make_horner_tab(p, x % p, 1, &tab);
+  WsLease ws;
+  RCHK(ws.acquire(2 * nchunks * 8, s));
+  RCHK(horner_reduce_dev(f, d_c, d, tab, ws.u(), nchunks, d_out, s));
+  return RONK_OK;
+}
 extern "C" int ronk_poly_eval(uint64_t p, const uint64_t* c, size_t d, uint64_t x, uint64_t* out) {
   if (!c || !out) return RONK_ERR_INVALID;
   RCHK(need_device());
   FieldCtx f;
   RCHK(make_field(p, &f));
   if (d == 0) { *out = 0; return RONK_OK; }
-  const u32 blocks = d < 256 * 64 ? 1 : 256;
-  DevBuf dc, dpart, dres;
-  RCHK(dc.alloc(d * 8)); RCHK(dpart.alloc(blocks * 8)); RCHK(dres.alloc(8));
+  DevBuf dc, dres;
+  RCHK(dc.alloc(d * 8)); RCHK(dres.alloc(8));
   HIPCHK(hipMemcpy(dc.p, c, d * 8, hipMemcpyHostToDevice));
-  FIELD_DISPATCH(f, {
-    hipLaunchKernelGGL((poly_eval_partial_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, 0, ops, dc.u(), d, x % p,
-                       dpart.u());
-    hipLaunchKernelGGL((sum_kernel<decltype(ops)>), dim3(1), dim3(256), 0, 0, ops, dpart.u(), (size_t)blocks, dres.u());
-  });
-  HIPCHK(hipGetLastError());
+  RCHK(ronk_poly_eval_dev(p, dc.u(), d, x, dres.u(), 0));
   HIPCHK(hipMemcpy(out, dres.p, 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+
+// poly / (b0 + b1 x), b1 != 0: the kzg::open shape (src/kzg/setup.rs:63-78).  d_quot: d coefficients (the top one
+// is ZERO, as in the reference's D-long quotient); d_rem (optional): ONE element, the remainder's constant
+// coefficient c(-b0/b1) -- its other d-1 coefficients are ZERO.
+extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t b0, uint64_t b1,
+                                        uint64_t* d_quot, uint64_t* d_rem, void* stream) {
+  if (!d_c || !d_quot || d == 0) return RONK_ERR_INVALID;
+  if (d > HORNER_MAX) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  b0 %= p; b1 %= p;
+  if (b1 == 0) return RONK_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const u64 b1inv = h_powmod(b1, p - 2, p);
+  const u64 z = h_mulmod((p - b0) % p, b1inv, p);        // -b0 / b1
+  const size_t nchunks = (d + HCHUNK - 1) / HCHUNK;
+  HornerTab tab;
+  make_horner_tab(p, z, b1inv, &tab);
+  WsLease ws;
+  RCHK(ws.acquire(2 * nchunks * 8, s));
+  RCHK(horner_reduce_dev(f, d_c, d, tab, ws.u(), nchunks, d_rem, s));
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_apply_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, s, ops, d_c, d,
+                                        tab, ws.u() + nchunks, d_quot); });
+  HIPCHK(hipGetLastError());
   return RONK_OK;
 }
 
@@ -741,29 +863,15 @@ extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const u
   RCHK(need_device());
   FieldCtx f;
   RCHK(make_field(p, &f));
-  // kzg::open shape (src/kzg/setup.rs:63-78): a linear divisor b0 + b1*x with b1 != 0, b0 != 0 -> parallel scan
-  if (d2 == 2 && d >= 2 && b[1] % p != 0 && b[0] % p != 0 && d <= (size_t)SCAN_CHUNK * 4096 && p > 2) {
-    const u64 b0 = b[0] % p, b1 = b[1] % p;
-    const u64 b1inv = h_powmod(b1, p - 2, p);
-    const u64 z = h_mulmod(p - b0, b1inv, p);          // -b0 / b1
-    const u64 zinv = h_powmod(z, p - 2, p);
-    const size_t nchunks = (d + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    DevBuf dc, dt, dsum, dtot, dqq;
-    RCHK(dc.alloc(d * 8)); RCHK(dt.alloc(d * 8)); RCHK(dsum.alloc(nchunks * 8)); RCHK(dtot.alloc(8)); RCHK(dqq.alloc(d * 8));
+  // kzg::open shape (src/kzg/setup.rs:63-78): a linear divisor b0 + b1*x with b1 != 0 -> Horner scan
+  if (d2 == 2 && b[1] % p != 0 && d <= HORNER_MAX) {
+    DevBuf dc, dqq, dr;
+    RCHK(dc.alloc(d * 8)); RCHK(dqq.alloc(d * 8)); RCHK(dr.alloc(8));
     HIPCHK(hipMemcpy(dc.p, a, d * 8, hipMemcpyHostToDevice));
-    FIELD_DISPATCH(f, {
-      hipLaunchKernelGGL((lindiv_scale_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, 0, ops, dc.u(), d, b1inv, z,
-                         dt.u(), dsum.u());
-      hipLaunchKernelGGL((lindiv_chunk_scan_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, 0, ops, dsum.u(), nchunks, dtot.u());
-      hipLaunchKernelGGL((lindiv_finish_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, 0, ops, dt.u(), d, zinv,
-                         dsum.u(), dqq.u());
-    });
-    HIPCHK(hipGetLastError());
-    u64 s0 = 0;
-    HIPCHK(hipMemcpy(&s0, dtot.p, 8, hipMemcpyDeviceToHost));
+    RCHK(ronk_poly_div_linear_dev(p, dc.u(), d, b[0], b[1], dqq.u(), dr.u(), 0));
     HIPCHK(hipMemcpy(quot, dqq.p, d * 8, hipMemcpyDeviceToHost));
     memset(rem, 0, d * 8);
-    rem[0] = h_mulmod(s0, b1, p);                      // remainder = p(z) = b1 * S_0
+    HIPCHK(hipMemcpy(rem, dr.p, 8, hipMemcpyDeviceToHost));
     return RONK_OK;
   }
   DevBuf drem, db, dq, dst;

