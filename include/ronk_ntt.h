@@ -163,6 +163,10 @@ int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t
 /* Reed-Solomon Message::encode::<N> (src/codes/reed_solomon.rs:42-52): xs[i] = omega_N^i,
  * ys[i] = poly(omega_N^i) -- a size-N DFT of the zero-padded K-coefficient message. */
 int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t n, uint64_t* xs, uint64_t* ys);
+/* Reed-Solomon Message::decode (src/codes/reed_solomon.rs:54-106): Lagrange interpolation through the first k
+ * coordinates (xs[j], ys[j]) of a (possibly erased) codeword -> the k message coefficients.  Coincident nodes are
+ * the reference's `numerator / denominator` panic -> RONK_ERR_ZERO_INVERSE.  k <= 2^14 (O(k^2) work). */
+int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out);
 
 /* ---- multi-GPU four-step building blocks (one process per GPU; the exchange between the two
  *      phases is an RCCL all-to-all issued by the host side, see ronkathon_amd/dist.py) ----

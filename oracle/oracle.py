@@ -77,6 +77,7 @@ def _load():
         "orc_leading_coefficient": (u64, [pu, sz]),
         "orc_poly_from": (None, [pu, sz, pu, sz]),
         "orc_rs_encode": (C.c_int, [u64, u64, pu, sz, sz, pu, pu]),
+        "orc_rs_decode": (C.c_int, [u64, pu, pu, sz, pu]),
         "orc_kzg_open_quotient": (C.c_int, [u64, pu, sz, u64, pu]),
         "orc_fft_recursive": (None, [u64, pu, sz, u64]),
     }
@@ -253,6 +254,15 @@ def rs_encode(p, g, msg, n):
     xs = np.empty(n, dtype=np.uint64); ys = np.empty(n, dtype=np.uint64)
     _chk(_lib.orc_rs_encode(p, g, _p(msg), msg.size, n, _p(xs), _p(ys)))
     return xs, ys
+
+
+def rs_decode(p, xs, ys, k):
+    """Message::decode (codes/reed_solomon.rs:54-106): the first k coordinates -> k message coefficients"""
+    xs = _arr(xs); ys = _arr(ys)
+    assert xs.size >= k and ys.size >= k
+    out = np.empty(k, dtype=np.uint64)
+    _chk(_lib.orc_rs_decode(p, _p(xs), _p(ys), k, _p(out)))
+    return out
 
 
 def kzg_open_quotient(p, coeffs, z):

@@ -388,6 +388,45 @@ int orc_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t 
   return ORC_OK;
 }
 
+/* codes/reed_solomon.rs:54-106, Message::decode: Lagrange interpolation through the FIRST k coordinates,
+ *   data[i] += (i odd ? -1 : 1) * (sum over (k-1-i)-subsets of {x_m : m != j} of their product) * y_j
+ *              / prod_{m != j} (x_m - x_j)
+ * The subset sum is the elementary symmetric polynomial e_(k-1-i) of the k-1 remaining nodes; it is built
+ * here with the usual recurrence e_r(v_1..v_n) = e_r(v_1..v_(n-1)) + v_n * e_(r-1)(v_1..v_(n-1)) instead of
+ * enumerating `combinations` (same value, field arithmetic is exact).  `numerator / denominator` is
+ * Div -> inverse().unwrap() (prime/arithmetic.rs:50-55): coincident nodes panic. */
+int orc_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out) {
+  if (k == 0) return ORC_OK;
+  uint64_t* e = (uint64_t*)malloc(k * sizeof *e); /* e[r], r = 0..k-1 */
+  for (size_t i = 0; i < k; i++) out[i] = 0;
+  for (size_t j = 0; j < k; j++) {
+    /* elementary symmetric polynomials of the nodes without x_j */
+    for (size_t r = 0; r < k; r++) e[r] = 0;
+    e[0] = 1 % p;
+    size_t cnt = 0;
+    for (size_t m = 0; m < k; m++) {
+      if (m == j) continue;
+      cnt++;
+      for (size_t r = cnt; r >= 1; r--) e[r] = orc_add(p, e[r], orc_mul(p, xs[m] % p, e[r - 1]));
+    }
+    uint64_t den = 1 % p; /* reed_solomon.rs:92-99 */
+    for (size_t m = 0; m < k; m++) {
+      if (m == j) continue;
+      den = orc_mul(p, den, orc_sub(p, xs[m] % p, xs[j] % p));
+    }
+    for (size_t i = 0; i < k; i++) {
+      uint64_t xc = e[k - 1 - i];
+      if (i % 2 == 1) xc = orc_mul(p, orc_sub(p, 0, 1 % p), xc); /* (ZERO - ONE) * ..., :78-82 */
+      uint64_t num = orc_mul(p, xc, ys[j] % p), q;
+      int rc = orc_div(p, num, den, &q);
+      if (rc) { free(e); return rc; }
+      out[i] = orc_add(p, out[i], q);
+    }
+  }
+  free(e);
+  return ORC_OK;
+}
+
 /* kzg/setup.rs:63-78: poly.div([-z, 1]) */
 int orc_kzg_open_quotient(uint64_t p, const uint64_t* coeffs, size_t d, uint64_t z, uint64_t* quot) {
   uint64_t divisor[2] = {orc_neg(p, z), 1 % p};

@@ -78,6 +78,8 @@ void orc_poly_from(const uint64_t* c, size_t n, uint64_t* out, size_t d);       
 /* ---- callers either side of the path ("next" rows) ---- */
 /* Reed-Solomon encode: src/codes/reed_solomon.rs:42-52; x[i]=w^i, y[i]=poly(w^i), i<n */
 int orc_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t n, uint64_t* xs, uint64_t* ys);
+/* codes/reed_solomon.rs:54-106: interpolate the first k coordinates back to the k message coefficients */
+int orc_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out);
 /* KZG open quotient: src/kzg/setup.rs:63-78; poly / (x - z), length d */
 int orc_kzg_open_quotient(uint64_t p, const uint64_t* coeffs, size_t d, uint64_t z, uint64_t* quot);
 

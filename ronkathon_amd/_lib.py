@@ -85,6 +85,7 @@ _SIG = {
     "ronk_lagrange_eval": (_int, [_u64, _vp, _vp, _sz, _u64, _pu]),
     "ronk_poly_divrem": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp]),
     "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),
+    "ronk_rs_decode": (_int, [_u64, _vp, _vp, _sz, _vp]),
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
     "ronk_dist_plan_destroy": (_int, [_vp]),
     "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),

@@ -25,6 +25,20 @@ class Message:
         return xs, ys
 
 
+    @classmethod
+    def decode(cls, field, xs, ys, K):
+        """`Message::decode::<M>` (codes/reed_solomon.rs:54-106): interpolate the first K coordinates of a
+        codeword (after erasures: any K surviving coordinates, in any order) back to the K message symbols."""
+        xs = L.arr([int(v) % field.ORDER for v in xs]); ys = L.arr([int(v) % field.ORDER for v in ys])
+        if xs.size < K or ys.size < K:
+            raise L.RonkPanic(L.ERR_INDEX, "Code size must be greater than or equal to K")  # assert_ge::<M, K>()
+        out = np.empty(K, dtype=np.uint64)
+        L.check(L.lib.ronk_rs_decode(field.ORDER, L.ptr(xs), L.ptr(ys), K, L.ptr(out)))
+        msg = cls.__new__(cls)
+        msg.field, msg.data = field, out
+        return msg
+
+
 def kzg_open_quotient(field, coeffs, eval_point):
     """`kzg::open`'s polynomial step (kzg/setup.rs:63-78): Polynomial::new(coeffs).div([-z, 1])."""
     poly = Polynomial.new(field, coeffs)

@@ -16,6 +16,7 @@
 #include "../../include/ronk_ntt.h"
 #include "field_kernels.h"
 #include "scan_kernels.h"
+#include "interp_kernels.h"
 #include "plan.h"
 #include "tile_launch.h"
 
@@ -900,6 +901,40 @@ extern "C" int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_
   std::vector<u64> padded(n, 0);
   memcpy(padded.data(), msg, k * 8);
   return ronk_dft(p, g, padded.data(), ys, n);
+}
+
+// Message::decode (codes/reed_solomon.rs:54-106): the first k coordinates -> the k message coefficients
+extern "C" int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out) {
+  if (k == 0) return RONK_OK;
+  if (!xs || !ys || !out) return RONK_ERR_INVALID;
+  if (k > RS_DECODE_MAX_K) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  const u32 nblk = (u32)((k + 255) / 256);
+  std::vector<u64> hx(k), hy(k);
+  for (size_t i = 0; i < k; i++) { hx[i] = xs[i] % p; hy[i] = ys[i] % p; }
+  DevBuf dx, dy, dw, dm, dpart, dout, dflag;
+  RCHK(dx.alloc(k * 8)); RCHK(dy.alloc(k * 8)); RCHK(dw.alloc(k * 8)); RCHK(dm.alloc((k + 1) * 8));
+  RCHK(dpart.alloc((size_t)nblk * k * 8)); RCHK(dout.alloc(k * 8)); RCHK(dflag.alloc(4));
+  HIPCHK(hipMemcpy(dx.p, hx.data(), k * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dy.p, hy.data(), k * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dflag.p, 0, 4));
+  FIELD_DISPATCH(f, {
+    hipLaunchKernelGGL((rs_weights_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, 0, ops, dx.u(), dy.u(), k, dw.u(),
+                       (int*)dflag.p);
+    hipLaunchKernelGGL((master_poly_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, 0, ops, dx.u(), k, dm.u());
+    hipLaunchKernelGGL((rs_accumulate_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, 0, ops, dx.u(), dw.u(), dm.u(), k,
+                       dpart.u());
+    hipLaunchKernelGGL((rs_finish_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, 0, ops, dpart.u(), (size_t)nblk, k,
+                       dout.u());
+  });
+  HIPCHK(hipGetLastError());
+  int hflag = 0;
+  HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
+  if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: numerator / ZERO
+  HIPCHK(hipMemcpy(out, dout.p, k * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
 }
 
 // ------------------------------------------------------------------------------ multi-GPU four-step

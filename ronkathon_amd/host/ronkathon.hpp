@@ -179,4 +179,32 @@ Polynomial<Monomial, F, D> operator%(const Polynomial<Monomial, F, D>& a, const 
   return a.quotient_and_remainder_dyn(b.raw(), D2).second;
 }
 
+// ---- Reed-Solomon (src/codes/reed_solomon.rs) ---------------------------------------------------------
+template <class F> struct Coordinate { F x, y; };                                                   // :27-35
+template <size_t N, size_t K, class F> struct Codeword { std::array<Coordinate<F>, N> data; };       // :20-25
+template <size_t K, class F>
+struct Message {                                                                                     // :14-18
+  std::array<F, K> data;
+  static Message new_(std::array<F, K> d) { return Message{d}; }                                     // :39
+  // Message::encode::<N> (:42-52): x_i = root^i, y_i = polynomial.evaluate(root^i)
+  template <size_t N> Codeword<N, K, F> encode() const {
+    static_assert(N >= K, "Code size must be greater than or equal to K");                            // assert_ge, :108-110
+    std::array<uint64_t, N> xs, ys;
+    check(ronk_rs_encode(F::ORDER, F::PRIMITIVE_ELEMENT().value, reinterpret_cast<const uint64_t*>(data.data()), K, N,
+                         xs.data(), ys.data()));
+    Codeword<N, K, F> cw;
+    for (size_t i = 0; i < N; i++) { cw.data[i].x.value = xs[i]; cw.data[i].y.value = ys[i]; }
+    return cw;
+  }
+  // Message::decode::<M> (:54-106): interpolate the first K coordinates
+  template <size_t M> static Message decode(const Codeword<M, K, F>& cw) {
+    static_assert(M >= K, "Code size must be greater than or equal to K");
+    std::array<uint64_t, K> xs, ys;
+    for (size_t i = 0; i < K; i++) { xs[i] = cw.data[i].x.value; ys[i] = cw.data[i].y.value; }
+    Message m;
+    check(ronk_rs_decode(F::ORDER, xs.data(), ys.data(), K, reinterpret_cast<uint64_t*>(m.data.data())));
+    return m;
+  }
+};
+
 }  // namespace ronkathon

@@ -67,6 +67,15 @@ int main() {
   CHECK(*back == *big);
   CHECK(lag->basis.nodes[1] == G::primitive_root_of_unity(N));
   CHECK(lag->coefficients[0] == [&] { G acc = G::ZERO(); for (auto& v : big->coefficients) acc = acc + v; return acc; }());  // X[0] = sum x_j
+  // codes/reed_solomon.rs tests (:136-218) over the Mersenne prime 127
+  using M7 = PrimeField<127>;
+  auto msg = Message<3, M7>::new_(arr<M7, 3>({1, 2, 3}));
+  auto cw3 = msg.encode<3>();
+  CHECK(cw3.data[1].x == M7::new_(107) && cw3.data[2].x == M7::new_(19));
+  CHECK(cw3.data[0].y == M7::new_(6) && cw3.data[1].y == M7::new_(18) && cw3.data[2].y == M7::new_(106));
+  CHECK((Message<3, M7>::decode<7>(msg.encode<7>()).data == msg.data));
+  auto msg5 = Message<5, M7>::new_(arr<M7, 5>({1, 2, 3, 4, 5}));
+  CHECK((Message<5, M7>::decode<7>(msg5.encode<7>()).data == msg5.data));
   printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

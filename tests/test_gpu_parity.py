@@ -454,6 +454,44 @@ def test_horner_scan_device_api(R, orc):
         assert orc.poly_eval(GP, a, x) == rhs
 
 
+def test_rs_decode_vs_oracle_and_erasure_roundtrip(R, orc, refvec):
+    """Message::decode (codes/reed_solomon.rs:54-106): reference round trips, oracle parity, encode -> erase -> decode"""
+    from ronkathon_amd.callers import Message
+    d = refvec["rs_decode"]
+    F = R.PrimeField(d["p"])
+    for msg in d["cases"]:
+        xs, ys = Message(F, msg).encode(d["n"])
+        assert Message.decode(F, xs, ys, len(msg)).data.tolist() == msg
+    rng = np.random.default_rng(5)
+    for p, g, n in ((127, 3, 126), (101, 2, 100), (GP, GG, 256)):
+        F = R.PrimeField(p)
+        for K in (1, 2, 3, 17, 64, 100):
+            if K > n:
+                continue
+            msg = splitmix_field(K + 3, K, p)
+            xs, ys = Message(F, msg).encode(n)
+            keep = rng.permutation(n)[:K]                     # K surviving coordinates in arbitrary order
+            got = Message.decode(F, xs[keep], ys[keep], K).data
+            assert np.array_equal(got, orc.rs_decode(p, xs[keep], ys[keep], K)), (p, K)
+            assert np.array_equal(got, msg)
+            # arbitrary (non-codeword) values at arbitrary distinct nodes
+            yy = splitmix_field(K + 99, K, p)
+            assert np.array_equal(Message.decode(F, xs[keep], yy, K).data, orc.rs_decode(p, xs[keep], yy, K))
+    with pytest.raises(R.RonkPanic) as e:                      # coincident nodes
+        Message.decode(R.PrimeField(127), [1, 1, 2], [3, 4, 5], 3)
+    assert e.value.code == -2
+    with pytest.raises(R.RonkPanic) as e:                      # assert_ge::<M, K>()
+        Message.decode(R.PrimeField(127), [1, 2], [3, 4], 3)
+    assert e.value.code == -6
+    # size the oracle cannot reach: 3000 symbols, 4096-point codeword (NTT path), 1096 erasures
+    F = R.GoldilocksField
+    K, n = 3000, 4096
+    msg = splitmix_field(1234, K)
+    xs, ys = Message(F, msg).encode(n)
+    keep = np.sort(rng.permutation(n)[:K])
+    assert np.array_equal(Message.decode(F, xs[keep], ys[keep], K).data, msg)
+
+
 def test_lagrange_evaluate_vs_oracle(R, orc):
     """Polynomial::<Lagrange>::evaluate on the GPU (ronk_lagrange_eval) vs the oracle's step-by-step fold"""
     for p, g, ns in ((101, 2, (1, 2, 4, 5, 10, 20, 25)), (17, 14, (1, 2, 4, 8, 16)), (GP, GG, (1, 3, 8, 15, 64, 96, 1024))):

@@ -113,6 +113,16 @@ def test_callers(refvec):
     assert orc.dft(127, 3, orc.poly_from([1, 2, 3], 7)).tolist() == ys7.tolist()
     d = refvec["kzg_open_quotient"]
     assert orc.kzg_open_quotient(d["p"], d["coeffs"], d["z"]).tolist() == d["quot"]
+    d = refvec["rs_decode"]
+    for msg in d["cases"]:
+        xs, ys = orc.rs_encode(d["p"], gen(d["p"]), msg, d["n"])
+        assert orc.rs_decode(d["p"], xs, ys, len(msg)).tolist() == msg
+        # any k surviving coordinates interpolate the same message (erasures)
+        assert orc.rs_decode(d["p"], xs[[6, 1, 4, 0, 3]], ys[[6, 1, 4, 0, 3]], len(msg)).tolist() == msg
+    with pytest.raises(orc.OraclePanic) as e:          # coincident nodes: numerator / ZERO -> unwrap on None
+        orc.rs_decode(127, [1, 1, 2], [3, 4, 5], 3)
+    assert e.value.code == -2
+    assert orc.rs_decode(127, [], [], 0).tolist() == []
 
 
 def test_reference_quirks():
