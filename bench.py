@@ -9,7 +9,8 @@ polynomial, no data-path collective): weak scaling, value = N*K / max-over-ranks
 Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 Other workloads (--workload): batch16 (1024 x 2^16), mul22 (polynomial multiply, NTT size 2^22),
 roundtrip16 (fwd+inv 2^16), fourstep (sharded four-step NTT with an RCCL all-to-all, N >= 1),
-open22 (kzg::open's quotient: 2^22 coefficients / (x - z)), eval22 (Polynomial::evaluate, 2^22 coefficients).
+open22 (kzg::open's quotient: 2^22 coefficients / (x - z)), eval22 (Polynomial::evaluate, 2^22 coefficients),
+rs16 (batched Reed-Solomon encode: 1024 messages of 2^15 symbols -> 2^16-point codewords).
 """
 import argparse
 import json
@@ -94,10 +95,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16, "open22": 22, "eval22": 22}[wl]
-    batch = args.batch or (1024 if wl == "batch16" else 1)
+    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16, "open22": 22, "eval22": 22, "rs16": 16}[wl]
+    batch = args.batch or (1024 if wl in ("batch16", "rs16") else 1)
     n = 1 << log2n
-    if wl == "batch16":
+    if wl in ("batch16", "rs16"):
         args.streams = 1
     # S independent transforms in flight: each stream has its own plan (scratch), input and output, so
     # the load/store phases of one transform overlap the VALU-bound butterflies of another.
@@ -126,6 +127,8 @@ def main():
             L.check(L.lib.ronk_poly_div_linear_dev(P, x.data_ptr(), n, P - zpt, 1, y.data_ptr(), scal.data_ptr(), stream))
         elif wl == "eval22":
             L.check(L.lib.ronk_poly_eval_dev(P, x.data_ptr(), n, zpt, scal.data_ptr(), stream))
+        elif wl == "rs16":
+            plan.rs_encode_batch_dev(x.data_ptr(), n // 2, y.data_ptr(), stream)   # x: [batch][n/2] compact messages
         elif wl == "roundtrip16":
             plan.forward_dev(x.data_ptr(), y.data_ptr(), stream)
             plan.inverse_dev(y.data_ptr(), y.data_ptr(), stream)
@@ -167,7 +170,7 @@ def main():
     plans[0] = plan0
     dev_ms = ev0.elapsed_time(ev1)
 
-    units_per_step = batch if wl != "roundtrip16" else 1
+    units_per_step = batch if wl not in ("roundtrip16",) else 1
     if wl == "ntt22":
         pass
     value = world * args.steps * units_per_step / dt
@@ -176,7 +179,8 @@ def main():
     pass_ms = None
     if wl in ("ntt22", "batch16"):
         pass_ms = lat_plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
-    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2, "open22": 1, "eval22": 0.5}[wl]
+    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2, "open22": 1, "eval22": 0.5,
+                     "rs16": 0.75 * batch}[wl]   # rs16: reads n/2 and writes n coefficients per codeword = 12*n bytes
     # 16*n bytes per n-point NTT; open22 reads n and writes n coefficients (16*n); eval22 reads n (8*n)
     alg_bytes_step = 16.0 * n * ntts_per_step
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream

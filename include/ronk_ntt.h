@@ -167,6 +167,11 @@ int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t
  * coordinates (xs[j], ys[j]) of a (possibly erased) codeword -> the k message coefficients.  Coincident nodes are
  * the reference's `numerator / denominator` panic -> RONK_ERR_ZERO_INVERSE.  k <= 2^14 (O(k^2) work). */
 int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out);
+/* Batched Message::encode::<N> on device (src/codes/reed_solomon.rs:42-52), the production shape of a
+ * Reed-Solomon / low-degree extension (1024 x 2^16): d_msgs holds plan.batch compact messages of k coefficients,
+ * d_ys receives plan.batch x N y-coordinates (x_i = omega_N^i: ronk_lagrange_nodes).  The zero padding of
+ * `Polynomial::from(message)` is implicit (no padded copy) for Goldilocks plans with N >= 2^13. */
+int ronk_rs_encode_batch_dev(ronk_plan* plan, const uint64_t* d_msgs, size_t k, uint64_t* d_ys, void* stream);
 
 /* ---- multi-GPU four-step building blocks (one process per GPU; the exchange between the two
  *      phases is an RCCL all-to-all issued by the host side, see ronkathon_amd/dist.py) ----

@@ -86,6 +86,7 @@ _SIG = {
     "ronk_poly_divrem": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp]),
     "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),
     "ronk_rs_decode": (_int, [_u64, _vp, _vp, _sz, _vp]),
+    "ronk_rs_encode_batch_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
     "ronk_dist_plan_destroy": (_int, [_vp]),
     "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),
@@ -144,7 +145,9 @@ class Plan:
             lib.ronk_plan_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:      # module globals are already torn down at interpreter exit
+            self.close()
 
     def num_passes(self):
         return lib.ronk_plan_num_passes(self.h)
@@ -169,6 +172,10 @@ class Plan:
 
     def inverse_dev(self, d_in, d_out, stream=0):
         check(lib.ronk_ntt_inverse_dev(self.h, d_in, d_out, stream))
+
+    def rs_encode_batch_dev(self, d_msgs, k, d_ys, stream=0):
+        """batched Message::encode::<N> (codes/reed_solomon.rs:42-52): [batch][k] messages -> [batch][n] y-coordinates"""
+        check(lib.ronk_rs_encode_batch_dev(self.h, d_msgs, k, d_ys, stream))
 
     def time_passes(self, d_in, d_out, inverse=False, iters=20, stream=0):
         np_ = self.num_passes()

@@ -80,6 +80,15 @@ __global__ void __launch_bounds__(256) vec_pow_kernel(Ops ops, const u64* __rest
   }
 }
 
+// From<[F;N]> zero padding (polynomial/mod.rs:503-515) for a batch: out[b][i] = i < k ? in[b][i] : ZERO
+__global__ void __launch_bounds__(256) pad_rows_kernel(const u64* __restrict__ in, size_t k, u64* __restrict__ out, size_t n,
+                                                        size_t total) {
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = t / n, i = t - b * n;
+    out[t] = i < k ? in[b * k + i] : 0;
+  }
+}
+
 // t[i] = w^i (Lagrange::new's nodes, polynomial/mod.rs:363)
 template <class Ops>
 __global__ void __launch_bounds__(256) power_table_kernel(Ops ops, u64 w, u64* __restrict__ t, size_t n) {

@@ -292,8 +292,9 @@ struct CompiledPlan {
   }
   // launch pass idx: BUF_IN -> in (and in2), BUF_OUT -> out, BUF_TMP -> tmp
   // in_valid / out_valid: implicit zero padding of the input / truncation of the output (TileArgs), ~0 = none
+  // in_poly_stride (multi-pass plans, 0 = n): element stride between the polynomials of a batched input
   int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-             u64 out_valid = ~(u64)0) const {
+             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0) const {
     const PassDesc& ps = pd.passes[idx];
     TileArgs a = ps.args;
     const u64* bufs_in[3] = {in, out, tmp};
@@ -301,7 +302,10 @@ struct CompiledPlan {
     a.in = bufs_in[ps.in_buf];
     a.in2 = (ps.in_buf == BUF_IN) ? in2 : nullptr;
     a.out = bufs_out[ps.out_buf];
-    if (ps.in_buf == BUF_IN) a.in_valid = in_valid;
+    if (ps.in_buf == BUF_IN) {
+      a.in_valid = in_valid;
+      if (in_poly_stride) a.in_sb1 = (i64)in_poly_stride;   // nb1 is the batch axis of every multi-pass plan (plan.h)
+    }
     if (ps.out_buf == BUF_OUT) a.out_valid = out_valid;
     a.wr = d_wr[ps.wr_id];
     if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
@@ -311,8 +315,9 @@ struct CompiledPlan {
     return RONK_OK;
   }
   int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-          u64 out_valid = ~(u64)0) const {
-    for (size_t i = 0; i < pd.passes.size(); i++) RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid));
+          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0) const {
+    for (size_t i = 0; i < pd.passes.size(); i++)
+      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride));
     return RONK_OK;
   }
 };
@@ -455,6 +460,20 @@ static int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* 
     return RONK_OK;
   }
   return generic_transform(pl, inverse, in, out, s);
+}
+// Batched Message::encode::<N> on device (codes/reed_solomon.rs:42-52): the y-coordinates of `batch` codewords,
+// ys[b][i] = message_b(omega_N^i), from compact messages msgs[b][0..k).  Multi-pass Goldilocks plans read the
+// messages in place with implicit zero padding; other plans pad into d_ys first and transform in place.
+extern "C" int ronk_rs_encode_batch_dev(ronk_plan* pl, const uint64_t* d_msgs, size_t k, uint64_t* d_ys, void* st) {
+  if (!pl || !d_msgs || !d_ys || k == 0) return RONK_ERR_INVALID;
+  if (k > pl->n) return RONK_ERR_INDEX;   // assert_ge::<N, K>()
+  hipStream_t s = (hipStream_t)st;
+  if (pl->fast && pl->fwd.pd.passes.size() > 1)
+    return pl->fwd.run(d_msgs, nullptr, d_ys, pl->d_tmp, s, (u64)k, ~(u64)0, (u64)k);
+  const size_t total = pl->n * pl->batch;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_msgs, k, d_ys, (size_t)pl->n, total);
+  HIPCHK(hipGetLastError());
+  return transform_dev(pl, false, d_ys, nullptr, d_ys, s);
 }
 extern "C" int ronk_ntt_forward_dev(ronk_plan* pl, const uint64_t* in, uint64_t* out, void* st) {
   return transform_dev(pl, false, in, nullptr, out, (hipStream_t)st);

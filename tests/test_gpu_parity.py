@@ -331,6 +331,40 @@ def test_device_pointer_api_inplace_and_streams(R, orc):
     assert np.array_equal(dz.cpu().numpy().view(np.uint64), orc.vec_mul(GP, a, a))
 
 
+def test_hipgraph_capture_of_dev_entry_points(R, orc):
+    """the _dev entry points only enqueue kernels on the caller's stream, so they can be captured in a hipGraph
+    (here through torch.cuda.CUDAGraph) and replayed; results equal the oracle on every replay"""
+    import torch
+    from ronkathon_amd import _lib as L
+    k = 14
+    n = 1 << k
+    x = splitmix_field(4242, n)
+    dx = torch.from_numpy(x.view(np.int64)).cuda()
+    dy = torch.zeros_like(dx); dz = torch.zeros_like(dx)
+    plan = L.Plan(GP, GG, k, 1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.forward_dev(dx.data_ptr(), dy.data_ptr(), s.cuda_stream)   # warm-up outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        st = torch.cuda.current_stream().cuda_stream
+        plan.forward_dev(dx.data_ptr(), dy.data_ptr(), st)
+        plan.inverse_dev(dy.data_ptr(), dz.data_ptr(), st)
+    ref = orc.fft(GP, GG, x)
+    for rep in range(3):
+        dy.zero_(); dz.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(dy.cpu().numpy().view(np.uint64), ref)
+        assert np.array_equal(dz.cpu().numpy().view(np.uint64), x)
+        x = splitmix_field(4243 + rep, n)                    # new input, same graph
+        dx.copy_(torch.from_numpy(x.view(np.int64)))
+        ref = orc.fft(GP, GG, x)
+    del g
+    plan.close()
+
+
 def test_plan_cache_eviction_and_threads(R, orc):
     """more distinct one-shot sizes than cache entries, then concurrent callers (the reference's
     `cargo test` runs tests on parallel threads; the library must be re-entrant)"""
@@ -490,6 +524,36 @@ def test_rs_decode_vs_oracle_and_erasure_roundtrip(R, orc, refvec):
     xs, ys = Message(F, msg).encode(n)
     keep = np.sort(rng.permutation(n)[:K])
     assert np.array_equal(Message.decode(F, xs[keep], ys[keep], K).data, msg)
+
+
+def test_rs_encode_batch_dev_vs_oracle(R, orc):
+    """ronk_rs_encode_batch_dev: compact [batch][k] messages -> [batch][n] codeword values, vs Message::encode of
+    the oracle (implicit zero padding on multi-pass plans, pad kernel on single-pass / generic-prime plans)"""
+    import torch
+    from ronkathon_amd import _lib as L
+    torch.zeros(1).cuda()
+    for p, g, k2, batch, K in ((GP, GG, 13, 7, 5000), (GP, GG, 14, 3, 1), (GP, GG, 13, 2, 8192), (GP, GG, 10, 5, 300),
+                               (GP, GG, 16, 4, 32768), (257, 3, 8, 3, 100), (GP, GG, 25, 1, 1 << 24)):
+        n = 1 << k2
+        msgs = splitmix_field(k2 * 100 + batch, batch * K, p)
+        dm = torch.from_numpy(msgs.view(np.int64)).cuda()
+        dy = torch.full((batch * n,), -1, dtype=torch.int64, device="cuda")
+        plan = L.Plan(p, g, k2, batch)
+        plan.rs_encode_batch_dev(dm.data_ptr(), K, dy.data_ptr(), 0)
+        torch.cuda.synchronize()
+        got = dy.cpu().numpy().view(np.uint64)
+        for b in range(batch):
+            if k2 <= 16:
+                want = orc.fft(p, g, orc.poly_from(msgs[b * K:(b + 1) * K], n))
+                assert np.array_equal(got[b * n:(b + 1) * n], want), (p, k2, b)
+            else:   # too big for the oracle's recursion in test time: the padded transform through the plain entry point
+                pad = np.zeros(n, dtype=np.uint64); pad[:K] = msgs[b * K:(b + 1) * K]
+                assert np.array_equal(got[b * n:(b + 1) * n], plan.forward(pad))
+        plan.close()
+    with pytest.raises(R.RonkPanic) as e:                    # assert_ge::<N, K>()
+        plan = L.Plan(GP, GG, 13, 1)
+        plan.rs_encode_batch_dev(dm.data_ptr(), 8193, dy.data_ptr(), 0)
+    assert e.value.code == -6
 
 
 def test_lagrange_evaluate_vs_oracle(R, orc):
