@@ -58,6 +58,33 @@ def cpu_baseline(log2n, budget_s=12.0):
             "host_cores_available": os.cpu_count()}
 
 
+def cpu_baseline_batched(log2n, budget_s=10.0):
+    """the batched shape on ALL host cores, one polynomial per thread (the oracle's C code
+    runs outside the GIL); the reference itself is single-threaded, so `cores` says what was used"""
+    import concurrent.futures as cf
+    import oracle as orc
+    n = 1 << log2n
+    cores = os.cpu_count() or 1
+    w = orc.primitive_root_of_unity(orc.GOLDILOCKS_P, orc.GOLDILOCKS_G, n)
+    polys = [synth(n, 1000 + i) for i in range(cores)]
+
+    def work(v):
+        t_end = time.perf_counter() + budget_s
+        done = 0
+        while time.perf_counter() < t_end:
+            orc.fft_recursive_inplace(orc.GOLDILOCKS_P, v, w)   # in place: the input of the next repetition
+            done += 1
+        return done
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        total = sum(ex.map(work, polys))
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "NTT/s", "cores": cores, "kind": "port",
+            "sample": "%d forward 2^%d NTTs in %.1f s, one polynomial per thread on %d threads, recursive algorithm of the "
+                      "reference restated in C" % (total, log2n, dt, cores)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +250,8 @@ def main():
                "roofline": roofline}
         if not args.no_cpu and wl == "ntt22":
             res["cpu_baseline"] = cpu_baseline(log2n)
+        if not args.no_cpu and wl in ("batch16", "rs16"):
+            res["cpu_baseline"] = cpu_baseline_batched(log2n)
         print(json.dumps(res), flush=True)
     for p_ in plans + [lat_plan]:
         p_.close()
