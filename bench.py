@@ -10,7 +10,8 @@ Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_b
 Other workloads (--workload): batch16 (1024 x 2^16), mul22 (polynomial multiply, NTT size 2^22),
 roundtrip16 (fwd+inv 2^16), fourstep (sharded four-step NTT with an RCCL all-to-all, N >= 1),
 open22 (kzg::open's quotient: 2^22 coefficients / (x - z)), eval22 (Polynomial::evaluate, 2^22 coefficients),
-rs16 (batched Reed-Solomon encode: 1024 messages of 2^15 symbols -> 2^16-point codewords).
+rs16 (batched Reed-Solomon encode: 1024 messages of 2^15 symbols -> 2^16-point codewords),
+vecmul24 / vecadd24 (element-wise Field Mul / Add over 2^24-element arrays: 24 bytes per element).
 """
 import argparse
 import json
@@ -122,7 +123,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16, "open22": 22, "eval22": 22, "rs16": 16}[wl]
+    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16, "open22": 22, "eval22": 22, "rs16": 16, "vecmul24": 24, "vecadd24": 24}[wl]
     batch = args.batch or (1024 if wl in ("batch16", "rs16") else 1)
     n = 1 << log2n
     if wl in ("batch16", "rs16"):
@@ -143,6 +144,8 @@ def main():
         b = torch.from_numpy(synth(n // 2, 0x5EED1000 + rank).view(np.int64)).cuda()
         a = x[: n // 2].contiguous()
         out = torch.empty(n - 1, dtype=torch.int64, device="cuda")
+    if wl in ("vecmul24", "vecadd24"):
+        x2 = torch.from_numpy(synth(n, 0x5EED2000 + rank).view(np.int64)).cuda()
     if wl in ("open22", "eval22"):
         zpt = 0x123456789ABCDEF1 % P                       # evaluation point z; divisor is x - z = [-z, 1]
         scal = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -154,6 +157,10 @@ def main():
             L.check(L.lib.ronk_poly_div_linear_dev(P, x.data_ptr(), n, P - zpt, 1, y.data_ptr(), scal.data_ptr(), stream))
         elif wl == "eval22":
             L.check(L.lib.ronk_poly_eval_dev(P, x.data_ptr(), n, zpt, scal.data_ptr(), stream))
+        elif wl == "vecmul24":
+            L.check(L.lib.ronk_vec_mul_dev(P, x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, stream))
+        elif wl == "vecadd24":
+            L.check(L.lib.ronk_vec_add_dev(P, x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, stream))
         elif wl == "rs16":
             plan.rs_encode_batch_dev(x.data_ptr(), n // 2, y.data_ptr(), stream)   # x: [batch][n/2] compact messages
         elif wl == "roundtrip16":
@@ -206,7 +213,7 @@ def main():
     pass_ms = None
     if wl in ("ntt22", "batch16"):
         pass_ms = lat_plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
-    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2, "open22": 1, "eval22": 0.5,
+    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2, "open22": 1, "eval22": 0.5, "vecmul24": 1.5, "vecadd24": 1.5,   # 24 bytes per element
                      "rs16": 0.75 * batch}[wl]   # rs16: reads n/2 and writes n coefficients per codeword = 12*n bytes
     # 16*n bytes per n-point NTT; open22 reads n and writes n coefficients (16*n); eval22 reads n (8*n)
     alg_bytes_step = 16.0 * n * ntts_per_step
@@ -230,7 +237,8 @@ def main():
                                 "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
                                 "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n) if traffic else None,
                 "kernel": {"open22": "chunk_horner_kernel + chunk_carry_kernel + lindiv_apply_kernel (csrc/scan_kernels.h)",
-                           "eval22": "chunk_horner_kernel + chunk_carry_kernel (csrc/scan_kernels.h)"}.get(
+                           "eval22": "chunk_horner_kernel + chunk_carry_kernel (csrc/scan_kernels.h)",
+                           "vecmul24": "vec_binary_kernel<GlOps, VEC_MUL>", "vecadd24": "vec_binary_kernel<GlOps, VEC_ADD>"}.get(
                                wl, "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes())),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "note": "achieved/frac: one transform at a time on ONE stream, default plan (kernel durations); "
@@ -248,9 +256,9 @@ def main():
                           % (log2n, batch) if wl in ("ntt22", "batch16") else wl,
                           "log2n": log2n, "batch": batch, "streams": S, "parallelism": "independent polynomials per GPU (x%d)" % world},
                "roofline": roofline}
-        if not args.no_cpu and wl == "ntt22":
+        if not args.no_cpu and world == 1 and wl == "ntt22":       # reported at N = 1 only (bench contract)
             res["cpu_baseline"] = cpu_baseline(log2n)
-        if not args.no_cpu and wl in ("batch16", "rs16"):
+        if not args.no_cpu and world == 1 and wl in ("batch16", "rs16"):
             res["cpu_baseline"] = cpu_baseline_batched(log2n)
         print(json.dumps(res), flush=True)
     for p_ in plans + [lat_plan]:

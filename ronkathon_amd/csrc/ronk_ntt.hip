@@ -174,6 +174,12 @@ static int vec_binary_dev(u64 p, const u64* a, const u64* b, u64* out, size_t n,
   FieldCtx f;
   RCHK(make_field(p, &f));
   if (n == 0) return RONK_OK;
+  if (nb >= n && (n & 1) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) {
+    FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_binary2_kernel<decltype(ops), OP>), dim3(grid_for(n / 2)), dim3(256), 0, s, ops,
+                                          (const ulonglong2*)a, (const ulonglong2*)b, (ulonglong2*)out, n / 2); });
+    HIPCHK(hipGetLastError());
+    return RONK_OK;
+  }
   FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_binary_kernel<decltype(ops), OP>), dim3(grid_for(n)), dim3(256), 0, s, ops,
                                         a, b, out, n, nb); });
   HIPCHK(hipGetLastError());
