@@ -54,6 +54,7 @@ extern "C" {
 #define RONK_ERR_HIP (-8)           /* a HIP runtime call failed; ronk_last_hip_error() has the text */
 #define RONK_ERR_UNSUPPORTED (-9)   /* size outside what the kernels cover (stated per function) */
 #define RONK_ERR_NO_DEVICE (-10)    /* no HIP device: the library never computes on the CPU */
+#define RONK_ERR_NOT_ON_CURVE (-11) /* assert!(point.is_on_curve(), "Point is not on curve"), src/curve/mod.rs:79 */
 
 const char* ronk_strerror(int code);
 const char* ronk_last_hip_error(void);
@@ -172,6 +173,16 @@ int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k,
  * d_ys receives plan.batch x N y-coordinates (x_i = omega_N^i: ronk_lagrange_nodes).  The zero padding of
  * `Polynomial::from(message)` is implicit (no padded copy) for Goldilocks plans with N >= 2^13. */
 int ronk_rs_encode_batch_dev(ronk_plan* plan, const uint64_t* d_msgs, size_t k, uint64_t* d_ys, void* stream);
+
+/* kzg::commit (src/kzg/setup.rs:45-60): sum_i points[i] * scalars[i] with the reference's AffinePoint Add / Mul<ScalarField>
+ * (src/curve/mod.rs:152-211) on y^2 = x^3 + a x + b over the quadratic extension F_p[u]/(u^2 - nr) of a small prime
+ * field (p < 2^32; PlutoExtendedCurve: p = 101, nr = 99 (X^2 + 2), a = 0, b = 3 -- src/curve/pluto_curve.rs:39-51,
+ * src/algebra/field/extension/gf_101_2.rs:12-18).  A point is 5 words: x0 x1 y0 y1 inf (inf != 0: Infinity).
+ * n_points < n is the reference's assert (RONK_ERR_INDEX); an off-curve point is AffinePoint::new's panic
+ * (RONK_ERR_NOT_ON_CURVE).  kzg::open = ronk_poly_divrem by [-z, 1] over the scalar field, then this. */
+typedef struct ronk_curve { uint64_t p, nr, a, b; } ronk_curve;
+int ronk_curve_msm(const ronk_curve* curve, const uint64_t* points, size_t n_points, const uint64_t* scalars, size_t n,
+                   uint64_t out[5]);
 
 /* ---- multi-GPU four-step building blocks (one process per GPU; the exchange between the two
  *      phases is an RCCL all-to-all issued by the host side, see ronkathon_amd/dist.py) ----

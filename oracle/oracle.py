@@ -22,6 +22,7 @@ PANICS = {
     -4: "input is not a prime number",
     -5: "generator not found",
     -6: "index out of bounds / unwrap on None",
+    -11: "Point is not on curve",
 }
 
 
@@ -78,6 +79,10 @@ def _load():
         "orc_poly_from": (None, [pu, sz, pu, sz]),
         "orc_rs_encode": (C.c_int, [u64, u64, pu, sz, sz, pu, pu]),
         "orc_rs_decode": (C.c_int, [u64, pu, pu, sz, pu]),
+        "orc_curve_is_on_curve": (C.c_int, [C.c_void_p, pu]),
+        "orc_curve_add": (C.c_int, [C.c_void_p, pu, pu, pu]),
+        "orc_curve_mul": (C.c_int, [C.c_void_p, pu, u64, pu]),
+        "orc_kzg_commit": (C.c_int, [C.c_void_p, pu, sz, pu, sz, pu]),
         "orc_kzg_open_quotient": (C.c_int, [u64, pu, sz, u64, pu]),
         "orc_fft_recursive": (None, [u64, pu, sz, u64]),
     }
@@ -263,6 +268,44 @@ def rs_decode(p, xs, ys, k):
     out = np.empty(k, dtype=np.uint64)
     _chk(_lib.orc_rs_decode(p, _p(xs), _p(ys), k, _p(out)))
     return out
+
+
+# ---- curve arithmetic behind kzg::commit.  A point is 5 words: x0 x1 y0 y1 inf.
+class Curve(C.Structure):
+    """y^2 = x^3 + a x + b over F_p[u]/(u^2 - nr)  (src/curve/pluto_curve.rs:27-51, extension/gf_101_2.rs:12-18)"""
+    _fields_ = [("p", C.c_uint64), ("nr", C.c_uint64), ("a", C.c_uint64), ("b", C.c_uint64)]
+
+
+PLUTO_CURVE = Curve(101, 99, 0, 3)          # X^2 + 2 irreducible -> u^2 = -2 = 99; y^2 = x^3 + 3
+INFINITY = [0, 0, 0, 0, 1]
+
+
+def point(x0, y0, x1=0, y1=0):
+    return [x0, x1, y0, y1, 0]
+
+
+def curve_is_on_curve(c, pt):
+    return bool(_lib.orc_curve_is_on_curve(C.byref(c), _p(_arr(pt))))
+
+
+def curve_add(c, p1, p2):
+    out = np.empty(5, dtype=np.uint64)
+    _chk(_lib.orc_curve_add(C.byref(c), _p(_arr(p1)), _p(_arr(p2)), _p(out)))
+    return out.tolist()
+
+
+def curve_mul(c, pt, k):
+    out = np.empty(5, dtype=np.uint64)
+    _chk(_lib.orc_curve_mul(C.byref(c), _p(_arr(pt)), k, _p(out)))
+    return out.tolist()
+
+
+def kzg_commit(c, coeffs, srs):
+    """kzg::commit (kzg/setup.rs:45-60); srs: list of points"""
+    flat = _arr([w for pt in srs for w in pt]); co = _arr(coeffs)
+    out = np.empty(5, dtype=np.uint64)
+    _chk(_lib.orc_kzg_commit(C.byref(c), _p(flat), len(srs), _p(co), co.size, _p(out)))
+    return out.tolist()
 
 
 def kzg_open_quotient(p, coeffs, z):

@@ -435,3 +435,94 @@ int orc_kzg_open_quotient(uint64_t p, const uint64_t* coeffs, size_t d, uint64_t
   free(rem);
   return rc;
 }
+
+/* ====================================================================================================
+ * the curve arithmetic behind kzg::commit (src/kzg/setup.rs:45-60).
+ * Quadratic extension F_p[u]/(u^2 - nr) (src/algebra/field/extension/gf_101_2.rs: X^2 + 2, i.e. nr = -2),
+ * short Weierstrass curve y^2 = x^3 + a x + b with a, b in F_p (src/curve/pluto_curve.rs:27-51),
+ * affine points with an Infinity variant (src/curve/mod.rs:66-73).  A point is 5 words: x0 x1 y0 y1 inf.
+ * ==================================================================================================== */
+typedef struct { uint64_t c0, c1; } fp2;
+static fp2 f2(uint64_t a, uint64_t b) { fp2 r = {a, b}; return r; }
+static fp2 f2_add(const orc_curve* c, fp2 a, fp2 b) { return f2(orc_add(c->p, a.c0, b.c0), orc_add(c->p, a.c1, b.c1)); }
+static fp2 f2_sub(const orc_curve* c, fp2 a, fp2 b) { return f2(orc_sub(c->p, a.c0, b.c0), orc_sub(c->p, a.c1, b.c1)); }
+static fp2 f2_neg(const orc_curve* c, fp2 a) { return f2(orc_neg(c->p, a.c0), orc_neg(c->p, a.c1)); }
+static int f2_eq(fp2 a, fp2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+/* gf_101_2.rs:83-97: (poly_self * poly_rhs) % irreducible = (a0 b0 + nr a1 b1) + (a0 b1 + a1 b0) u */
+static fp2 f2_mul(const orc_curve* c, fp2 a, fp2 b) {
+  uint64_t p = c->p;
+  return f2(orc_add(p, orc_mul(p, a.c0, b.c0), orc_mul(p, c->nr % p, orc_mul(p, a.c1, b.c1))),
+            orc_add(p, orc_mul(p, a.c0, b.c1), orc_mul(p, a.c1, b.c0)));
+}
+/* gf_101_2.rs:34-47: multiply by the conjugate, scalar = (a0^2 - nr a1^2)^-1 */
+static int f2_inv(const orc_curve* c, fp2 a, fp2* out) {
+  uint64_t p = c->p;
+  if (a.c0 == 0 && a.c1 == 0) return ORC_PANIC_ZERO_INVERSE; /* Div: rhs.inverse().expect("invalid inverse") */
+  uint64_t norm = orc_sub(p, orc_mul(p, a.c0, a.c0), orc_mul(p, c->nr % p, orc_mul(p, a.c1, a.c1))), s;
+  int rc = orc_inverse(p, norm, &s);
+  if (rc) return rc;
+  *out = f2(orc_mul(p, a.c0, s), orc_mul(p, orc_neg(p, a.c1), s));
+  return ORC_OK;
+}
+static fp2 f2_small(const orc_curve* c, uint64_t k) { return f2(k % c->p, 0); }
+
+/* curve/mod.rs:129-138 */
+int orc_curve_is_on_curve(const orc_curve* c, const uint64_t pt[5]) {
+  if (pt[4]) return 1;
+  fp2 x = f2(pt[0], pt[1]), y = f2(pt[2], pt[3]);
+  fp2 rhs = f2_add(c, f2_add(c, f2_mul(c, f2_mul(c, x, x), x), f2_mul(c, f2_small(c, c->a), x)), f2_small(c, c->b));
+  return f2_eq(f2_mul(c, y, y), rhs);
+}
+/* impl Add, curve/mod.rs:176-211, case by case; AffinePoint::new at the end asserts is_on_curve (:77-81) */
+int orc_curve_add(const orc_curve* c, const uint64_t p1[5], const uint64_t p2[5], uint64_t out[5]) {
+  if (p1[4]) { memcpy(out, p2, 5 * sizeof *out); return ORC_OK; }
+  if (p2[4]) { memcpy(out, p1, 5 * sizeof *out); return ORC_OK; }
+  fp2 x1 = f2(p1[0], p1[1]), y1 = f2(p1[2], p1[3]), x2 = f2(p2[0], p2[1]), y2 = f2(p2[2], p2[3]);
+  if (f2_eq(x1, x2) && f2_eq(y1, f2_neg(c, y2))) { out[0] = out[1] = out[2] = out[3] = 0; out[4] = 1; return ORC_OK; }
+  fp2 lambda, den, inv;
+  if (f2_eq(x1, x2) && f2_eq(y1, y2)) {
+    fp2 num = f2_add(c, f2_mul(c, f2_mul(c, f2_small(c, 3), x1), x1), f2_small(c, c->a));
+    den = f2_mul(c, f2_small(c, 2), y1);
+    int rc = f2_inv(c, den, &inv);
+    if (rc) return rc;
+    lambda = f2_mul(c, num, inv);
+  } else {
+    den = f2_sub(c, x2, x1);
+    int rc = f2_inv(c, den, &inv);
+    if (rc) return rc;
+    lambda = f2_mul(c, f2_sub(c, y2, y1), inv);
+  }
+  fp2 x = f2_sub(c, f2_sub(c, f2_mul(c, lambda, lambda), x1), x2);
+  fp2 y = f2_sub(c, f2_mul(c, lambda, f2_sub(c, x1, x)), y1);
+  out[0] = x.c0; out[1] = x.c1; out[2] = y.c0; out[3] = y.c1; out[4] = 0;
+  return orc_curve_is_on_curve(c, out) ? ORC_OK : ORC_PANIC_NOT_ON_CURVE;
+}
+/* impl Mul<ScalarField>, curve/mod.rs:152-166: ZERO -> Infinity, else self added rhs-1 times */
+int orc_curve_mul(const orc_curve* c, const uint64_t pt[5], uint64_t k, uint64_t out[5]) {
+  if (k == 0) { out[0] = out[1] = out[2] = out[3] = 0; out[4] = 1; return ORC_OK; }
+  uint64_t val[5], t[5];
+  memcpy(val, pt, sizeof val);
+  for (uint64_t i = 1; i < k; i++) {
+    int rc = orc_curve_add(c, val, pt, t);
+    if (rc) return rc;
+    memcpy(val, t, sizeof val);
+  }
+  memcpy(out, val, sizeof val);
+  return ORC_OK;
+}
+/* kzg::commit, kzg/setup.rs:45-60: assert!(g1_srs.len() >= coeffs.len()); zip, map(g1 * coeff), sum (reduce, :213-217) */
+int orc_kzg_commit(const orc_curve* c, const uint64_t* srs, size_t n_srs, const uint64_t* coeffs, size_t n, uint64_t out[5]) {
+  if (n_srs < n) return ORC_PANIC_INDEX;
+  uint64_t acc[5] = {0, 0, 0, 0, 1}, term[5], t[5];
+  for (size_t i = 0; i < n; i++) {
+    if (!orc_curve_is_on_curve(c, srs + 5 * i)) return ORC_PANIC_NOT_ON_CURVE;
+    int rc = orc_curve_mul(c, srs + 5 * i, coeffs[i], term);
+    if (rc) return rc;
+    if (i == 0) { memcpy(acc, term, sizeof acc); continue; }
+    rc = orc_curve_add(c, acc, term, t);
+    if (rc) return rc;
+    memcpy(acc, t, sizeof acc);
+  }
+  memcpy(out, acc, sizeof acc);
+  return ORC_OK;
+}

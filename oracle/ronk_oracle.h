@@ -34,6 +34,7 @@ extern "C" {
 #define ORC_PANIC_NOT_PRIME (-4)    /* is_prime panic, prime/mod.rs:92-100 */
 #define ORC_PANIC_NO_GENERATOR (-5) /* find_primitive_element panic, prime/mod.rs:122 */
 #define ORC_PANIC_INDEX (-6)        /* slice index out of bounds / unwrap on None */
+#define ORC_PANIC_NOT_ON_CURVE (-11) /* assert!(point.is_on_curve(), "Point is not on curve"), curve/mod.rs:79 */
 
 /* ---- prime field: src/algebra/field/prime/{mod,arithmetic}.rs ---- */
 int orc_is_prime(uint64_t p);                                   /* prime/mod.rs:92-100 */
@@ -90,4 +91,12 @@ void orc_fft_recursive(uint64_t p, uint64_t* values, size_t n, uint64_t omega);
 #ifdef __cplusplus
 }
 #endif
+/* ---- curve arithmetic behind kzg::commit: src/curve/mod.rs, src/kzg/setup.rs:45-60 ----
+ * y^2 = x^3 + a x + b over F_p[u]/(u^2 - nr); a point is 5 words x0 x1 y0 y1 inf */
+typedef struct orc_curve { uint64_t p, nr, a, b; } orc_curve;
+int orc_curve_is_on_curve(const orc_curve* c, const uint64_t pt[5]);                                  /* curve/mod.rs:129-138 */
+int orc_curve_add(const orc_curve* c, const uint64_t p1[5], const uint64_t p2[5], uint64_t out[5]);   /* curve/mod.rs:176-211 */
+int orc_curve_mul(const orc_curve* c, const uint64_t pt[5], uint64_t k, uint64_t out[5]);             /* curve/mod.rs:152-166 */
+int orc_kzg_commit(const orc_curve* c, const uint64_t* srs, size_t n_srs, const uint64_t* coeffs, size_t n, uint64_t out[5]);
+
 #endif

@@ -25,6 +25,7 @@ GOLDILOCKS_G = 7
 
 OK, ERR_NO_ROOT, ERR_ZERO_INVERSE, ERR_NOT_POW2, ERR_NOT_PRIME = 0, -1, -2, -3, -4
 ERR_NO_GENERATOR, ERR_INDEX, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = -5, -6, -7, -8, -9, -10
+ERR_NOT_ON_CURVE = -11
 
 
 class RonkPanic(Exception):
@@ -87,6 +88,7 @@ _SIG = {
     "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),
     "ronk_rs_decode": (_int, [_u64, _vp, _vp, _sz, _vp]),
     "ronk_rs_encode_batch_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "ronk_curve_msm": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
     "ronk_dist_plan_destroy": (_int, [_vp]),
     "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),

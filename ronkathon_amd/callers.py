@@ -3,7 +3,10 @@
 * Reed-Solomon `Message::encode::<N>` (reference src/codes/reed_solomon.rs:42-52): evaluating the
   K-coefficient message at omega_N^i, i < N, is a size-N DFT of the zero-padded message.
 * KZG `open` quotient (reference src/kzg/setup.rs:63-78): poly / (x - z).
+* KZG `commit` / `open` (reference src/kzg/setup.rs:45-78): the multi-scalar multiplication over the SRS.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _lib as L
@@ -44,3 +47,27 @@ def kzg_open_quotient(field, coeffs, eval_point):
     poly = Polynomial.new(field, coeffs)
     divisor = Polynomial.new(field, [int(-field(eval_point)), 1])
     return (poly / divisor).coefficients
+
+
+class Curve(C.Structure):
+    """y^2 = x^3 + a x + b over F_p[u]/(u^2 - nr) (src/curve/pluto_curve.rs:27-51, extension/gf_101_2.rs:12-18).
+    Points are 5-word lists [x0, x1, y0, y1, inf] (`AffinePoint::Point(x, y)` / `AffinePoint::Infinity`)."""
+    _fields_ = [("p", C.c_uint64), ("nr", C.c_uint64), ("a", C.c_uint64), ("b", C.c_uint64)]
+
+
+PlutoExtendedCurve = Curve(101, 99, 0, 3)      # X^2 + 2 -> u^2 = -2; EQUATION_A = 0, EQUATION_B = 3
+INFINITY = [0, 0, 0, 0, 1]
+
+
+def kzg_commit(curve, coeffs, g1_srs):
+    """`kzg::commit` (kzg/setup.rs:45-60): sum_i g1_srs[i] * coeffs[i]; panics if the SRS is shorter"""
+    pts = L.arr([int(w) for pt in g1_srs for w in pt])
+    sc = L.arr([int(c) for c in coeffs])
+    out = np.empty(5, dtype=np.uint64)
+    L.check(L.lib.ronk_curve_msm(C.byref(curve), L.ptr(pts), len(g1_srs), L.ptr(sc), sc.size, L.ptr(out)))
+    return out.tolist()
+
+
+def kzg_open(curve, scalar_field, coeffs, eval_point, g1_srs):
+    """`kzg::open::<D>` (kzg/setup.rs:63-78): commit(poly.div([-z, 1]).coefficients, g1_srs)"""
+    return kzg_commit(curve, kzg_open_quotient(scalar_field, coeffs, eval_point), g1_srs)

@@ -17,6 +17,7 @@
 #include "field_kernels.h"
 #include "scan_kernels.h"
 #include "interp_kernels.h"
+#include "curve_kernels.h"
 #include "plan.h"
 #include "tile_launch.h"
 
@@ -53,6 +54,7 @@ extern "C" const char* ronk_strerror(int code) {
     case RONK_ERR_HIP: return "HIP runtime error";
     case RONK_ERR_UNSUPPORTED: return "size not supported by this kernel";
     case RONK_ERR_NO_DEVICE: return "no HIP device (libronk_ntt has no CPU path)";
+    case RONK_ERR_NOT_ON_CURVE: return "Point is not on curve";
     default: return "unknown error";
   }
 }
@@ -959,6 +961,41 @@ extern "C" int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys
   HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
   if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: numerator / ZERO
   HIPCHK(hipMemcpy(out, dout.p, k * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+
+// kzg::commit (src/kzg/setup.rs:45-60): sum_i points[i] * scalars[i] on y^2 = x^3 + a x + b over F_p[u]/(u^2 - nr)
+extern "C" int ronk_curve_msm(const ronk_curve* cv, const uint64_t* points, size_t n_points, const uint64_t* scalars,
+                              size_t n, uint64_t out[5]) {
+  if (!cv || !out || (n && (!points || !scalars))) return RONK_ERR_INVALID;
+  if (cv->p < 3 || cv->p >= ((u64)1 << 32)) return RONK_ERR_UNSUPPORTED;   // products of residues must fit 64 bits
+  RCHK(ronk_check_prime(cv->p));
+  if (n_points < n) return RONK_ERR_INDEX;          // assert!(g1_srs.len() >= coeffs.len())
+  if (n == 0) { out[0] = out[1] = out[2] = out[3] = 0; out[4] = 1; return RONK_OK; }   // empty sum -> Infinity
+  RCHK(need_device());
+  const u64 p = cv->p;
+  CurveCtx c{p, cv->nr % p, cv->a % p, cv->b % p};
+  std::vector<u64> hp(5 * n), hs(n);
+  for (size_t i = 0; i < n; i++) {
+    for (int w = 0; w < 4; w++) hp[5 * i + w] = points[5 * i + w] % p;
+    hp[5 * i + 4] = points[5 * i + 4] ? 1 : 0;
+    hs[i] = scalars[i];
+  }
+  const u32 nblk = (u32)((n + 255) / 256);
+  DevBuf dp, ds, dpart, dout, dflag;
+  RCHK(dp.alloc(5 * n * 8)); RCHK(ds.alloc(n * 8)); RCHK(dpart.alloc((size_t)nblk * 5 * 8)); RCHK(dout.alloc(5 * 8));
+  RCHK(dflag.alloc(4));
+  HIPCHK(hipMemcpy(dp.p, hp.data(), 5 * n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, hs.data(), n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dflag.p, 0, 4));
+  hipLaunchKernelGGL(msm_terms_kernel, dim3(nblk), dim3(256), 0, 0, c, dp.u(), ds.u(), n, dpart.u(), (int*)dflag.p);
+  hipLaunchKernelGGL(msm_reduce_kernel, dim3(1), dim3(256), 0, 0, c, dpart.u(), (size_t)nblk, dout.u(), (int*)dflag.p);
+  HIPCHK(hipGetLastError());
+  int hflag = 0;
+  HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
+  if (hflag & CURVE_ERR_NOT_ON_CURVE) return RONK_ERR_NOT_ON_CURVE;   // AffinePoint::new: "Point is not on curve"
+  if (hflag & CURVE_ERR_INVERSE) return RONK_ERR_ZERO_INVERSE;        // Div: expect("invalid inverse")
+  HIPCHK(hipMemcpy(out, dout.p, 5 * 8, hipMemcpyDeviceToHost));
   return RONK_OK;
 }
 

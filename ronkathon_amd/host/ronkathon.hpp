@@ -207,4 +207,33 @@ struct Message {                                                                
   }
 };
 
+// ---- KZG commit / open (src/kzg/setup.rs:45-78) over AffinePoint<PlutoExtendedCurve> (src/curve/mod.rs:66-73) --------
+struct AffinePoint {                       // Point(x, y) with x = x0 + x1 t, y = y0 + y1 t in GF(101^2), or Infinity
+  std::array<uint64_t, 5> w{0, 0, 0, 0, 1};
+  static AffinePoint Infinity() { return AffinePoint{}; }
+  static AffinePoint new_(uint64_t x0, uint64_t x1, uint64_t y0, uint64_t y1) { AffinePoint p; p.w = {x0, x1, y0, y1, 0}; return p; }
+  friend bool operator==(const AffinePoint& a, const AffinePoint& b) { return a.w == b.w; }
+};
+inline const ronk_curve& PlutoExtendedCurve() { static const ronk_curve c{101, 99, 0, 3}; return c; }   // pluto_curve.rs:39-51
+namespace kzg {
+// commit(coeffs, g1_srs): SUM g1_srs[i] * coeffs[i]
+template <class S>
+AffinePoint commit(const std::vector<S>& coeffs, const std::vector<AffinePoint>& g1_srs, const ronk_curve& curve = PlutoExtendedCurve()) {
+  std::vector<uint64_t> pts, sc;
+  for (auto& p : g1_srs) pts.insert(pts.end(), p.w.begin(), p.w.end());
+  for (auto& c : coeffs) sc.push_back(c.value);
+  AffinePoint out;
+  check(ronk_curve_msm(&curve, pts.data(), g1_srs.size(), sc.data(), sc.size(), out.w.data()));
+  return out;
+}
+// open::<D>(coeffs, eval_point, g1_srs): commit(poly.div([-z, 1]).coefficients, g1_srs)
+template <class S, size_t D>
+AffinePoint open(const std::array<S, D>& coeffs, S eval_point, const std::vector<AffinePoint>& g1_srs) {
+  auto poly = Polynomial<Monomial, S, D>::new_(coeffs);
+  auto divisor = Polynomial<Monomial, S, 2>::new_(std::array<S, 2>{-eval_point, S::ONE()});
+  auto q = poly / divisor;
+  return commit(std::vector<S>(q.coefficients.begin(), q.coefficients.end()), g1_srs);
+}
+}  // namespace kzg
+
 }  // namespace ronkathon

@@ -76,6 +76,15 @@ int main() {
   CHECK((Message<3, M7>::decode<7>(msg.encode<7>()).data == msg.data));
   auto msg5 = Message<5, M7>::new_(arr<M7, 5>({1, 2, 3, 4, 5}));
   CHECK((Message<5, M7>::decode<7>(msg5.encode<7>()).data == msg5.data));
+  // kzg/tests.rs:92-176: commits over the SRS g1 * tau^i and the opening of (x-1)(x-2)(x-3) at 4
+  using S = PlutoScalarField;
+  std::vector<AffinePoint> srs = {AffinePoint::new_(1, 0, 2, 0), AffinePoint::new_(68, 0, 74, 0), AffinePoint::new_(65, 0, 98, 0),
+                                  AffinePoint::new_(18, 0, 49, 0), AffinePoint::new_(1, 0, 99, 0), AffinePoint::new_(68, 0, 27, 0),
+                                  AffinePoint::new_(65, 0, 3, 0)};
+  CHECK(kzg::commit(std::vector<S>{S::new_(11), S::new_(11), S::new_(11), S::new_(1)}, srs) == AffinePoint::Infinity());
+  CHECK(kzg::commit(std::vector<S>{S::new_(7), S::new_(16), S::new_(1), S::new_(11), S::new_(1)}, srs) == AffinePoint::new_(32, 0, 59, 0));
+  CHECK(kzg::commit(std::vector<S>{S::new_(3), S::new_(2), S::new_(1)}, srs) == AffinePoint::new_(32, 0, 59, 0));
+  CHECK((kzg::open<S, 4>(arr<S, 4>({11, 11, 11, 1}), S::new_(4), srs) == AffinePoint::new_(26, 0, 45, 0)));
   printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -556,6 +556,41 @@ def test_rs_encode_batch_dev_vs_oracle(R, orc):
     assert e.value.code == -6
 
 
+def test_kzg_commit_msm_vs_reference_vectors_and_oracle(R, orc, refvec):
+    """SURVEY.md 8f N4: kzg::commit / kzg::open through ronk_curve_msm -- the reference's own vectors
+    (src/kzg/tests.rs:92-176), random MSMs against the oracle's repeated-addition restatement, panics"""
+    from ronkathon_amd import callers as K
+    v = refvec["curve"]
+    cv = K.Curve(v["p"], v["nr"], v["a"], v["b"])
+    oc = orc.Curve(v["p"], v["nr"], v["a"], v["b"])
+    srs = v["g1_srs"]
+    for case in refvec["kzg_commit"]["cases"]:
+        assert K.kzg_commit(cv, case["coeffs"], srs) == case["commit"]
+    o = refvec["kzg_commit"]["opening"]
+    assert K.kzg_open(cv, R.PlutoScalarField, o["coeffs"], o["z"], srs) == o["open"]
+    assert K.kzg_commit(cv, [], srs) == K.INFINITY
+    # single terms = scalar multiplication: every multiple of both generators, scalars beyond the group order too
+    for base in (v["g"], v["g2"]):
+        order, acc = 1, base
+        while acc != orc.INFINITY:                       # order of the point, by the oracle's repeated addition
+            acc = orc.curve_add(oc, acc, base); order += 1
+        for k in list(range(0, 40)) + [16 * 17 + 5, 2**40 + 3, 2**64 - 1]:
+            assert K.kzg_commit(cv, [k], [base]) == orc.curve_mul(oc, base, k % order), (base, k)
+    # random MSMs over points of both subgroups (and Infinity), more terms than one workgroup
+    rng = np.random.default_rng(11)
+    pool = [orc.curve_mul(oc, v["g"], k) for k in range(0, 17)] + [orc.curve_mul(oc, v["g2"], k) for k in range(1, 12)]
+    for n in (1, 2, 7, 255, 256, 257, 1000):
+        pts = [pool[i] for i in rng.integers(0, len(pool), n)]
+        sc = rng.integers(0, 17, n).tolist()
+        assert K.kzg_commit(cv, sc, pts) == orc.kzg_commit(oc, sc, pts), n
+    with pytest.raises(R.RonkPanic) as e:
+        K.kzg_commit(cv, [1, 2], [v["false_point"], v["g"]])
+    assert e.value.code == -11
+    with pytest.raises(R.RonkPanic) as e:
+        K.kzg_commit(cv, [1, 2, 3], [v["g"], v["g"]])
+    assert e.value.code == -6
+
+
 def test_lagrange_evaluate_vs_oracle(R, orc):
     """Polynomial::<Lagrange>::evaluate on the GPU (ronk_lagrange_eval) vs the oracle's step-by-step fold"""
     for p, g, ns in ((101, 2, (1, 2, 4, 5, 10, 20, 25)), (17, 14, (1, 2, 4, 8, 16)), (GP, GG, (1, 3, 8, 15, 64, 96, 1024))):

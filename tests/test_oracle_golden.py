@@ -125,6 +125,40 @@ def test_callers(refvec):
     assert orc.rs_decode(127, [], [], 0).tolist() == []
 
 
+def test_curve_and_kzg_commit(refvec):
+    """the reference's curve and KZG vectors pin the oracle's curve arithmetic"""
+    v = refvec["curve"]
+    c = orc.Curve(v["p"], v["nr"], v["a"], v["b"])
+    g = v["g"]
+    assert orc.curve_add(c, g, g) == v["multiples_of_g"]["2"]                      # doubling through Add
+    acc = g
+    for k in range(2, 18):
+        acc = orc.curve_add(c, acc, g)
+        if str(k) in v["multiples_of_g"]:
+            assert acc == v["multiples_of_g"][str(k)], k
+        assert orc.curve_mul(c, g, k) == acc
+    assert acc == orc.INFINITY and orc.curve_mul(c, g, 17) == orc.INFINITY          # order 17
+    assert orc.curve_mul(c, g, 0) == orc.INFINITY
+    assert orc.curve_add(c, g, orc.INFINITY) == g and orc.curve_add(c, orc.INFINITY, g) == g
+    assert orc.curve_add(c, g, v["multiples_of_g"]["16"]) == orc.INFINITY           # g + (-g)
+    assert orc.curve_add(c, v["g2"], v["g2"]) == v["two_g2"]                        # extension-field doubling
+    assert orc.curve_is_on_curve(c, v["g2"]) and not orc.curve_is_on_curve(c, v["false_point"])
+    srs = [orc.curve_mul(c, g, pow(v["tau"], i, v["scalar_order"])) for i in range(7)]   # kzg/setup.rs:12-40
+    assert srs == v["g1_srs"]
+    k = refvec["kzg_commit"]
+    for case in k["cases"]:
+        assert orc.kzg_commit(c, case["coeffs"], srs) == case["commit"]
+    o = k["opening"]
+    quot = orc.kzg_open_quotient(v["scalar_order"], o["coeffs"], o["z"])
+    assert orc.kzg_commit(c, quot.tolist(), srs) == o["open"]                         # kzg::open = commit(quotient)
+    with pytest.raises(orc.OraclePanic) as e:
+        orc.kzg_commit(c, [1, 2], [v["false_point"], g])
+    assert e.value.code == -11
+    with pytest.raises(orc.OraclePanic) as e:                                         # srs shorter than the coefficients
+        orc.kzg_commit(c, [1, 2, 3], [g, g])
+    assert e.value.code == -6
+
+
 def test_reference_quirks():
     # Lagrange evaluate AT a node: the fold's `return c` replaces the accumulator and the product
     # with l(x) == 0 gives ZERO (polynomial/mod.rs:382-415)
