@@ -642,6 +642,30 @@ extern "C" int ronk_ifft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* o
 }
 
 // ------------------------------------------------------------------------------ dft (any n | p-1)
+static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_b, size_t d2, u64* d_out, size_t out_len,
+                    hipStream_t s);
+
+// Bluestein's chirp-z for n that is not a power of two (Goldilocks): with C(m) = m(m-1)/2, j*k = C(j+k) - C(j) - C(k), so
+//   X_k = w^-C(k) * sum_j (x_j w^-C(j)) * w^C(j+k)
+// is a correlation, computed as ONE cyclic convolution of size 2^ceil(log2(2n-1)) on the fast NTT path.  Only w = omega_n
+// itself is needed (no square root of it).  Same values as Polynomial::dft (polynomial/mod.rs:240-258), O(n log n).
+static int bluestein_dev(u64 p, u64 g, u64 w, const u64* d_x, u64* d_out, size_t n, hipStream_t s) {
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  const size_t lb = 2 * n - 1;
+  int k = ilog2(lb);
+  if (k < 4) k = 4;
+  DevBuf dT, da, db, dc;
+  RCHK(dT.alloc(n * 8)); RCHK(da.alloc(n * 8)); RCHK(db.alloc(lb * 8)); RCHK(dc.alloc(lb * 8));
+  RCHK(lagrange_nodes_dev(f, w, dT.u(), n, s));
+  hipLaunchKernelGGL(bluestein_pre_kernel, dim3(grid_for(lb)), dim3(256), 0, s, d_x, dT.u(), n, da.u(), db.u());
+  HIPCHK(hipGetLastError());
+  RCHK(conv_dev(p, g, k, da.u(), n, db.u(), lb, dc.u(), lb, s));   // cyclic wrap-around only reaches indices < n-1
+  hipLaunchKernelGGL(bluestein_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, dc.u(), dT.u(), n, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));   // the temporaries above are freed on return
+  return RONK_OK;
+}
 
 extern "C" int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n) {
   if (!in || !out || n == 0) return RONK_ERR_INVALID;
@@ -650,12 +674,18 @@ extern "C" int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* ou
   RCHK(need_device());
   if (is_pow2(n) && p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 16)
     return fft_oneshot(false, p, g, in, out, nullptr, n);
-  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
+  const bool chirp = p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 512 && n <= ((size_t)1 << 29);
+  if (!chirp && n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
   FieldCtx f;
   RCHK(make_field(p, &f));
   DevBuf di, dout;
   RCHK(di.alloc(n * 8)); RCHK(dout.alloc(n * 8));
   HIPCHK(hipMemcpy(di.p, in, n * 8, hipMemcpyHostToDevice));
+  if (chirp) {
+    RCHK(bluestein_dev(p, g % p, w, di.u(), dout.u(), n, 0));
+    HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+    return RONK_OK;
+  }
   FIELD_DISPATCH(f, { hipLaunchKernelGGL((dft_naive_kernel<decltype(ops)>), dim3((u32)((n + 255) / 256)), dim3(256), 0, 0,
                                         ops, di.u(), dout.u(), n, w); });
   HIPCHK(hipGetLastError());
@@ -683,7 +713,13 @@ extern "C" int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, si
   }
   int k = ilog2(m);
   if (k < 4) k = 4;
+  return conv_dev(p, g, k, d_a, d, d_b, d2, d_out, m, s);
+}
+// cyclic convolution of size N = 2^k of a (d entries) and b (d2 entries), the first out_len entries stored
+static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_b, size_t d2, u64* d_out, size_t out_len,
+                    hipStream_t s) {
   const size_t N = (size_t)1 << k;
+  const size_t m = out_len;
   RCHK(need_device());
   std::lock_guard<std::mutex> lk(g_cache_mu);
   CacheEntry* e = nullptr;

@@ -591,6 +591,43 @@ def test_kzg_commit_msm_vs_reference_vectors_and_oracle(R, orc, refvec):
     assert e.value.code == -6
 
 
+def test_dft_non_power_of_two_bluestein(R, orc):
+    """Polynomial::dft for n | p-1 that is not a power of two (polynomial/mod.rs:240-258): chirp-z on the NTT path
+    for n >= 512, the O(n^2) kernel below; both against the oracle's definition-by-definition dft"""
+    from ronkathon_amd import _lib as L
+    F = R.GoldilocksField
+    for n in (3, 5, 15, 17, 255, 257, 768, 771, 1285, 3855, 4369):
+        assert (GP - 1) % n == 0
+        x = splitmix_field(n, n)
+        out = np.empty(n, dtype=np.uint64)
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(x), L.ptr(out), n))
+        assert np.array_equal(out, orc.dft(GP, GG, x)), n
+    # sizes the O(n^2) oracle cannot reach: delta at index 1 -> the nodes omega^k; X_0 = sum; linearity
+    for n in (65537, 3 * (1 << 20), 65535 * 16):
+        assert (GP - 1) % n == 0
+        nodes = np.empty(n, dtype=np.uint64)
+        L.check(L.lib.ronk_lagrange_nodes(GP, GG, L.ptr(nodes), n))
+        d1 = np.zeros(n, dtype=np.uint64); d1[1] = 1
+        out = np.empty(n, dtype=np.uint64)
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(d1), L.ptr(out), n))
+        assert np.array_equal(out, nodes)
+        x = splitmix_field(n + 1, n); y = splitmix_field(n + 2, n)
+        X = np.empty(n, dtype=np.uint64); Y = np.empty(n, dtype=np.uint64); Z = np.empty(n, dtype=np.uint64)
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(x), L.ptr(X), n))
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(y), L.ptr(Y), n))
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(F.vec_add(x, y)), L.ptr(Z), n))
+        assert np.array_equal(Z, F.vec_add(X, Y))
+        assert int(X[0]) == int(np.sum(x.astype(object)) % GP)
+        # X_k for one k by the definition: sum_j x_j w^(jk) = evaluate at w^k
+        k = 12345 % n
+        assert int(X[k]) == orc.poly_eval(GP, x, int(nodes[k]))
+    # Reed-Solomon encode with a non-power-of-two codeword length goes through the same path
+    from ronkathon_amd.callers import Message
+    msg = splitmix_field(5, 1000)
+    xs, ys = Message(F, msg).encode(3 * 1024)
+    assert int(ys[7]) == orc.poly_eval(GP, msg, int(xs[7])) and int(ys[3071]) == orc.poly_eval(GP, msg, int(xs[3071]))
+
+
 def test_lagrange_evaluate_vs_oracle(R, orc):
     """Polynomial::<Lagrange>::evaluate on the GPU (ronk_lagrange_eval) vs the oracle's step-by-step fold"""
     for p, g, ns in ((101, 2, (1, 2, 4, 5, 10, 20, 25)), (17, 14, (1, 2, 4, 8, 16)), (GP, GG, (1, 3, 8, 15, 64, 96, 1024))):
