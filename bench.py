@@ -26,6 +26,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
+# workload -> (log2n, polynomials per step, algorithmic bytes per step as a multiple of n, unit, dominant kernel)
+# Algorithmic bytes: an n-point NTT reads n and writes n 8-byte elements = 16*n.
+WORKLOADS = {
+    "ntt22":       (22, 1,    16.0,          "NTT/s", None),   # the headline: one forward transform per step
+    "batch16":     (16, 1024, 16.0 * 1024,   "NTT/s", None),   # config 4: 1024 x 2^16 in one launch pair
+    "mul22":       (22, 1,    48.0,          "op/s",  None),   # config 3: 3 transforms of size 2^22, pad/pointwise/truncate fused
+    "roundtrip16": (16, 1,    32.0,          "op/s",  None),   # config 2: forward + inverse
+    "open22":      (22, 1,    16.0,          "op/s",  "chunk_horner_kernel + chunk_carry_kernel + lindiv_apply_kernel (csrc/scan_kernels.h)"),
+    "eval22":      (22, 1,    8.0,           "op/s",  "chunk_horner_kernel + chunk_carry_kernel (csrc/scan_kernels.h)"),
+    "rs16":        (16, 1024, 12.0 * 1024,   "op/s",  None),   # reads n/2, writes n coefficients per codeword
+    "vecmul24":    (24, 1,    24.0,          "op/s",  "vec_binary2_kernel<GlOps, VEC_MUL>"),
+    "vecadd24":    (24, 1,    24.0,          "op/s",  "vec_binary2_kernel<GlOps, VEC_ADD>"),
+}
+
 
 def synth(n, seed):
     """i.i.d. uniform on [0, p), as int64-viewable uint64"""
@@ -123,8 +137,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    log2n = args.log2n or {"ntt22": 22, "batch16": 16, "mul22": 22, "roundtrip16": 16, "open22": 22, "eval22": 22, "rs16": 16, "vecmul24": 24, "vecadd24": 24}[wl]
-    batch = args.batch or (1024 if wl in ("batch16", "rs16") else 1)
+    wl_log2n, wl_batch, wl_bytes_per_n, wl_unit, wl_kernel = WORKLOADS[wl]
+    log2n = args.log2n or wl_log2n
+    batch = args.batch or wl_batch
     n = 1 << log2n
     if wl in ("batch16", "rs16"):
         args.streams = 1
@@ -191,7 +206,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # single-stream device time of the same step (events on the launch stream): the per-kernel roofline
+    value = world * args.steps * batch / dt          # whole-job units per second (polynomials, products, ...)
+
+    # Roofline of the dominant kernel: the same K steps again, one at a time on ONE stream with the default plan,
+    # bracketed by HIP events recorded on the launch stream (torch's current stream IS the launch stream here).
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     S_saved, S, plan0 = S, 1, plans[0]
     plans[0] = lat_plan
@@ -204,19 +222,11 @@ def main():
     plans[0] = plan0
     dev_ms = ev0.elapsed_time(ev1)
 
-    units_per_step = batch if wl not in ("roundtrip16",) else 1
-    if wl == "ntt22":
-        pass
-    value = world * args.steps * units_per_step / dt
-
     # per-kernel device time (hipEvents on the launch stream) for the roofline of the dominant kernel
     pass_ms = None
     if wl in ("ntt22", "batch16"):
         pass_ms = lat_plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
-    ntts_per_step = {"ntt22": batch, "batch16": batch, "mul22": 3, "roundtrip16": 2, "open22": 1, "eval22": 0.5, "vecmul24": 1.5, "vecadd24": 1.5,   # 24 bytes per element
-                     "rs16": 0.75 * batch}[wl]   # rs16: reads n/2 and writes n coefficients per codeword = 12*n bytes
-    # 16*n bytes per n-point NTT; open22 reads n and writes n coefficients (16*n); eval22 reads n (8*n)
-    alg_bytes_step = 16.0 * n * ntts_per_step
+    alg_bytes_step = wl_bytes_per_n * (batch / wl_batch) * n
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
     achieved = alg_bytes_step / step_s / 1e9
     # HBM bytes per launch from the PMC passes of the same command under rocprofv3 (tools/rocprof_summary.py;
@@ -236,10 +246,8 @@ def main():
                                 "algorithmic bytes = %d per transform (16*n), i.e. %d per launch of the 2-launch plan; each launch reads and "
                                 "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
                                 "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n) if traffic else None,
-                "kernel": {"open22": "chunk_horner_kernel + chunk_carry_kernel + lindiv_apply_kernel (csrc/scan_kernels.h)",
-                           "eval22": "chunk_horner_kernel + chunk_carry_kernel (csrc/scan_kernels.h)",
-                           "vecmul24": "vec_binary_kernel<GlOps, VEC_MUL>", "vecadd24": "vec_binary_kernel<GlOps, VEC_ADD>"}.get(
-                               wl, "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes())),
+                "kernel": wl_kernel or "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n,
+                                                                                         plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "note": "achieved/frac: one transform at a time on ONE stream, default plan (kernel durations); "
                         "value: %d streams%s" % (S, ", plans tuned for concurrency (tile_log2_columns=2)" if tile_lc >= 0 else ""),
@@ -248,7 +256,7 @@ def main():
 
     if rank == 0:
         res = {"metric": "forward NTTs/s, degree 2^%d, 64-bit Goldilocks prime" % log2n if wl == "ntt22" else wl,
-               "value": value, "unit": "NTT/s" if wl in ("ntt22", "batch16") else "op/s",
+               "value": value, "unit": wl_unit,
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
