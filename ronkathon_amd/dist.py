@@ -99,7 +99,17 @@ class FourStepNTT:
         stream = torch.cuda.current_stream().cuda_stream if local_in.is_cuda else 0
         self.engine.phase1(self._ptr(local_in), self._ptr(send), stream)
         if self.world > 1:
-            self.dist.all_to_all_single(recv, send, group=self.group)   # RCCL over xGMI
+            if local_in.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                # a backend without device collectives (gloo): stage the exchange through host memory.  Not the
+                # product configuration -- it lets the real HIP phases run under a real process group on boxes
+                # with fewer GPUs than ranks (tests/test_dist_gpu_procs.py).
+                torch.cuda.current_stream().synchronize()
+                h_send = send.cpu()
+                h_recv = torch.empty_like(h_send)
+                self.dist.all_to_all_single(h_recv, h_send, group=self.group)
+                recv.copy_(h_recv)
+            else:
+                self.dist.all_to_all_single(recv, send, group=self.group)   # RCCL over xGMI
         else:
             recv = send
         self.engine.phase2(self._ptr(recv), self._ptr(out), stream)
@@ -171,7 +181,7 @@ def bench_fourstep(log2n, steps, warmup):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n = 1 << log2n
