@@ -117,9 +117,10 @@ RONK_HD u64 mul_2exp(u64 x) {
   if constexpr (s == 0) {
     y0 = x0; y1 = x1; y2 = 0;
   } else {
-    u64 p0 = (u64)x0 << s;
-    u64 p1 = ((u64)x1 << s) + (p0 >> 32);
-    y0 = (u32)p0; y1 = (u32)p1; y2 = (u32)(p1 >> 32);
+    // 96-bit shift on 32-bit limbs: shift, funnel shift (v_alignbit_b32), shift -- 3 instructions
+    y0 = x0 << s;
+    y1 = (x1 << s) | (x0 >> (32 - s));
+    y2 = x1 >> (32 - s);
   }
   if constexpr (q == 0) {
     u64 n = ((u64)y1 << 32) | y0;            // may be >= p
