@@ -247,12 +247,28 @@ def main():
                     traffic = c["_hbm_bytes_per_launch"]["total"]
     except Exception:
         pass
+    traffic_note = None
+    if traffic:
+        traffic_note = ("HBM bytes per kernel launch (rocprofv3 PMC, profiles/latest_pmc_ntt22.json); "
+                        "algorithmic bytes = %d per transform (16*n), i.e. %d per launch of the 2-launch plan; each launch reads and "
+                        "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
+                        "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n))
+    elif wl != "ntt22":
+        try:   # the other workloads: the dominant (longest) kernel of the committed PMC run of the same command
+            with open(os.path.join(ROOT, "profiles", "latest_pmc_workloads.json")) as f:
+                ks = json.load(f).get(wl, {})
+            if ks and log2n == wl_log2n and batch == wl_batch:
+                kname, kv = max(ks.items(), key=lambda kv_: kv_[1].get("avg_us") or 0.0)
+                traffic = kv["hbm_bytes_per_launch"]
+                traffic_note = ("HBM bytes per launch of %s (rocprofv3 PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
+                                "profiles/r01_rocprof_%s.txt); all kernels of one step move %d bytes against %d algorithmic"
+                                % (kname, wl, sum(v["hbm_bytes_per_launch"] for v in ks.values()) *
+                                   (2 if wl in ("batch16", "rs16") else 1), int(wl_bytes_per_n * n)))
+        except Exception:
+            pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_note": "HBM bytes per kernel launch (rocprofv3 PMC, profiles/latest_pmc_ntt22.json); "
-                                "algorithmic bytes = %d per transform (16*n), i.e. %d per launch of the 2-launch plan; each launch reads and "
-                                "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
-                                "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n) if traffic else None,
+                "traffic_note": traffic_note,
                 "kernel": wl_kernel or "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n,
                                                                                          plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
