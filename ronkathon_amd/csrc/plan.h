@@ -1,7 +1,7 @@
 // plan.h -- host-side decomposition of an n-point NTT (n = 2^k) into tile passes.
 //
 // Pure C++ (no HIP calls): produces pass descriptors and the twiddle tables they index.
-// The same code is used by the library (ronk_ntt.hip uploads the tables and launches one
+// The same code is used by the library (ronk_plan.hip uploads the tables and launches one
 // ntt_tile kernel per pass) and by the host kernel emulator under tests/emu.
 //
 // Decomposition (natural order in, natural order out; reference semantics

@@ -1,0 +1,412 @@
+// ronk_plan.hip -- C ABI of libronk_ntt.so, part 2: plan construction (plan.h), twiddle upload, transform launches
+// (tile_kernels.hip; generic primes: field_kernels.h), staging for the host-pointer entry points, the plan cache and
+// what is built on it (fft / ifft / dft, polynomial multiply, batched Reed-Solomon encode).
+#include "runtime.h"
+#include "ntt_aux_kernels.h"
+
+// ------------------------------------------------------------------------------------- plans
+
+
+
+extern "C" int ronk_plan_destroy(ronk_plan* pl) {
+  if (!pl) return RONK_ERR_INVALID;
+  pl->fwd.release();
+  pl->inv.release();
+  if (pl->d_tmp) (void)hipFree(pl->d_tmp);
+  if (pl->d_stage_in) (void)hipFree(pl->d_stage_in);
+  if (pl->d_stage_out) (void)hipFree(pl->d_stage_out);
+  if (pl->d_wtab_f) (void)hipFree(pl->d_wtab_f);
+  if (pl->d_wtab_i) (void)hipFree(pl->d_wtab_i);
+  delete pl;
+  return RONK_OK;
+}
+
+extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device) {
+  return ronk_plan_create_tuned(out, p, g, log2n, batch, device, -1, -1);
+}
+
+extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
+                                      int tile_log2_columns, int twiddle_matrix_log2_max) {
+  if (!out || batch == 0 || log2n > 36) return RONK_ERR_INVALID;
+  *out = nullptr;
+  RCHK(ronk_check_prime(p));                                   // PrimeField::new -> is_prime
+  if (p < 2) return RONK_ERR_INVALID;
+  const u64 n = (u64)1 << log2n;
+  if ((p - 1) % n != 0) return RONK_ERR_NO_ROOT;               // field/mod.rs:72, polynomial/mod.rs:361
+  RCHK(need_device());
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  else HIPCHK(hipGetDevice(&device));
+  ronk_plan* pl = new ronk_plan();
+  pl->p = p; pl->g = g % p; pl->log2n = log2n; pl->n = n; pl->batch = batch; pl->device = device;
+  int rc = make_field(p, &pl->field);
+  if (rc) { delete pl; return rc; }
+  // tile path: Goldilocks with the reference generator, 16 <= n <= 2^30 (32-bit lane offsets inside a tile,
+  // grids below 2^31 workgroups); anything else takes the generic radix-2 path
+  pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4 && log2n <= 30 &&
+              batch < ((u64)1 << 31) && (double)batch * (double)n / 2048.0 < 2.0e9);
+  if (pl->fast) {
+    // columns per tile = 2^max_logc at most (4 = 128-byte segments, 1 workgroup per CU at 2^11 rows; 2 = 32-byte
+    // segments but two workgroups per CU, better when several transforms are in flight); RONK_MAX_LOGC overrides
+    int max_logc = 4;
+    if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) max_logc = v; }
+    if (tile_log2_columns >= 0 && tile_log2_columns <= 8) max_logc = tile_log2_columns;
+    // Full inter-pass twiddle matrix (one coalesced load + one multiply instead of two gathers + two
+    // multiplies) while it stays L2-resident: up to 2^18 entries = 2 MiB.  Larger matrices would add an
+    // n-element HBM read per transform (measured +4 % speed at 2^22 for +25 % traffic): left to RONK_TWF_MAX_LOG.
+    int twf_max_log = 18;
+    if (const char* e = getenv("RONK_TWF_MAX_LOG")) { int v = atoi(e); if (v >= 0 && v <= 26) twf_max_log = v; }
+    if (twiddle_matrix_log2_max >= 0 && twiddle_matrix_log2_max <= 26) twf_max_log = twiddle_matrix_log2_max;
+    int three_from = 25;  // RONK_THREE_PASS_FROM: split smaller sizes in three passes too (experiment knob)
+    if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from));
+    for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
+      if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
+  } else {
+    pl->w_f = h_powmod(pl->g, (p - 1) / n, p);
+    pl->w_i = h_powmod(pl->w_f, p - 2, p);                     // root.inverse().unwrap(), mod.rs:433
+    pl->n_inv = h_powmod(n % p, p - 2, p);                     // F::from(D).inverse().unwrap(), mod.rs:442
+    if (n % p == 0) { ronk_plan_destroy(pl); return RONK_ERR_ZERO_INVERSE; }
+    if (log2n >= 1) {
+      size_t half = n / 2;
+      hipError_t e = hipMalloc((void**)&pl->d_wtab_f, half * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&pl->d_wtab_i, half * 8);
+      if (e != hipSuccess) { ronk_plan_destroy(pl); return hip_fail(e, "hipMalloc"); }
+      FIELD_DISPATCH(pl->field, {
+        hipLaunchKernelGGL((power_table_kernel<decltype(ops)>), dim3(grid_for(half)), dim3(256), 0, 0, ops, pl->w_f,
+                           pl->d_wtab_f, half);
+        hipLaunchKernelGGL((power_table_kernel<decltype(ops)>), dim3(grid_for(half)), dim3(256), 0, 0, ops, pl->w_i,
+                           pl->d_wtab_i, half);
+      });
+      if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = RONK_ERR_HIP;
+    }
+  }
+  if (!rc) {
+    hipError_t e = hipMalloc((void**)&pl->d_tmp, n * batch * 8);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(scratch)");
+  }
+  if (rc) { ronk_plan_destroy(pl); return rc; }
+  *out = pl;
+  return RONK_OK;
+}
+
+extern "C" int ronk_plan_num_passes(const ronk_plan* pl) {
+  if (!pl) return RONK_ERR_INVALID;
+  return pl->fast ? (int)pl->fwd.pd.passes.size() : (int)pl->log2n + 1;
+}
+
+// generic power-of-two transform: bit-reversal copy + log2(n) radix-2 DIT stages
+static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* out, hipStream_t s) {
+  const size_t total = pl->n * pl->batch;
+  u64* work = out;
+  if (in == out) work = pl->d_tmp;  // bit-reversal is not in-place safe
+  FIELD_DISPATCH(pl->field, {
+    hipLaunchKernelGGL((bitrev_copy_kernel<decltype(ops)>), dim3(grid_for(total)), dim3(256), 0, s, ops, in, work,
+                       (int)pl->log2n, total);
+    for (int st = 0; st < (int)pl->log2n; st++) {
+      const bool last = st == (int)pl->log2n - 1;
+      hipLaunchKernelGGL((radix2_stage_kernel<decltype(ops)>), dim3(grid_for(total / 2)), dim3(256), 0, s, ops, work,
+                         inverse ? pl->d_wtab_i : pl->d_wtab_f, (int)pl->log2n, st, total / 2,
+                         (inverse && last) ? pl->n_inv : (u64)1);
+    }
+  });
+  HIPCHK(hipGetLastError());
+  if (work != out) HIPCHK(hipMemcpyAsync(out, work, total * 8, hipMemcpyDeviceToDevice, s));
+  return RONK_OK;
+}
+
+int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s, u64 in_valid,
+                  u64 out_valid) {
+  if (!pl || !in || !out) return RONK_ERR_INVALID;
+  if (pl->fast) {
+    // in == out is safe: a single-pass plan rewrites exactly the tile it read; multi-pass plans
+    // read BUF_IN only in pass 1 and write BUF_OUT only in the last pass.
+    return (inverse ? pl->inv : pl->fwd).run(in, in2, out, pl->d_tmp, s, in_valid, out_valid);
+  }
+  if (in2 || in_valid != ~(u64)0 || out_valid != ~(u64)0) return RONK_ERR_UNSUPPORTED;
+  if (pl->log2n == 0) {  // n = 1: fft/ifft are the identity (the recursion returns at n <= 1)
+    if (in != out) HIPCHK(hipMemcpyAsync(out, in, pl->batch * 8, hipMemcpyDeviceToDevice, s));
+    return RONK_OK;
+  }
+  return generic_transform(pl, inverse, in, out, s);
+}
+// Batched Message::encode::<N> on device (codes/reed_solomon.rs:42-52): the y-coordinates of `batch` codewords,
+// ys[b][i] = message_b(omega_N^i), from compact messages msgs[b][0..k).  Multi-pass Goldilocks plans read the
+// messages in place with implicit zero padding; other plans pad into d_ys first and transform in place.
+extern "C" int ronk_rs_encode_batch_dev(ronk_plan* pl, const uint64_t* d_msgs, size_t k, uint64_t* d_ys, void* st) {
+  if (!pl || !d_msgs || !d_ys || k == 0) return RONK_ERR_INVALID;
+  if (k > pl->n) return RONK_ERR_INDEX;   // assert_ge::<N, K>()
+  hipStream_t s = (hipStream_t)st;
+  if (pl->fast && pl->fwd.pd.passes.size() > 1)
+    return pl->fwd.run(d_msgs, nullptr, d_ys, pl->d_tmp, s, (u64)k, ~(u64)0, (u64)k);
+  const size_t total = pl->n * pl->batch;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_msgs, k, d_ys, (size_t)pl->n, total);
+  HIPCHK(hipGetLastError());
+  return transform_dev(pl, false, d_ys, nullptr, d_ys, s);
+}
+extern "C" int ronk_ntt_forward_dev(ronk_plan* pl, const uint64_t* in, uint64_t* out, void* st) {
+  return transform_dev(pl, false, in, nullptr, out, (hipStream_t)st);
+}
+extern "C" int ronk_ntt_inverse_dev(ronk_plan* pl, const uint64_t* in, uint64_t* out, void* st) {
+  return transform_dev(pl, true, in, nullptr, out, (hipStream_t)st);
+}
+
+static int ensure_stage(ronk_plan* pl) {
+  const size_t bytes = pl->n * pl->batch * 8;
+  if (!pl->d_stage_in) HIPCHK(hipMalloc((void**)&pl->d_stage_in, bytes));
+  if (!pl->d_stage_out) HIPCHK(hipMalloc((void**)&pl->d_stage_out, bytes));
+  return RONK_OK;
+}
+static int transform_host(ronk_plan* pl, bool inverse, const u64* in, u64* out) {
+  if (!pl || !in || !out) return RONK_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  HIPCHK(hipSetDevice(pl->device));
+  RCHK(ensure_stage(pl));
+  const size_t bytes = pl->n * pl->batch * 8;
+  HIPCHK(hipMemcpy(pl->d_stage_in, in, bytes, hipMemcpyHostToDevice));
+  RCHK(transform_dev(pl, inverse, pl->d_stage_in, nullptr, pl->d_stage_out, 0));
+  HIPCHK(hipMemcpy(out, pl->d_stage_out, bytes, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+
+static int lagrange_nodes_dev(const FieldCtx& f, u64 w, u64* d_nodes, size_t n, hipStream_t s) {
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((power_table_kernel<decltype(ops)>), dim3(grid_for(n)), dim3(256), 0, s, ops, w,
+                                        d_nodes, n); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_lagrange_nodes(uint64_t p, uint64_t g, uint64_t* nodes, size_t n) {
+  if (!nodes || n == 0) return RONK_ERR_INVALID;
+  u64 w;
+  RCHK(ronk_root_of_unity(p, g % p, n, &w));   // assert_eq!((F::ORDER - 1) % n, 0), mod.rs:361
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  DevBuf d;
+  RCHK(d.alloc(n * 8));
+  RCHK(lagrange_nodes_dev(f, w, d.u(), n, 0));
+  HIPCHK(hipMemcpy(nodes, d.p, n * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+
+extern "C" int ronk_ntt_forward(ronk_plan* pl, const uint64_t* in, uint64_t* out, uint64_t* nodes) {
+  RCHK(transform_host(pl, false, in, out));
+  if (nodes) RCHK(ronk_lagrange_nodes(pl->p, pl->g, nodes, pl->n));
+  return RONK_OK;
+}
+extern "C" int ronk_ntt_inverse(ronk_plan* pl, const uint64_t* in, uint64_t* out) {
+  return transform_host(pl, true, in, out);
+}
+
+extern "C" int ronk_plan_time_passes(ronk_plan* pl, const uint64_t* d_in, uint64_t* d_out, int inverse, int iters,
+                                     float* ms, void* st) {
+  if (!pl || !d_in || !d_out || !ms || iters < 1) return RONK_ERR_INVALID;
+  if (!pl->fast) return RONK_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)st;
+  const CompiledPlan& cp = inverse ? pl->inv : pl->fwd;
+  const size_t np = cp.pd.passes.size();
+  std::vector<hipEvent_t> ev(np + 1);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  std::vector<double> acc(np, 0.0);
+  for (int it = 0; it < iters; it++) {
+    HIPCHK(hipEventRecord(ev[0], s));
+    for (size_t i = 0; i < np; i++) {
+      RCHK(cp.launch(i, d_in, nullptr, d_out, pl->d_tmp, s));
+      HIPCHK(hipEventRecord(ev[i + 1], s));
+    }
+    HIPCHK(hipEventSynchronize(ev[np]));
+    for (size_t i = 0; i < np; i++) {
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      acc[i] += t;
+    }
+  }
+  for (size_t i = 0; i < np; i++) ms[i] = (float)(acc[i] / iters);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return RONK_OK;
+}
+
+// ------------------------------------------------------------------------------ plan cache
+// One-shot entry points (ronk_fft/ronk_ifft/ronk_dft/ronk_poly_mul*) reuse plans -- twiddle tables and
+// scratch stay resident in HBM -- through a small LRU cache guarded by one lock (the reference is
+// stateless; `cargo test` calls in from many threads).  An entry also owns two padded operand
+// buffers for the multiply; an event orders successive uses of an entry across streams.
+
+struct CacheEntry {
+  ronk_plan* pl = nullptr;
+  u64 *fa = nullptr, *fb = nullptr;  // poly_mul operands, n elements each (lazy)
+  hipEvent_t done = nullptr;
+  uint64_t stamp = 0;
+};
+static std::mutex g_cache_mu;
+static std::vector<CacheEntry> g_cache;
+static uint64_t g_cache_clock = 0;
+
+static void cache_entry_free(CacheEntry& e) {
+  if (e.pl) ronk_plan_destroy(e.pl);
+  if (e.fa) (void)hipFree(e.fa);
+  if (e.fb) (void)hipFree(e.fb);
+  if (e.done) (void)hipEventDestroy(e.done);
+  e = CacheEntry();
+}
+// caller holds g_cache_mu
+static int cache_get(u64 p, u64 g, u32 log2n, CacheEntry** out) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  for (auto& e : g_cache)
+    if (e.pl && e.pl->p == p && e.pl->g == g % p && e.pl->log2n == log2n && e.pl->batch == 1 && e.pl->device == dev) {
+      e.stamp = ++g_cache_clock;
+      *out = &e;
+      return RONK_OK;
+    }
+  if (g_cache.size() >= 8) {  // evict the least recently used entry (its work must have drained)
+    size_t lru = 0;
+    for (size_t i = 1; i < g_cache.size(); i++) if (g_cache[i].stamp < g_cache[lru].stamp) lru = i;
+    if (g_cache[lru].done) (void)hipEventSynchronize(g_cache[lru].done);
+    cache_entry_free(g_cache[lru]);
+    g_cache.erase(g_cache.begin() + lru);
+  }
+  CacheEntry e;
+  RCHK(ronk_plan_create(&e.pl, p, g, log2n, 1, -1));
+  hipError_t he = hipEventCreateWithFlags(&e.done, hipEventDisableTiming);
+  if (he != hipSuccess) { cache_entry_free(e); return hip_fail(he, "hipEventCreate"); }
+  e.stamp = ++g_cache_clock;
+  g_cache.push_back(e);
+  *out = &g_cache.back();
+  return RONK_OK;
+}
+
+// Polynomial::fft / ifft one-shot forms (polynomial/mod.rs:273-292, :430-453) on host pointers
+static int fft_oneshot(bool inverse, u64 p, u64 g, const u64* in, u64* out, u64* nodes, size_t n) {
+  if (!in || !out || n == 0) return RONK_ERR_INVALID;
+  if (!is_pow2(n)) return RONK_ERR_NOT_POW2;  // `[(); D.is_power_of_two() as usize - 1]:`
+  RCHK(ronk_check_prime(p));
+  if (p < 2) return RONK_ERR_INVALID;
+  if ((p - 1) % n != 0) return RONK_ERR_NO_ROOT;
+  RCHK(need_device());
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CacheEntry* e = nullptr;
+    RCHK(cache_get(p, g, (u32)ilog2(n), &e));
+    RCHK(inverse ? ronk_ntt_inverse(e->pl, in, out) : ronk_ntt_forward(e->pl, in, out, nullptr));
+  }
+  if (nodes) RCHK(ronk_lagrange_nodes(p, g, nodes, n));
+  return RONK_OK;
+}
+extern "C" int ronk_fft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, uint64_t* nodes, size_t n) {
+  return fft_oneshot(false, p, g, in, out, nodes, n);
+}
+extern "C" int ronk_ifft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n) {
+  return fft_oneshot(true, p, g, in, out, nullptr, n);
+}
+
+// ------------------------------------------------------------------------------ dft (any n | p-1)
+static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_b, size_t d2, u64* d_out, size_t out_len,
+                    hipStream_t s);
+
+// Bluestein's chirp-z for n that is not a power of two (Goldilocks): with C(m) = m(m-1)/2, j*k = C(j+k) - C(j) - C(k), so
+//   X_k = w^-C(k) * sum_j (x_j w^-C(j)) * w^C(j+k)
+// is a correlation, computed as ONE cyclic convolution of size 2^ceil(log2(2n-1)) on the fast NTT path.  Only w = omega_n
+// itself is needed (no square root of it).  Same values as Polynomial::dft (polynomial/mod.rs:240-258), O(n log n).
+static int bluestein_dev(u64 p, u64 g, u64 w, const u64* d_x, u64* d_out, size_t n, hipStream_t s) {
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  const size_t lb = 2 * n - 1;
+  int k = ilog2(lb);
+  if (k < 4) k = 4;
+  DevBuf dT, da, db, dc;
+  RCHK(dT.alloc(n * 8)); RCHK(da.alloc(n * 8)); RCHK(db.alloc(lb * 8)); RCHK(dc.alloc(lb * 8));
+  RCHK(lagrange_nodes_dev(f, w, dT.u(), n, s));
+  hipLaunchKernelGGL(bluestein_pre_kernel, dim3(grid_for(lb)), dim3(256), 0, s, d_x, dT.u(), n, da.u(), db.u());
+  HIPCHK(hipGetLastError());
+  RCHK(conv_dev(p, g, k, da.u(), n, db.u(), lb, dc.u(), lb, s));   // cyclic wrap-around only reaches indices < n-1
+  hipLaunchKernelGGL(bluestein_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, dc.u(), dT.u(), n, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));   // the temporaries above are freed on return
+  return RONK_OK;
+}
+
+extern "C" int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n) {
+  if (!in || !out || n == 0) return RONK_ERR_INVALID;
+  u64 w;
+  RCHK(ronk_root_of_unity(p, g % p, n, &w));
+  RCHK(need_device());
+  if (is_pow2(n) && p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 16)
+    return fft_oneshot(false, p, g, in, out, nullptr, n);
+  const bool chirp = p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 512 && n <= ((size_t)1 << 29);
+  if (!chirp && n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  DevBuf di, dout;
+  RCHK(di.alloc(n * 8)); RCHK(dout.alloc(n * 8));
+  HIPCHK(hipMemcpy(di.p, in, n * 8, hipMemcpyHostToDevice));
+  if (chirp) {
+    RCHK(bluestein_dev(p, g % p, w, di.u(), dout.u(), n, 0));
+    HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+    return RONK_OK;
+  }
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((dft_naive_kernel<decltype(ops)>), dim3((u32)((n + 255) / 256)), dim3(256), 0, 0,
+                                        ops, di.u(), dout.u(), n, w); });
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+
+// ------------------------------------------------------------------------------ polynomial multiply
+// Goldilocks: pad both to N = 2^k >= d + d2 - 1, NTT(a), then the inverse plan's first pass loads
+// NTT(a) * NTT(b) (fused pointwise product) -- 3 transforms, 48*N algorithmic bytes.
+extern "C" int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2,
+                                 uint64_t* d_out, void* st) {
+  if (!d_a || !d_b || !d_out || d == 0 || d2 == 0) return RONK_ERR_INVALID;
+  hipStream_t s = (hipStream_t)st;
+  const size_t m = d + d2 - 1;
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  const bool fast = (p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && m > 64);
+  if (!fast) {
+    if ((double)d * (double)d2 > 1.2e12) return RONK_ERR_UNSUPPORTED;
+    FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_mul_schoolbook_kernel<decltype(ops)>), dim3(grid_for(m)), dim3(256), 0, s,
+                                          ops, d_a, d, d_b, d2, d_out); });
+    HIPCHK(hipGetLastError());
+    return RONK_OK;
+  }
+  int k = ilog2(m);
+  if (k < 4) k = 4;
+  return conv_dev(p, g, k, d_a, d, d_b, d2, d_out, m, s);
+}
+// cyclic convolution of size N = 2^k of a (d entries) and b (d2 entries), the first out_len entries stored
+static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_b, size_t d2, u64* d_out, size_t out_len,
+                    hipStream_t s) {
+  const size_t N = (size_t)1 << k;
+  const size_t m = out_len;
+  RCHK(need_device());
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  CacheEntry* e = nullptr;
+  RCHK(cache_get(p, g, (u32)k, &e));
+  if (!e->fa) HIPCHK(hipMalloc((void**)&e->fa, N * 8));
+  if (!e->fb) HIPCHK(hipMalloc((void**)&e->fb, N * 8));
+  ronk_plan* pl = e->pl;
+  HIPCHK(hipStreamWaitEvent(s, e->done, 0));                                // previous use of this entry's scratch
+  // From<[F;N]> zero padding (mod.rs:503-515) is implicit: the forward transforms read the operands in place and
+  // treat indices >= d (d2) as ZERO; the inverse loads NTT(a)*NTT(b) (pointwise product fused into the load) and
+  // stores only the d + d2 - 1 product coefficients, straight into the caller's buffer.  No memset, no copy.
+  RCHK(transform_dev(pl, false, d_a, nullptr, e->fa, s, (u64)d));
+  RCHK(transform_dev(pl, false, d_b, nullptr, e->fb, s, (u64)d2));
+  RCHK(transform_dev(pl, true, e->fa, e->fb, d_out, s, ~(u64)0, (u64)m));
+  HIPCHK(hipEventRecord(e->done, s));
+  return RONK_OK;
+}
+extern "C" int ronk_poly_mul(uint64_t p, uint64_t g, const uint64_t* a, size_t d, const uint64_t* b, size_t d2,
+                             uint64_t* out) {
+  if (!a || !b || !out || d == 0 || d2 == 0) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  const size_t m = d + d2 - 1;
+  DevBuf da, db, dout;
+  RCHK(da.alloc(d * 8)); RCHK(db.alloc(d2 * 8)); RCHK(dout.alloc(m * 8));
+  HIPCHK(hipMemcpy(da.p, a, d * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db.p, b, d2 * 8, hipMemcpyHostToDevice));
+  RCHK(ronk_poly_mul_dev(p, g, da.u(), d, db.u(), d2, dout.u(), 0));
+  HIPCHK(hipMemcpy(out, dout.p, m * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+

@@ -1,6 +1,6 @@
 // emu_tile.cpp -- HOST EMULATOR of the HIP tile kernel (TEST INFRASTRUCTURE ONLY).
 //
-// Runs the very same ronk::tile_body<> template that ronk_ntt.hip launches on the GPU,
+// Runs the very same ronk::tile_body<> template that ronk_plan.hip launches on the GPU,
 // but on ucontext fibers (one fiber per work-item, barrier = yield), so the plan algebra
 // (strides, digit maps, twiddle exponents, LDS swizzle) can be checked against the oracle
 // in the CPU-only container.  It is built and run by tests/test_emu_kernel.py only; the
