@@ -628,6 +628,35 @@ def test_dft_non_power_of_two_bluestein(R, orc):
     assert int(ys[7]) == orc.poly_eval(GP, msg, int(xs[7])) and int(ys[3071]) == orc.poly_eval(GP, msg, int(xs[3071]))
 
 
+def test_scan_and_chirp_adversarial_inputs(R, orc):
+    """edge values through the Horner scans, the chirp-z dft and the interpolation: all p-1 / all zero / single one
+    coefficients, evaluation points and divisors at 0, 1, p-1, 2^32-1 (= 2^64 mod p), 2^32"""
+    from ronkathon_amd import _lib as L
+    from ronkathon_amd.callers import Message
+    F = R.GoldilocksField
+    d = 9000
+    for a in adversarial(d):
+        for z in (0, 1, GP - 1, 0xFFFFFFFF, 1 << 32, GP - 0xFFFFFFFF):
+            assert int(R.Polynomial.new(F, a).evaluate(z)) == orc.poly_eval(GP, a, z)
+            b = [(GP - z) % GP, 1]                                    # x - z
+            q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+            oq, orr = orc.poly_divrem(GP, a, b)
+            assert np.array_equal(q.coefficients, oq) and np.array_equal(r.coefficients, orr), z
+        b = [GP - 1, GP - 1]                                           # non-monic, both coefficients p-1
+        q, r = R.Polynomial.new(F, a).quotient_and_remainder(R.Polynomial.new(F, b))
+        oq, orr = orc.poly_divrem(GP, a, b)
+        assert np.array_equal(q.coefficients, oq) and np.array_equal(r.coefficients, orr)
+    n = 771                                                            # 3 * 257: chirp-z path
+    for a in adversarial(n):
+        out = np.empty(n, dtype=np.uint64)
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(a), L.ptr(out), n))
+        assert np.array_equal(out, orc.dft(GP, GG, a))
+    K = 64
+    xs, _ = Message(F, [1] * K).encode(256)
+    for y in adversarial(K):                                           # interpolation of edge values at the first K nodes
+        assert np.array_equal(Message.decode(F, xs, y, K).data, orc.rs_decode(GP, xs, y, K))
+
+
 def test_lagrange_evaluate_vs_oracle(R, orc):
     """Polynomial::<Lagrange>::evaluate on the GPU (ronk_lagrange_eval) vs the oracle's step-by-step fold"""
     for p, g, ns in ((101, 2, (1, 2, 4, 5, 10, 20, 25)), (17, 14, (1, 2, 4, 8, 16)), (GP, GG, (1, 3, 8, 15, 64, 96, 1024))):
