@@ -236,13 +236,18 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
       for (int i = 0; i < 16; i++)
         if (!(ABL & 8)) x[i] = lc[swz_row(base + i * RLAST) << logc];
+      // The results are parked at row k2*(16*RLAST) + m  (m = d1*RLAST + d3), NOT back at the rows just read: with
+      // the digits in this order the last round's group v = row / RLAST is the natural output index k1 + 16*k2
+      // itself, so consecutive lanes finish with consecutive output rows (full-line stores instead of 8-byte pieces
+      // 16 rows apart).  Not in place any more: everyone must have read before anyone writes.
+      if (!(ABL & 8)) barrier();
       if (!(ABL & 4)) Dif<16, INV>::run(x);
       const u32 tstep = 16 * d3;  // omega_{R/16}^{d3*k2} = omega_R^{16*d3*k2}
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
         if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, tstep * k2)));
-        if (!(ABL & 8)) lc[swz_row(base + k2 * RLAST) << logc] = x[i];
+        if (!(ABL & 8)) lc[swz_row(k2 * (16 * RLAST) + m) << logc] = x[i];
       }
       if (!(ABL & 8)) barrier();
     }
@@ -275,8 +280,8 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
       for (int i = 0; i < GSZ; i++) kg[i] = brev(i, 4);
     } else {
       if (!(ABL & 4)) Dif<RLAST, INV>::run(xg);
-      const u32 v = m * (16 / RLAST) + g;                          // (d1[,d2]) pair index of this group
-      const u32 kl = (Q == 3) ? ((v >> 4) + 16 * (v & 15)) : v;    // k1 + 16 k2  |  k1
+      const u32 v = m * (16 / RLAST) + g;                          // group index = row / RLAST
+      const u32 kl = v;                                            // = k1 + 16 k2 (three rounds, see the parking) | k1
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }

@@ -74,18 +74,55 @@ static float time_launch(std::function<void()> f, int iters) {
   return ms * 1e3f / iters;  // us
 }
 
-template <int ABL>
+template <int ABL, int LOGR = 11>
 static void run_abl(const PlanDesc& pd, int pass, TileArgs a, const char* label) {
   const PassDesc& ps = pd.passes[pass];
-  static bool attr = false;
-  (void)attr;
-  CK(hipFuncSetAttribute((const void*)abl_kernel<11, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  float us = time_launch([&] { hipLaunchKernelGGL((abl_kernel<11, false, ABL>), dim3(ps.grid), dim3(ps.block), ps.lds_bytes, 0, a); }, 50);
+  CK(hipFuncSetAttribute((const void*)abl_kernel<LOGR, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  float us = time_launch([&] { hipLaunchKernelGGL((abl_kernel<LOGR, false, ABL>), dim3(ps.grid), dim3(ps.block), ps.lds_bytes, 0, a); }, 50);
   printf("  pass %d  ABL=%2d  %-42s %8.2f us\n", pass, ABL, label, us);
+}
+
+// single-pass batched transforms (n = 2^LOGR, the batch is the column axis): the same ablation
+template <int LOGR>
+static void single_pass_ablation(u64 batch, int max_logc) {
+  const size_t n = (size_t)1 << LOGR, total = n * batch;
+  PlanDesc pd = build_plan(LOGR, batch, false, max_logc);
+  std::vector<u64> h(total);
+  u64 s = 777;
+  for (auto& v : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = s % gl64::P; }
+  u64 *d_in, *d_out, *d_wr;
+  CK(hipMalloc(&d_in, total * 8)); CK(hipMalloc(&d_out, total * 8));
+  CK(hipMemcpy(d_in, h.data(), total * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_wr, pd.wr[0].size() * 8)); CK(hipMemcpy(d_wr, pd.wr[0].data(), pd.wr[0].size() * 8, hipMemcpyHostToDevice));
+  const PassDesc& ps = pd.passes[0];
+  TileArgs a = ps.args;
+  a.in = d_in; a.out = d_out; a.wr = d_wr;
+  printf("== single-pass ablation, n = 2^%d x %llu polynomials, logc = %u, grid %u x %u threads, lds %zu B\n", LOGR,
+         (unsigned long long)batch, ps.args.logc, ps.grid, ps.block, ps.lds_bytes);
+  run_abl<0, LOGR>(pd, 0, a, "full");
+  run_abl<2, LOGR>(pd, 0, a, "- round twiddles");
+  run_abl<4, LOGR>(pd, 0, a, "- butterflies");
+  run_abl<7, LOGR>(pd, 0, a, "- all math (loads, LDS, stores only)");
+  run_abl<8, LOGR>(pd, 0, a, "- LDS exchange");
+  run_abl<15, LOGR>(pd, 0, a, "- math - LDS (global loads+stores only)");
+  run_abl<16, LOGR>(pd, 0, a, "- global loads");
+  run_abl<32, LOGR>(pd, 0, a, "- global stores");
+  run_abl<48, LOGR>(pd, 0, a, "- global loads - stores (compute+LDS only)");
+  run_abl<47, LOGR>(pd, 0, a, "loads only");
+  run_abl<31, LOGR>(pd, 0, a, "stores only");
+  run_abl<56, LOGR>(pd, 0, a, "math only (no mem, no LDS)");
+  CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_wr));
 }
 
 int main(int argc, char** argv) {
   int max_logc = argc > 1 ? atoi(argv[1]) : 4;
+  if (argc > 2) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
+    const int k = atoi(argv[2]);
+    if (k == 12) single_pass_ablation<12>(4096, max_logc);
+    else if (k == 10) single_pass_ablation<10>(16384, max_logc);
+    else single_pass_ablation<8>(65536, max_logc);
+    return 0;
+  }
   const int log2n = 22;
   const size_t n = (size_t)1 << log2n;
   PlanDesc pd = build_plan(log2n, 1, false, max_logc);
