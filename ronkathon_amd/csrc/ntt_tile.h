@@ -6,7 +6,7 @@
 // one 64-128 B segment on both the load and the store side, whatever the strides are.  A
 // thread owns 16 coefficients in VGPRs; the R-point transform is done as up to three
 // register-resident radix-16 (last round radix-2..16) decimation-in-frequency rounds with
-// the tile staged through LDS between rounds (in place, two barriers at most):
+// the tile staged through LDS between rounds (three barriers at most; the second exchange is digit-swapped):
 //
 //   round i : 16-point sub-DFT over digit j_i (pure shifts: omega_16^k = +-2^K, gl64.h)
 //             then one table twiddle omega_M^{rest * k_i} per coefficient
