@@ -93,22 +93,23 @@ struct PlanBuilder {
   }
 
   // columns per tile for an R-row pass over `ncols` columns
-  static u32 pick_logc(int logr, u64 ncols, int max_logc) {
+  // wg_floor_log: log2 of the smallest tile in coefficients (12 = 256 work-items; single-pass plans use 10 = one wave)
+  static u32 pick_logc(int logr, u64 ncols, int max_logc, int wg_floor_log = 12) {
     int lc = 14 - logr;                 // R*C <= 16384 coefficients (128 KiB LDS, 1024 threads)
-    int want = max_logc > 12 - logr ? max_logc : 12 - logr;  // small R: widen to 256 threads
+    int want = max_logc > wg_floor_log - logr ? max_logc : wg_floor_log - logr;  // small R: widen the workgroup
     if (lc > want) lc = want;
     if (lc < 0) lc = 0;
     while (lc > 0 && ((u64)1 << lc) > ncols) lc--;
     return (u32)lc;
   }
 
-  PassDesc& add_pass(int logr, u64 ncols, int max_logc) {
+  PassDesc& add_pass(int logr, u64 ncols, int max_logc, int wg_floor_log = 12) {
     PassDesc p;
     p.logr = logr;
     p.args = TileArgs();
     p.args.in = p.args.in2 = nullptr;
     p.args.out = nullptr;
-    p.args.logc = pick_logc(logr, ncols, max_logc);
+    p.args.logc = pick_logc(logr, ncols, max_logc, wg_floor_log);
     u64 C = (u64)1 << p.args.logc;
     p.args.tiles = (u32)((ncols + C - 1) / C);
     p.args.ncols = ncols;
@@ -181,8 +182,9 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
   const u64 n = (u64)1 << log2n;
   const u64 scale = inverse ? gl64::inv(n % gl64::P) : 1;  // F::from(D).inverse(), mod.rs:442
   if (log2n <= 12) {
-    // the batch is the column axis: column c = polynomial c, rows contiguous
-    PassDesc& p = b.add_pass(log2n, batch, max_logc);
+    // the batch is the column axis: column c = polynomial c, rows contiguous.  Neighbouring columns are n elements
+    // apart, so narrow tiles (down to one wave) keep each wave on long contiguous runs of every polynomial.
+    PassDesc& p = b.add_pass(log2n, batch, max_logc, 10);
     p.args.in_sj = 1; p.args.in_sc = (i64)n;
     p.args.out_sk = 1; p.args.out_sc = (i64)n;
     p.args.scale = scale;
