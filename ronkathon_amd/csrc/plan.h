@@ -13,6 +13,7 @@
 // Every pass is the same kernel with different strides; exactly one pass transposes
 // (rows in, columns out), so it reads its input from a scratch buffer.
 #pragma once
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <map>
@@ -103,7 +104,9 @@ struct PlanBuilder {
     return (u32)lc;
   }
 
-  PassDesc& add_pass(int logr, u64 ncols, int max_logc, int wg_floor_log = 12) {
+  int multi_pass_floor_log = 12;   // smallest multi-pass tile, log2 coefficients (planner knob, RONK_WG_FLOOR_LOG)
+  PassDesc& add_pass(int logr, u64 ncols, int max_logc, int wg_floor_log = 0) {
+    if (wg_floor_log == 0) wg_floor_log = multi_pass_floor_log;
     PassDesc p;
     p.logr = logr;
     p.args = TileArgs();
@@ -174,10 +177,12 @@ struct PlanBuilder {
 
 // max_logc: widest tile (log2 columns) the builder may pick; 4 = 128-byte segments.
 // three_pass_from: smallest log2n that is split in three passes (25 = only when two do not fit).
+// auto_tiles: the caller left the tile width to the planner -- apply the measured per-pass preferences (below).
 inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0,
-                           int three_pass_from = 25) {
+                           int three_pass_from = 25, bool auto_tiles = false) {
   PlanBuilder b;
   b.twf_max_log = twf_max_log;
+  if (const char* e = getenv("RONK_WG_FLOOR_LOG")) { int v = atoi(e); if (v >= 10 && v <= 14) b.multi_pass_floor_log = v; }
   b.d.log2n = log2n; b.d.batch = batch; b.d.inverse = inverse;
   const u64 n = (u64)1 << log2n;
   const u64 scale = inverse ? gl64::inv(n % gl64::P) : 1;  // F::from(D).inverse(), mod.rs:442
@@ -197,9 +202,17 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     // Pass 1 then writes one contiguous A*Cp block per workgroup (adjacent 64-byte rows pair up into full
     // 128-byte lines inside one workgroup), and pass 2 -- lanes over (ka, 8 consecutive b) -- reads fully
     // contiguous 512-byte runs.  Only the two passes see this layout.
+    // Measured tile preference, applied when the tile width is left to the planner: when a pass has
+    // many tiles per CU (>= 4 of the largest size), tiles of 8192 coefficients -- two resident workgroups per CU, in
+    // different phases -- beat 16384 (2^20 x 64: 0.961 -> 0.826 ms, 2^22 x 16: 1.04 -> 0.925); with one tile per CU
+    // (a single 2^22 transform) the large tile stays better, and for 2^8 / 2^9-row passes C = 16 stays best.
+    const bool many_tiles = auto_tiles && (double)batch * (double)n / 16384.0 >= 1024.0;
+    int lc1 = max_logc, lc2 = max_logc;
+    if (many_tiles && ka >= 10 && ka <= 11 && lc1 > 13 - ka) lc1 = 13 - ka;
+    if (many_tiles && kb >= 10 && kb <= 11 && lc2 > 13 - kb) lc2 = 13 - kb;
     u32 logcp;
     {
-      PassDesc& p = b.add_pass(ka, B, max_logc);  // [A][B]: columns b, rows a
+      PassDesc& p = b.add_pass(ka, B, lc1);  // [A][B]: columns b, rows a
       logcp = p.args.logc;
       const i64 Cp = (i64)1 << logcp;
       p.args.in_sj = (i64)B; p.args.in_sc = 1;
@@ -212,7 +225,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
       b.finish(p);
     }
     {
-      PassDesc& p = b.add_pass(kb, A, max_logc);  // rows ka are the columns of this pass
+      PassDesc& p = b.add_pass(kb, A, lc2);  // rows ka are the columns of this pass
       const i64 Cp = (i64)1 << logcp, C2 = (i64)1 << p.args.logc;
       // j = b: (b >> logcp) selects the pass-1 tile, (b & (Cp-1)) the column inside it
       p.args.in_sj = 1; p.args.js_log = logcp; p.args.in_sj_hi = (i64)A * Cp;

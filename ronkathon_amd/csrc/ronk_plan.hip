@@ -52,8 +52,10 @@ extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, u
     // covers 64/C consecutive rows of each polynomial -- 2^12: 0.509 -> 0.431 ms, 2^11: 0.500 -> 0.414, 2^10: 0.512 ->
     // 0.429 per 2^26 coefficients against C = 16.
     int max_logc = log2n <= 12 ? 0 : 4;
-    if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) max_logc = v; }
-    if (tile_log2_columns >= 0 && tile_log2_columns <= 8) max_logc = tile_log2_columns;
+    bool auto_tiles = true;   // per-pass tile preferences of plan.h apply unless a width was asked for
+    if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) { max_logc = v; auto_tiles = false; } }
+    if (tile_log2_columns >= 0 && tile_log2_columns <= 8) { max_logc = tile_log2_columns; auto_tiles = false; }
+    if (getenv("RONK_WG_FLOOR_LOG")) auto_tiles = false;
     // Full inter-pass twiddle matrix (one coalesced load + one multiply instead of two gathers + two
     // multiplies) while it stays L2-resident: up to 2^18 entries = 2 MiB.  Larger matrices would add an
     // n-element HBM read per transform (measured +4 % speed at 2^22 for +25 % traffic): left to RONK_TWF_MAX_LOG.
@@ -62,8 +64,8 @@ extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, u
     if (twiddle_matrix_log2_max >= 0 && twiddle_matrix_log2_max <= 26) twf_max_log = twiddle_matrix_log2_max;
     int three_from = 25;  // RONK_THREE_PASS_FROM: split smaller sizes in three passes too (experiment knob)
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
-    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from));
-    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from));
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles));
     for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
       if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
   } else {

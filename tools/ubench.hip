@@ -114,18 +114,11 @@ static void single_pass_ablation(u64 batch, int max_logc) {
   CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_wr));
 }
 
-int main(int argc, char** argv) {
-  int max_logc = argc > 1 ? atoi(argv[1]) : 4;
-  if (argc > 2) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
-    const int k = atoi(argv[2]);
-    if (k == 12) single_pass_ablation<12>(4096, max_logc);
-    else if (k == 10) single_pass_ablation<10>(16384, max_logc);
-    else single_pass_ablation<8>(65536, max_logc);
-    return 0;
-  }
-  const int log2n = 22;
-  const size_t n = (size_t)1 << log2n;
-  PlanDesc pd = build_plan(log2n, 1, false, max_logc);
+// two-pass ablation of a [batch][2^log2n] transform whose passes both have 2^LOGR rows
+template <int LOGR>
+static void two_pass_ablation(int log2n, u64 batch, int max_logc, u64** keep_in, u64** keep_out) {
+  const size_t n = ((size_t)1 << log2n) * batch;
+  PlanDesc pd = build_plan(log2n, batch, false, max_logc, 18);
   std::vector<u64> h(n);
   u64 s = 12345;
   for (auto& v : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = s % gl64::P; }
@@ -142,7 +135,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&hi, t.hi.size() * 8)); CK(hipMemcpy(hi, t.hi.data(), t.hi.size() * 8, hipMemcpyHostToDevice));
     d_tw.push_back({lo, hi});
   }
-  printf("== ablation, n = 2^22, logc = %u / %u, grid %u x %u threads, lds %zu B\n", pd.passes[0].args.logc,
+  printf("== ablation, n = 2^%d x %llu, logc = %u / %u, grid %u x %u threads, lds %zu B\n", log2n, (unsigned long long)batch, pd.passes[0].args.logc,
          pd.passes[1].args.logc, pd.passes[0].grid, pd.passes[0].block, pd.passes[0].lds_bytes);
   for (int pass = 0; pass < 2; pass++) {
     const PassDesc& ps = pd.passes[pass];
@@ -151,23 +144,47 @@ int main(int argc, char** argv) {
     a.out = pass == 0 ? d_tmp : d_out;
     a.wr = d_wr[ps.wr_id];
     if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
-    run_abl<0>(pd, pass, a, "full");
-    run_abl<1>(pd, pass, a, "- inter-pass twiddle");
-    run_abl<2>(pd, pass, a, "- round twiddles");
-    run_abl<3>(pd, pass, a, "- all twiddles");
-    run_abl<4>(pd, pass, a, "- butterflies");
-    run_abl<7>(pd, pass, a, "- all math (loads, LDS, stores only)");
-    run_abl<8>(pd, pass, a, "- LDS exchange");
-    run_abl<15>(pd, pass, a, "- math - LDS (global loads+stores only)");
-    run_abl<16>(pd, pass, a, "- global loads");
-    run_abl<32>(pd, pass, a, "- global stores");
-    run_abl<48>(pd, pass, a, "- global loads - stores (compute+LDS only)");
-    run_abl<47>(pd, pass, a, "loads only");
-    run_abl<31>(pd, pass, a, "stores only");
-    run_abl<56>(pd, pass, a, "math only (no mem, no LDS)");
-    run_abl<64>(pd, pass, a, "full, twiddle values without table loads");
-    run_abl<120>(pd, pass, a, "math only, no twiddle loads");
+    if (ps.twf_id >= 0) {
+      u64* d; CK(hipMalloc(&d, pd.twf[ps.twf_id].size() * 8));
+      CK(hipMemcpy(d, pd.twf[ps.twf_id].data(), pd.twf[ps.twf_id].size() * 8, hipMemcpyHostToDevice));
+      a.tw_full = d;
+    }
+    run_abl<0, LOGR>(pd, pass, a, "full");
+    run_abl<1, LOGR>(pd, pass, a, "- inter-pass twiddle");
+    run_abl<2, LOGR>(pd, pass, a, "- round twiddles");
+    run_abl<3, LOGR>(pd, pass, a, "- all twiddles");
+    run_abl<4, LOGR>(pd, pass, a, "- butterflies");
+    run_abl<7, LOGR>(pd, pass, a, "- all math (loads, LDS, stores only)");
+    run_abl<8, LOGR>(pd, pass, a, "- LDS exchange");
+    run_abl<15, LOGR>(pd, pass, a, "- math - LDS (global loads+stores only)");
+    run_abl<16, LOGR>(pd, pass, a, "- global loads");
+    run_abl<32, LOGR>(pd, pass, a, "- global stores");
+    run_abl<48, LOGR>(pd, pass, a, "- global loads - stores (compute+LDS only)");
+    run_abl<47, LOGR>(pd, pass, a, "loads only");
+    run_abl<31, LOGR>(pd, pass, a, "stores only");
+    run_abl<56, LOGR>(pd, pass, a, "math only (no mem, no LDS)");
+    run_abl<64, LOGR>(pd, pass, a, "full, twiddle values without table loads");
+    run_abl<120, LOGR>(pd, pass, a, "math only, no twiddle loads");
   }
+  *keep_in = d_in; *keep_out = d_out;
+}
+
+int main(int argc, char** argv) {
+  int max_logc = argc > 1 ? atoi(argv[1]) : 4;
+  if (argc == 3) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
+    const int k = atoi(argv[2]);
+    if (k == 12) single_pass_ablation<12>(4096, max_logc);
+    else if (k == 10) single_pass_ablation<10>(16384, max_logc);
+    else single_pass_ablation<8>(65536, max_logc);
+    return 0;
+  }
+  u64 *d_in = nullptr, *d_out = nullptr;
+  if (argc > 3) {   // ubench <max_logc> 16 1024: the two LOGR = 8 passes of the batched 2^16 transform (config 4)
+    two_pass_ablation<8>(16, (u64)atoll(argv[3]), max_logc, &d_in, &d_out);
+    return 0;
+  }
+  const size_t n = (size_t)1 << 22;
+  two_pass_ablation<11>(22, 1, max_logc, &d_in, &d_out);
   // ---- raw op rates
   u64* d_scr;
   CK(hipMalloc(&d_scr, 256 * 2048 * 8));
