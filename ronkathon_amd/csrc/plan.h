@@ -13,6 +13,7 @@
 // Every pass is the same kernel with different strides; exactly one pass transposes
 // (rows in, columns out), so it reads its input from a scratch buffer.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
 
@@ -242,7 +243,13 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     }
     b.d.needs_tmp = true;
   } else {
-    const int ka = (log2n + 2) / 3, kb = (log2n - ka + 1) / 2, kc = log2n - ka - kb;
+    int ka = (log2n + 2) / 3, kb = (log2n - ka + 1) / 2;
+    if (const char* e = getenv("RONK_SPLIT3")) {   // "ka,kb" (planner experiments)
+      int va = 0, vb = 0;
+      if (sscanf(e, "%d,%d", &va, &vb) == 2 && va >= 4 && va <= 12 && vb >= 4 && vb <= 12 && log2n - va - vb >= 4 &&
+          log2n - va - vb <= 12) { ka = va; kb = vb; }
+    }
+    const int kc = log2n - ka - kb;
     const u64 A = (u64)1 << ka, B = (u64)1 << kb, C = (u64)1 << kc, BC = B * C;
     {
       PassDesc& p = b.add_pass(ka, BC, max_logc);  // [A][B*C]
