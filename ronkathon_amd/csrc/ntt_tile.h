@@ -71,6 +71,11 @@ struct TileArgs {
   // (everything but the b1 term), loads with lin >= in_valid read as ZERO and stores with lin >= out_valid are
   // dropped.  ~0 = no limit.
   u64 in_valid, out_valid;
+  // Staged I/O for single-pass plans of tiny transforms (n = 16, 32; plan.h): the tile -- C whole polynomials -- is one contiguous
+  // run of R*C elements on both sides, but a lane's own accesses are only M*8 bytes long (n = 16: one polynomial per
+  // lane, 128-byte lane stride, outputs in bit-reversed order).  With stage_io the run is copied HBM <-> LDS with fully
+  // coalesced accesses and the per-lane indexing happens against LDS (image e + e/16, e = c*R + row).
+  u32 stage_io;
 };
 
 // ---- compile-time helpers -------------------------------------------------------------
@@ -197,7 +202,23 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
     for (int i = 0; i < 16; i++) joff[i] = j0 + i * step;
   }
-  if (ABL & 16) {
+  const u32 T = (u32)(R / 16) << logc;                     // work-items of the tile
+  const u64 tile_cols = a.ncols - col0 < (u64)C ? a.ncols - col0 : (u64)C;
+  const u32 stage_valid = (u32)tile_cols * (u32)R;         // elements of the tile that exist (ragged last tile)
+  if (a.stage_io && !(ABL & 16)) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 e = tid + T * i;
+      lds[e + (e >> 4)] = e < stage_valid ? in[e] : 0;
+    }
+    barrier();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 e = c * (u32)R + (u32)(i * M) + m;
+      x[i] = lds[e + (e >> 4)];
+    }
+    barrier();                                             // the image is read before round 1 parks anything
+  } else if (ABL & 16) {
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = (u64)(tid * 16 + i);
   } else if (live && a.in_valid != ~(u64)0) {
@@ -271,6 +292,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   const u64* const tf = a.tw_full ? a.tw_full + (col * a.tf_sc + b2 * a.tf_sb2) : nullptr;
   const u64 lin_out0 = (u64)b2 * (u64)a.out_sb2 + (u64)t * (u64)a.out_st;
   u64 keep = 0;
+  if (a.stage_io && Q > 1) barrier();                      // every lane has read its last-round rows: LDS is free
 #pragma unroll
   for (int g = 0; g < 16 / GSZ; g++) {
     u64* xg = x + g * GSZ;
@@ -307,7 +329,13 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
       for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], a.scale);
     }
-    if (ABL & 32) {
+    if (a.stage_io && !(ABL & 32)) {
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) {
+        const u32 e = c * (u32)R + kg[i];
+        lds[e + (e >> 4)] = xg[i];
+      }
+    } else if (ABL & 32) {
 #pragma unroll
       for (int i = 0; i < GSZ; i++) keep ^= xg[i];
     } else if (live && a.out_valid != ~(u64)0) {
@@ -319,6 +347,14 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
     } else if (live) {
 #pragma unroll
       for (int i = 0; i < GSZ; i++) st_out(outp + (out_lane + kg[i] * out_sk), xg[i]);
+    }
+  }
+  if (a.stage_io && !(ABL & 32)) {
+    barrier();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 e = tid + T * i;
+      if (e < stage_valid) st_out(outp + e, lds[e + (e >> 4)]);
     }
   }
   if ((ABL & 32) && keep == 0x123456789ull) outp[0] = keep;  // keeps x live, never true in practice

@@ -127,6 +127,7 @@ struct PlanBuilder {
     p.args.yk = p.args.yb1 = p.args.yb2 = p.args.y0 = 0;
     p.args.scale = 1;
     p.args.in_valid = p.args.out_valid = ~(u64)0;
+    p.args.stage_io = 0;
     p.wr_id = wr_table(logr);
     p.args.wr = nullptr;
     p.tw_id = -1;
@@ -135,6 +136,7 @@ struct PlanBuilder {
     p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
     p.block = (u32)((((u64)1 << logr) * C) / 16);
     p.lds_bytes = logr > 4 ? ((((size_t)1 << logr) + ((size_t)1 << logr) / 16) * C * 8) : 0;  // +1 dummy row per 16
+    // (the staged-I/O image of a single-pass plan, e + e/16 over R*C elements, has the same size; build_plan sets it for R = 16)
     d.passes.push_back(p);
     return d.passes.back();
   }
@@ -194,6 +196,12 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     p.args.in_sj = 1; p.args.in_sc = (i64)n;
     p.args.out_sk = 1; p.args.out_sc = (i64)n;
     p.args.scale = scale;
+    if (log2n <= 5) {   // n = 16, 32: HBM <-> LDS copies of the contiguous tile (TileArgs::stage_io); n = 16: 112 -> 58 us per
+                        // 2^24 coefficients, n = 32: 0.428 -> 0.338 ms per 2^26; n = 64 is better without (0.301 vs 0.346 ms)
+      p.args.stage_io = 1;
+      const size_t E = (size_t)n << p.args.logc;
+      p.lds_bytes = (E + E / 16) * 8;
+    }
     b.finish(p);
   } else if (log2n <= 24 && log2n < three_pass_from) {
     // Balanced split, except 2^18: a 2^9-row pass costs three radix rounds (16*16*2), so (10, 8) -- five rounds -- beats

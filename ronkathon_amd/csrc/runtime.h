@@ -139,6 +139,7 @@ struct CompiledPlan {
       if (in_poly_stride) a.in_sb1 = (i64)in_poly_stride;   // nb1 is the batch axis of every multi-pass plan (plan.h)
     }
     if (ps.out_buf == BUF_OUT) a.out_valid = out_valid;
+    if (in_valid != ~(u64)0 || out_valid != ~(u64)0 || in_poly_stride) a.stage_io = 0;   // staged I/O copies whole tiles
     a.wr = d_wr[ps.wr_id];
     if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
     if (ps.twf_id >= 0) a.tw_full = d_twf[ps.twf_id];

@@ -86,7 +86,7 @@ static void run_abl(const PlanDesc& pd, int pass, TileArgs a, const char* label)
 template <int LOGR>
 static void single_pass_ablation(u64 batch, int max_logc) {
   const size_t n = (size_t)1 << LOGR, total = n * batch;
-  PlanDesc pd = build_plan(LOGR, batch, false, max_logc);
+  PlanDesc pd = build_plan(LOGR, batch, false, max_logc);   // same tile rule as the library: pass max_logc = 0
   std::vector<u64> h(total);
   u64 s = 777;
   for (auto& v : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = s % gl64::P; }
@@ -173,7 +173,9 @@ int main(int argc, char** argv) {
   int max_logc = argc > 1 ? atoi(argv[1]) : 4;
   if (argc == 3) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
     const int k = atoi(argv[2]);
-    if (k == 12) single_pass_ablation<12>(4096, max_logc);
+    if (k == 4) single_pass_ablation<4>(1048576, max_logc);
+    else if (k == 6) single_pass_ablation<6>(262144, max_logc);
+    else if (k == 12) single_pass_ablation<12>(4096, max_logc);
     else if (k == 10) single_pass_ablation<10>(16384, max_logc);
     else single_pass_ablation<8>(65536, max_logc);
     return 0;
