@@ -32,6 +32,9 @@ def run(emu, *args):
 def test_single_pass(emu, k):
     run(emu, k, 3, 0, 4)
     run(emu, k, 2, 1, 4)
+    if k <= 6:      # tiny transforms: staged I/O (n <= 32) with full, several and ragged tiles, both tile-width rules
+        run(emu, k, 200, 0, 4)
+        run(emu, k, 257, 1, 0)
 
 
 @pytest.mark.parametrize("k,batch,inv,logc", [(13, 2, 0, 4), (16, 1, 1, 4), (17, 1, 0, 3), (20, 1, 0, 4), (22, 1, 0, 4)])
