@@ -257,10 +257,12 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 #pragma unroll
       for (int i = 0; i < 16; i++)
         if (!(ABL & 8)) x[i] = lc[swz_row(base + i * RLAST) << logc];
-      // The results are parked at row k2*(16*RLAST) + m  (m = d1*RLAST + d3), NOT back at the rows just read: with
-      // the digits in this order the last round's group v = row / RLAST is the natural output index k1 + 16*k2
-      // itself, so consecutive lanes finish with consecutive output rows (full-line stores instead of 8-byte pieces
-      // 16 rows apart).  Not in place any more: everyone must have read before anyone writes.
+      // The results are NOT parked back at the rows just read.  The sub-transform with natural output index
+      // kl = k1 + 16*k2 (k1 = d1) goes to group slot s = (kl mod M)*G + kl div M, G = 16/RLAST groups per lane, i.e. rows
+      // s*RLAST .. s*RLAST + RLAST-1.  Lane m, which owns rows 16m .. 16m+15 in the last round, then holds the groups
+      // kl = m + g*M: consecutive lanes finish with consecutive output rows in every store instruction (full lines;
+      // with kl = (v >> 4) + 16*(v & 15) they were 16 rows apart, with kl = 2m + g a lane wrote the two halves of a
+      // 128-byte line at different times: +37 % write traffic in pass 1).  Not in place: read everything, then write.
       if (!(ABL & 8)) barrier();
       if (!(ABL & 4)) Dif<16, INV>::run(x);
       const u32 tstep = 16 * d3;  // omega_{R/16}^{d3*k2} = omega_R^{16*d3*k2}
@@ -268,7 +270,9 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
         if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, tstep * k2)));
-        if (!(ABL & 8)) lc[swz_row(k2 * (16 * RLAST) + m) << logc] = x[i];
+        const u32 klw = (u32)k2 * 16 + d1;
+        const u32 slot = (klw & (M - 1)) * (16 / RLAST) + (klw / M);
+        if (!(ABL & 8)) lc[swz_row((slot << LOGLAST) + d3) << logc] = x[i];
       }
       if (!(ABL & 8)) barrier();
     }
@@ -302,8 +306,9 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
       for (int i = 0; i < GSZ; i++) kg[i] = brev(i, 4);
     } else {
       if (!(ABL & 4)) Dif<RLAST, INV>::run(xg);
-      const u32 v = m * (16 / RLAST) + g;                          // group index = row / RLAST
-      const u32 kl = v;                                            // = k1 + 16 k2 (three rounds, see the parking) | k1
+      // three rounds: group g of lane m is the sub-transform kl = m + g*M (see the parking of round 2);
+      // two rounds: the groups are in row order, kl = row / RLAST
+      const u32 kl = (Q == 3) ? m + (u32)g * M : m * (16 / RLAST) + g;
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
