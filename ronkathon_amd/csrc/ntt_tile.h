@@ -241,12 +241,16 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
 
   if (Q > 1) {
     u64* const lc = lds + c;
-    // twiddle omega_R^{m*k1}, then park at row k1*M + m
+    // twiddle omega_R^{m*k1}, then park at row k1*M + m.  Two-round tiles (M == RLAST): the row block of k1 is the
+    // last round's group with natural output index kl = k1; it is parked at group slot (k1 mod M)*G + k1 div M so that
+    // lane m' of the last round (rows 16m' .. 16m'+15) owns the groups kl = m' + g*M -- adjacent output rows come from
+    // adjacent lanes of one store instruction (same reasoning as the parking of round 2 below).
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
       if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, m * k1)));
-      if (!(ABL & 8)) lc[swz_row(k1 * M + m) << logc] = x[i];
+      const u32 blk = (Q == 2) ? (k1 & (M - 1)) * (16 / RLAST) + k1 / M : k1;
+      if (!(ABL & 8)) lc[swz_row(blk * M + m) << logc] = x[i];
     }
     if (!(ABL & 8)) barrier();
 
@@ -306,9 +310,8 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
       for (int i = 0; i < GSZ; i++) kg[i] = brev(i, 4);
     } else {
       if (!(ABL & 4)) Dif<RLAST, INV>::run(xg);
-      // three rounds: group g of lane m is the sub-transform kl = m + g*M (see the parking of round 2);
-      // two rounds: the groups are in row order, kl = row / RLAST
-      const u32 kl = (Q == 3) ? m + (u32)g * M : m * (16 / RLAST) + g;
+      // group g of lane m is the sub-transform with natural index kl = m + g*M (see the parking of rounds 1 / 2)
+      const u32 kl = m + (u32)g * M;
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
