@@ -296,7 +296,7 @@ def test_device_pointer_api_inplace_and_streams(R, orc):
     """_dev entry points on caller-owned device memory: out-of-place, in-place, on a side stream"""
     import torch
     from ronkathon_amd import _lib as L
-    for k, batch in ((10, 5), (16, 2), (20, 1)):
+    for k, batch in ((4, 1000), (5, 77), (6, 300), (9, 40), (10, 5), (16, 2), (20, 1)):   # 4, 5: staged I/O tiles
         n = 1 << k
         x = splitmix_field(900 + k, n * batch)
         ref = np.concatenate([orc.fft(GP, GG, x[b * n:(b + 1) * n]) for b in range(batch)])
