@@ -44,6 +44,18 @@ class _Element:
     def __init__(self, value=0):                 # PrimeField::new: value % P (prime/mod.rs:48-51)
         self.value = int(value) % self.ORDER
 
+    @classmethod
+    def from_str(cls, s):                        # FromStr (prime/mod.rs:262-270): parse, then new
+        return cls(int(str(s).strip()))
+
+    @classmethod
+    def sample(cls, rng):                        # Distribution<PrimeField<P>> for Standard (prime/mod.rs:129-140):
+        while True:                              # 28-bit draws (next_u32 >> 4) until one is below ORDER
+            draws = rng.integers(0, 1 << 32, size=4096, dtype=np.uint64) >> np.uint64(4)   # (batched: for a small
+            ok = np.nonzero(draws < np.uint64(cls.ORDER))[0]                               #  P almost all are rejected)
+            if ok.size:
+                return cls(int(draws[ok[0]]))
+
     # --- Field trait (field/mod.rs:17-51)
     def inverse(self):                           # prime/mod.rs:62-72: None for zero
         if self.value == 0:

@@ -82,6 +82,14 @@ class Polynomial:
         return "Polynomial<%r, %s, %d>%s" % (self.basis, self.field.__name__, self.D,
                                               self.coefficients[:8].tolist())
 
+    def __str__(self):
+        """`Display` (Monomial: mod.rs:326-342, Lagrange: mod.rs:487-501): `c0 + c1x^1 + ...` / `c0*l_0(x) + ...`"""
+        c = self.coefficients.tolist()
+        if isinstance(self.basis, Monomial):
+            return " + ".join(("%d" % v) if i == 0 else ("%dx^%d" % (v, i)) for i, v in enumerate(c))
+        nodes = self.basis.nodes.tolist()         # the subscript is the NODE, as in the reference
+        return " + ".join("%d*l_%d(x)" % (v, nd) for v, nd in zip(c, nodes))
+
     def _mono(self):
         if not isinstance(self.basis, Monomial):
             raise TypeError("operation is only implemented for the Monomial basis")

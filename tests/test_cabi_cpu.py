@@ -96,3 +96,24 @@ def test_host_mirror_scalar_surface(refvec):
     assert int(R.GoldilocksField.PRIMITIVE_ELEMENT) == 7
     for p, n, w in refvec["roots_of_unity"]["cases"]:
         assert int(R.PrimeField(p).primitive_root_of_unity(n)) == w
+
+
+def test_minor_trait_surface_of_the_mirror():
+    """SURVEY.md 8(b) "minor surface": Display, From<i32>, FromStr, Distribution -- host-only, no device needed"""
+    import numpy as np
+    from ronkathon_amd.field import PrimeField
+    from ronkathon_amd.polynomial import Polynomial, Monomial, Lagrange
+    F = PrimeField(101)
+    assert F(-3) == F(98) and F.from_str(" 205 ") == F(3) and str(F(7)) == "7"          # prime/mod.rs:125-127, :250-270
+    rng = np.random.default_rng(1)
+    xs = [F.sample(rng) for _ in range(3)]                                               # 28-bit draws, rejection
+    assert all(0 <= int(x) < 101 for x in xs)
+    G = PrimeField(0xFFFFFFFF00000001)
+    assert all(int(G.sample(rng)) < (1 << 28) for _ in range(20))                        # the sampler never exceeds 28 bits
+    p = Polynomial.__new__(Polynomial)
+    p.field, p.basis, p.coefficients = F, Monomial(), np.array([1, 2, 3], dtype=np.uint64)
+    assert str(p) == "1 + 2x^1 + 3x^2"                                                     # polynomial/mod.rs:326-342
+    lag = Lagrange.__new__(Lagrange)
+    lag.nodes = np.array([1, 84, 16], dtype=np.uint64)
+    p.basis = lag
+    assert str(p) == "1*l_1(x) + 2*l_84(x) + 3*l_16(x)"                                    # polynomial/mod.rs:487-501
