@@ -62,7 +62,10 @@ extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, u
     int twf_max_log = 18;
     if (const char* e = getenv("RONK_TWF_MAX_LOG")) { int v = atoi(e); if (v >= 0 && v <= 26) twf_max_log = v; }
     if (twiddle_matrix_log2_max >= 0 && twiddle_matrix_log2_max <= 26) twf_max_log = twiddle_matrix_log2_max;
-    int three_from = 25;  // RONK_THREE_PASS_FROM: split smaller sizes in three passes too (experiment knob)
+    // Two passes up to 2^22; from 2^23 three passes are faster although they move 1.5x the bytes: a two-pass plan
+    // would need 2^12-row tiles of only 4 columns (32-byte row segments) -- 2^24: 0.331 -> 0.291 ms, 2^23 x 8: 1.135 ->
+    // 1.027 ms; at 2^22 two passes win (58.9 vs 66.6 us).  RONK_THREE_PASS_FROM overrides.
+    int three_from = 23;
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
     rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles));
     if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles));

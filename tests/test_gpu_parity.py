@@ -679,7 +679,7 @@ def test_lagrange_evaluate_vs_oracle(R, orc):
 
 @pytest.mark.parametrize("k", [24, 25])
 def test_large_plans_spot_and_roundtrip(R, orc, k):
-    """largest two-pass plan (2^24) and a three-pass plan (2^25): outputs spot-checked against the DEFINITION
+    """three-pass plans (the library default from 2^23 up): outputs spot-checked against the DEFINITION
     X[i] = sum_j x[j] w^(i j) (one O(n) Horner evaluation per checked output), plus the bit-exact round trip"""
     from ronkathon_amd import _lib as L
     n = 1 << k
