@@ -224,6 +224,21 @@ def test_config3_full_size_2_22(R, orc):
     assert int(prod[1]) == orc.add(GP, orc.mul(GP, int(a[0]), int(c[1])), orc.mul(GP, int(a[1]), int(c[0])))
 
 
+def test_config3_variant_ntt_size_2_23(R, orc):
+    """SURVEY.md 8(d) C3 variant: 2^22-coefficient operands -> NTT size 2^23 (a three-pass plan with the implicit
+    padding, the fused pointwise product and the truncated store); ragged operand lengths too.  Checked through the
+    evaluation homomorphism and the exact end coefficients."""
+    F = R.GoldilocksField
+    for da, db in ((1 << 22, 1 << 22), ((1 << 22) + 12345, (1 << 21) - 7)):
+        a = splitmix_field(0x5EED0A00 + da % 97, da); b = splitmix_field(0x5EED0B00 + db % 89, db)
+        prod = (R.Polynomial.new(F, a) * R.Polynomial.new(F, b)).coefficients
+        assert prod.size == da + db - 1
+        for pt in (3, 0x1234567890ABCDEF % GP):
+            assert orc.poly_eval(GP, prod, pt) == orc.mul(GP, orc.poly_eval(GP, a, pt), orc.poly_eval(GP, b, pt))
+        assert int(prod[0]) == orc.mul(GP, int(a[0]), int(b[0]))
+        assert int(prod[-1]) == orc.mul(GP, int(a[-1]), int(b[-1]))
+
+
 def test_poly_mul_vs_schoolbook(R, orc):
     F = R.GoldilocksField
     for d, d2 in ((1, 1), (17, 17), (64, 1), (100, 157), (1000, 3000), (5000, 5000)):
