@@ -83,7 +83,7 @@ static int horner_reduce_dev(const FieldCtx& f, const u64* d_c, size_t d, const 
   u64* H = ws; u64* carry = ws + nchunks;
   FIELD_DISPATCH(f, {
     hipLaunchKernelGGL((chunk_horner_kernel<decltype(ops)>), dim3((u32)nchunks), dim3(256), 0, s, ops, d_c, d, tab, H);
-    hipLaunchKernelGGL((chunk_carry_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, s, ops, H, nchunks, tab, carry, total);
+    hipLaunchKernelGGL((chunk_carry_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, H, nchunks, tab, carry, total);
   });
   HIPCHK(hipGetLastError());
   return RONK_OK;

@@ -10,7 +10,7 @@
 // Both are HBM-bound streaming jobs (8 B per coefficient read; the division also writes 8 B), organised
 // in chunks of CHUNK = 4096 coefficients = one 256-lane workgroup x 16:
 //   A  chunk_horner_kernel   H_b = sum_k c[base_b + k] z^k            (coalesced, lane-strided Horner in z^256)
-//   S  chunk_carry_kernel    G_b = H_b + z^4096 G_(b+1), G_nchunks = 0  (one workgroup; G_0 = c(z) = evaluate)
+//   S  chunk_carry_kernel    G_b = H_b + z^4096 G_(b+1), G_nchunks = 0  (one workgroup of 256; G_0 = c(z) = evaluate)
 //   B  lindiv_apply_kernel   q inside a chunk from the carry G_(b+1)   (LDS transpose, 16 contiguous per lane)
 // Powers of z come from the host in a kernarg table (HornerTab): no per-lane pow().
 #pragma once
@@ -69,33 +69,49 @@ __global__ void __launch_bounds__(256) chunk_horner_kernel(Ops ops, const u64* _
 }
 
 // S: carry[b] = G_(b+1) with G_b = H_b + Z G_(b+1), G_nchunks = 0 (Z = z^4096); *total = G_0.
-// One workgroup of 1024; segments of 1024 chunks from the top down, Hillis-Steele inside a segment.
+// One workgroup of 256; segments of 1024 chunks from the top down.  Inside a segment each lane owns 4 consecutive
+// chunks (sequential Horner), the lanes' results are scanned with the powers Z^(4*2^s) (Hillis-Steele, 8 steps),
+// then each lane re-runs its 4 entries from the value just above them.
 template <class Ops>
-__global__ void __launch_bounds__(1024) chunk_carry_kernel(Ops ops, const u64* __restrict__ H, size_t nchunks, HornerTab tab,
-                                                            u64* __restrict__ carry, u64* __restrict__ total) {
-  __shared__ u64 buf[1024];
+__global__ void __launch_bounds__(256) chunk_carry_kernel(Ops ops, const u64* __restrict__ H, size_t nchunks, HornerTab tab,
+                                                           u64* __restrict__ carry, u64* __restrict__ total) {
+  __shared__ u64 buf[256];
   __shared__ u64 s_in;
   const int tid = threadIdx.x;
+  const u64 Z = tab.Zp[0];
   const size_t nseg = (nchunks + 1023) / 1024;
   u64 incoming = 0;  // G at the first chunk above this segment
   for (size_t seg = nseg; seg-- > 0;) {
-    const size_t idx = seg * 1024 + tid;
-    u64 v = idx < nchunks ? H[idx] : 0;
-    if (tid == 1023) v = ops.add(v, ops.mul(tab.Zp[0], incoming));
+    const size_t i0 = seg * 1024 + 4 * (size_t)tid;
+    u64 h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = i0 + k < nchunks ? H[i0 + k] : 0;
+    if (tid == 255) h[3] = ops.add(h[3], ops.mul(Z, incoming));
+    // lane value: sum_k h[k] Z^k
+    u64 v = h[3];
+#pragma unroll
+    for (int k = 2; k >= 0; k--) v = ops.add(ops.mul(v, Z), h[k]);
     buf[tid] = v;
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 10; s++) {
+    for (int s = 0; s < 8; s++) {
       const int off = 1 << s;
       u64 w = v;
-      if (tid + off < 1024) w = ops.add(v, ops.mul(tab.Zp[s], buf[tid + off]));
+      if (tid + off < 256) w = ops.add(v, ops.mul(tab.Zp[s + 2], buf[tid + off]));   // (Z^4)^(2^s)
       __syncthreads();
       buf[tid] = v = w;
       __syncthreads();
     }
-    // v == G_idx.  carry of chunk idx-1 is G_idx.
-    if (idx >= 1 && idx <= nchunks) carry[idx - 1] = idx < nchunks ? v : 0;
-    if (tid == 0) s_in = v;
+    // v == G at chunk i0; the value just above this lane's 4 entries is the next lane's G (0 above the top)
+    u64 g = tid < 255 ? buf[tid + 1] : 0;
+    if (tid == 255) g = 0;   // incoming is already folded into h[3]
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+      g = ops.add(h[k], ops.mul(Z, g));                     // G at chunk i0 + k
+      const size_t idx = i0 + k;
+      if (idx >= 1 && idx <= nchunks) carry[idx - 1] = idx < nchunks ? g : 0;
+    }
+    if (tid == 0) s_in = g;                                  // == v: G at the first chunk of the segment
     __syncthreads();
     incoming = s_in;
     __syncthreads();
