@@ -52,12 +52,13 @@ __global__ void __launch_bounds__(256) chunk_horner_kernel(Ops ops, const u64* _
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * HCHUNK;
   u64 e[16];
+  // loads issued in the order the recurrence consumes them (e[15] first), so it can start on the first arrivals
   if (base + HCHUNK <= d) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) e[r] = c[base + tid + 256 * r];
+    for (int r = 15; r >= 0; r--) e[r] = c[base + tid + 256 * r];
   } else {
 #pragma unroll
-    for (int r = 0; r < 16; r++) { const size_t i = base + tid + 256 * r; e[r] = i < d ? c[i] : 0; }
+    for (int r = 15; r >= 0; r--) { const size_t i = base + tid + 256 * r; e[r] = i < d ? c[i] : 0; }
   }
   // lane t holds k = t + 256 r: Horner in z^256 over r, then the lane's own offset z^t
   u64 acc = e[15];
