@@ -53,6 +53,85 @@ def synth(n, seed):
     return x
 
 
+KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", "ronkathon_amd/csrc/plan.h",
+                  "ronkathon_amd/csrc/tile_kernels.hip")
+VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
+
+
+def kernel_source_hash():
+    """sha256 over the tile-kernel sources: PMC / census files record it, so stale counters are detected"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_if_current(path):
+    """a committed measurement file (profiles/latest_*.json) -- only if it was taken on the current kernel sources"""
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            d = json.load(f)
+    except Exception:  # noqa: BLE001
+        return None, "missing"
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None, "stale (kernel sources changed since %s was taken)" % path
+    return d, None
+
+
+def cpu_baseline_mul(log2n, budget_s=10.0):
+    """(a) the fair comparator: NTT - pointwise - iNTT with the reference's recursive fft/ifft restated
+    in C, one thread; (b) the reference's own schoolbook Mul (polynomial/arithmetic.rs:97-119) timed at small D and
+    EXTRAPOLATED ~ D^2 to the benchmark size (flagged as an extrapolation)."""
+    import oracle as orc
+    P, G = orc.GOLDILOCKS_P, orc.GOLDILOCKS_G
+    n = 1 << log2n
+    a = np.concatenate([synth(n // 2, 7), np.zeros(n // 2, dtype=np.uint64)])
+    b = np.concatenate([synth(n // 2, 8), np.zeros(n // 2, dtype=np.uint64)])
+    t0 = time.perf_counter()
+    fa, fb = orc.fft(P, G, a), orc.fft(P, G, b)
+    prod = orc.ifft(P, G, orc.vec_mul(P, fa, fb))
+    t_ntt = time.perf_counter() - t0
+    del prod
+    sb = []
+    for d in (1 << 11, 1 << 12, 1 << 13):
+        u, v = synth(d, 70 + d), synth(d, 71 + d)
+        t0 = time.perf_counter()
+        orc.poly_mul(P, u, v)
+        sb.append((d, time.perf_counter() - t0))
+        if sum(t for _, t in sb) > budget_s:
+            break
+    d_last, t_last = sb[-1]
+    extrap = t_last * ((n // 2) / d_last) ** 2
+    return {"value": 1.0 / t_ntt, "unit": "op/s", "cores": 1, "kind": "port",
+            "sample": "1 product of two 2^%d-coefficient polynomials by NTT size 2^%d (2 fft + pointwise + ifft, the "
+                      "reference's recursive algorithm restated in C), %.2f s, 1 thread" % (log2n - 1, log2n, t_ntt),
+            "schoolbook_reference_algorithm": {"measured": [{"D": d, "seconds": t} for d, t in sb],
+                                               "extrapolated_seconds_at_benchmark_size": extrap,
+                                               "note": "EXTRAPOLATION ~ D^2 from D = %d (polynomial/arithmetic.rs:97-119 is "
+                                                       "O(D*D2) and never uses the FFT)" % d_last},
+            "host_cores_available": os.cpu_count()}
+
+
+def cpu_baseline_roundtrip(log2n, budget_s=8.0):
+    """forward + inverse (polynomial/mod.rs:295-323, :430-453: same recursion + n^-1 scaling), one thread"""
+    import oracle as orc
+    P, G = orc.GOLDILOCKS_P, orc.GOLDILOCKS_G
+    x = synth(1 << log2n, 98)
+    reps, t = 0, 0.0
+    while t < budget_s and reps < 64:
+        t0 = time.perf_counter()
+        y = orc.fft(P, G, x)
+        z = orc.ifft(P, G, y)
+        t += time.perf_counter() - t0
+        reps += 1
+    assert np.array_equal(z, x)
+    return {"value": reps / t, "unit": "op/s", "cores": 1, "kind": "port",
+            "sample": "%d forward+inverse 2^%d round trips (root lookup included), recursive algorithm of the reference "
+                      "restated in C, 1 thread" % (reps, log2n), "host_cores_available": os.cpu_count()}
+
+
 def cpu_baseline(log2n, budget_s=12.0):
     """oracle (port of the reference's recursive fft, polynomial/mod.rs:295-323) on one host core"""
     import oracle as orc
@@ -110,6 +189,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="polynomials per launch (default: 1, batch16: 1024)")
     ap.add_argument("--streams", type=int, default=2, help="independent transforms in flight (HIP streams)")
+    ap.add_argument("--samples", type=int, default=5, help="timed regions of --steps steps each (median reported)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed plans")
     args = ap.parse_args()
 
     import torch
@@ -196,38 +277,129 @@ def main():
         for i in range(count):
             step(i)
 
+    # ---- verification (outside every timed region; the oracle is the CHECKER here, never the thing measured): every
+    # plan that is timed below transforms one input and is compared with the oracle's restatement of
+    # Polynomial::fft (reference src/polynomial/mod.rs:273-323); the other workloads are checked through the oracle too.
+    def to_np(t):
+        return t.cpu().numpy().view(np.uint64)
+
+    def verify():
+        import oracle as orc
+        checked = []
+        if wl in ("ntt22", "batch16"):
+            xh = to_np(xs[0])
+            rows = sorted({0, batch - 1, batch // 2})
+            refs = {r: orc.fft(P, G, xh[r * n:(r + 1) * n]) for r in rows}
+            seen = []
+            for pl_ in plans + [lat_plan]:
+                if any(pl_ is q for q in seen):
+                    continue
+                seen.append(pl_)
+                ys[0].zero_()
+                pl_.forward_dev(xs[0].data_ptr(), ys[0].data_ptr(), stream)
+                torch.cuda.synchronize()
+                yh = to_np(ys[0])
+                for r in rows:
+                    if not np.array_equal(yh[r * n:(r + 1) * n], refs[r]):
+                        raise SystemExit("bench.py: plan output differs from the oracle (polynomial %d) -- refusing to time it" % r)
+            checked.append("%d timed plan(s) x %d polynomial(s) == oracle.fft" % (len(seen), len(rows)))
+        elif wl == "mul22":
+            step(0); torch.cuda.synchronize()
+            ah, bh, oh = to_np(a), to_np(b), to_np(out)
+            for pt in (3, 0x1234567890ABCDEF % P):
+                if orc.poly_eval(P, oh, pt) != orc.mul(P, orc.poly_eval(P, ah, pt), orc.poly_eval(P, bh, pt)):
+                    raise SystemExit("bench.py: product fails the evaluation homomorphism")
+            if int(oh[0]) != orc.mul(P, int(ah[0]), int(bh[0])) or int(oh[-1]) != orc.mul(P, int(ah[-1]), int(bh[-1])):
+                raise SystemExit("bench.py: product end coefficients differ from the oracle")
+            checked.append("product(z) == a(z) b(z) at 2 points + exact end coefficients (oracle)")
+        elif wl in ("open22", "eval22"):
+            step(0); torch.cuda.synchronize()
+            xh = to_np(x)
+            val = orc.poly_eval(P, xh, zpt)
+            if int(to_np(scal)[0]) != val:
+                raise SystemExit("bench.py: evaluation / remainder differs from the oracle")
+            if wl == "open22":
+                qh = to_np(y)[: n - 1]
+                pt = 0xFEEDFACE12345 % P   # p(pt) == q(pt) (pt - z) + r
+                if orc.poly_eval(P, xh, pt) != orc.add(P, orc.mul(P, orc.poly_eval(P, qh, pt), orc.sub(P, pt, zpt)), val):
+                    raise SystemExit("bench.py: quotient fails p = q (x - z) + r")
+            checked.append("remainder / value == oracle.poly_eval" + ("; p(t) == q(t)(t - z) + r" if wl == "open22" else ""))
+        elif wl == "roundtrip16":
+            plan.forward_dev(x.data_ptr(), y.data_ptr(), stream); torch.cuda.synchronize()
+            if not np.array_equal(to_np(y), orc.fft(P, G, to_np(x))):
+                raise SystemExit("bench.py: forward differs from the oracle")
+            plan.inverse_dev(y.data_ptr(), y.data_ptr(), stream); torch.cuda.synchronize()
+            if not np.array_equal(to_np(y), to_np(x)):
+                raise SystemExit("bench.py: round trip is not the identity")
+            checked.append("forward == oracle.fft, inverse(forward(x)) == x")
+        elif wl == "rs16":
+            step(0); torch.cuda.synchronize()
+            xh, yh = to_np(x), to_np(y)
+            for r in (0, batch - 1):
+                msg = np.concatenate([xh[r * (n // 2):(r + 1) * (n // 2)], np.zeros(n // 2, dtype=np.uint64)])
+                if not np.array_equal(yh[r * n:(r + 1) * n], orc.fft(P, G, msg)):
+                    raise SystemExit("bench.py: codeword %d differs from the oracle" % r)
+            checked.append("2 codewords == oracle.fft(zero-padded message)")
+        elif wl in ("vecmul24", "vecadd24"):
+            step(0); torch.cuda.synchronize()
+            m = 1 << 16
+            f = orc.vec_mul if wl == "vecmul24" else orc.vec_add
+            if not np.array_equal(to_np(y)[:m], f(P, to_np(x)[:m], to_np(x2)[:m])):
+                raise SystemExit("bench.py: element-wise result differs from the oracle")
+            checked.append("first 2^16 elements == oracle")
+        return checked
+
+    verified_what = verify() if not args.no_verify else None
+
+    # ---- timing: W untimed warmup steps, a spin-up of untimed steps until the device has been busy >= 50 ms (clocks),
+    # then SAMPLES regions of exactly K steps each, every one bracketed by barrier + synchronize on both sides and
+    # max-reduced over ranks; `value` / `ms_per_step` come from the MEDIAN region, the minimum is reported beside it.
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     run(args.warmup)
     torch.cuda.synchronize()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.05:
+        run(max(1, args.steps))
+        torch.cuda.synchronize()
+    SAMPLES = max(1, args.samples)
+    dts = []
+    for _ in range(SAMPLES):
+        sync_all()
+        t0 = time.perf_counter()
+        run(args.steps)
+        sync_all()
+        dts.append(time.perf_counter() - t0)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor(dts, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dts = [float(v) for v in tt.tolist()]
+    dt = float(np.median(dts))
+    dt_min = float(min(dts))
 
     value = world * args.steps * batch / dt          # whole-job units per second (polynomials, products, ...)
 
     # Roofline of the dominant kernel: the same K steps again, one at a time on ONE stream with the default plan,
-    # bracketed by HIP events recorded on the launch stream (torch's current stream IS the launch stream here).
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # bracketed by HIP events recorded on the launch stream (torch's current stream IS the launch stream here);
+    # median of SAMPLES regions as above.
     S_saved, S, plan0 = S, 1, plans[0]
     plans[0] = lat_plan
     run(10)
-    ev0.record()
-    run(args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
+    dev_ms_samples = []
+    for _ in range(SAMPLES):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        run(args.steps)
+        ev1.record()
+        torch.cuda.synchronize()
+        dev_ms_samples.append(ev0.elapsed_time(ev1))
     S = S_saved
     plans[0] = plan0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = float(np.median(dev_ms_samples))
 
     # per-kernel device time (hipEvents on the launch stream) for the roofline of the dominant kernel
     pass_ms = None
@@ -236,52 +408,70 @@ def main():
     alg_bytes_step = wl_bytes_per_n * (batch / wl_batch) * n
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
     achieved = alg_bytes_step / step_s / 1e9
-    # HBM bytes per launch from the PMC passes of the same command under rocprofv3 (tools/rocprof_summary.py;
-    # FETCH_SIZE x2 gfx950 correction, calibrated on this kernel's known byte count); bench.py cannot
-    # read PMCs itself, so it reports the committed measurement of the dominant kernel, or null.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "latest_pmc_ntt22.json")) as f:
-            for kname, c in json.load(f)["counters"].items():
-                if "ntt_tile_kernel<11, false>" in kname and "_hbm_bytes_per_launch" in c and wl == "ntt22":
-                    traffic = c["_hbm_bytes_per_launch"]["total"]
-    except Exception:
-        pass
-    traffic_note = None
-    if traffic:
-        traffic_note = ("HBM bytes per kernel launch (rocprofv3 PMC, profiles/latest_pmc_ntt22.json); "
-                        "algorithmic bytes = %d per transform (16*n), i.e. %d per launch of the 2-launch plan; each launch reads and "
-                        "writes the whole vector once, so measured traffic per launch is ~2x the per-launch algorithmic share "
-                        "(inherent to a two-pass transform), with no wasted re-reads" % (16 * n, 8 * n))
-    elif wl != "ntt22":
-        try:   # the other workloads: the dominant (longest) kernel of the committed PMC run of the same command
-            with open(os.path.join(ROOT, "profiles", "latest_pmc_workloads.json")) as f:
-                ks = json.load(f).get(wl, {})
-            if ks and log2n == wl_log2n and batch == wl_batch:
-                kname, kv = max(ks.items(), key=lambda kv_: kv_[1].get("avg_us") or 0.0)
-                traffic = kv["hbm_bytes_per_launch"]
-                traffic_note = ("HBM bytes per launch of %s (rocprofv3 PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
-                                "profiles/r01_rocprof_%s.txt); all kernels of one step move %d bytes against %d algorithmic"
-                                % (kname, wl, sum(v["hbm_bytes_per_launch"] for v in ks.values()) *
-                                   (2 if wl in ("batch16", "rs16") else 1), int(wl_bytes_per_n * n)))
-        except Exception:
-            pass
+    # HBM bytes per launch from the PMC passes of the same command under rocprofv3 (tools/profile.sh ->
+    # tools/rocprof_summary.py; FETCH_SIZE x2 gfx950 correction, calibrated on this kernel's known byte count).
+    # bench.py cannot read PMCs itself: it reports the committed measurement of the dominant kernel IF that file was
+    # taken on the current kernel sources (hash stored in the file), else null.
+    traffic, traffic_note, valu = None, None, None
+    pmc, why = load_if_current("profiles/latest_pmc_%s.json" % wl)
+    if pmc and log2n == wl_log2n and batch == wl_batch:
+        kern = None
+        for kname, c in pmc.get("counters", {}).items():
+            if "_hbm_bytes_per_launch" in c and (kern is None or c.get("_avg_us", 0) > pmc["counters"][kern].get("_avg_us", 0)):
+                kern = kname
+        if kern:
+            c = pmc["counters"][kern]
+            traffic = c["_hbm_bytes_per_launch"]["total"]
+            traffic_note = ("HBM bytes per launch of %s (rocprofv3 PMC: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
+                            "profiles/%s)" % (kern, pmc.get("source", "latest_pmc_%s.json" % wl)))
+            if wl == "ntt22":
+                traffic_note += ("; algorithmic share per launch = %d bytes (8*n: each launch of the two-pass plan reads and "
+                                 "writes the whole vector once, so ~2x is inherent to two passes, anything above is re-reads)" % (8 * n))
+            if "SQ_INSTS_VALU" in c:
+                launches_per_step = plan.num_passes() if wl in ("ntt22", "batch16") else 1
+                valu = {"insts_per_coeff": c["SQ_INSTS_VALU"]["avg"] * 64.0 * launches_per_step / (n * batch),
+                        "source": "SQ_INSTS_VALU x 64 lanes x %d launches / coefficients (PMC, same file)" % launches_per_step}
+    else:
+        traffic_note = "no current PMC file for this workload/kernel (%s): re-run tools/profile.sh" % why
+    # Secondary ceiling: 64-bit modular arithmetic is VALU-issue bound.  Static census of the executed
+    # path (tools/census.py: instructions and issue slots per coefficient, weights from tools/instr_rate.hip).
+    if wl == "ntt22":
+        cen, why_c = load_if_current("profiles/latest_census.json")
+        if cen:
+            valu = valu or {}
+            issue_us = cen["slots_per_coeff"] * n / VALU_PEAK_LANE_OPS * 1e6
+            valu.update({"static_insts_per_coeff": cen["valu_per_coeff"], "issue_slots_per_coeff": cen["slots_per_coeff"],
+                         "issue_bound_us": issue_us, "frac_of_valu_peak": issue_us / (step_s * 1e6),
+                         "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                         "note": "issue_bound_us = issue slots per coefficient x n / measured full-rate VALU throughput "
+                                 "(profiles/r01_instr_rate_gfx950.txt); frac_of_valu_peak = issue_bound_us / device time per "
+                                 "transform: how close the kernel is to its own arithmetic ceiling"})
+        elif valu is None:
+            valu = {"note": "census " + why_c}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_note": traffic_note,
                 "kernel": wl_kernel or "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n,
                                                                                          plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
-                "note": "achieved/frac: one transform at a time on ONE stream, default plan (kernel durations); "
-                        "value: %d streams%s" % (S, ", plans tuned for concurrency (tile_log2_columns=2)" if tile_lc >= 0 else ""),
+                "device_us_per_step_min": min(dev_ms_samples) * 1e3 / args.steps,
+                "note": "achieved/frac: one transform at a time on ONE stream, default plan (kernel durations), median of %d "
+                        "regions of %d steps; value: %d streams%s" % (SAMPLES, args.steps, S, ", plans tuned for concurrency "
+                                                                     "(tile_log2_columns=2)" if tile_lc >= 0 else ""),
                 "throughput_GBs": alg_bytes_step * args.steps / dt / 1e9,
-                "pass_us": [m * 1e3 for m in pass_ms] if pass_ms else None}
+                "pass_us": [m * 1e3 for m in pass_ms] if pass_ms else None,
+                "valu": valu}
 
     if rank == 0:
         res = {"metric": "forward NTTs/s, degree 2^%d, 64-bit Goldilocks prime" % log2n if wl == "ntt22" else wl,
                "value": value, "unit": wl_unit,
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": dt_min / args.steps * 1e3,
+               "samples_ms_per_step": [t / args.steps * 1e3 for t in dts],
+               "timing": "median of %d regions of exactly %d steps after %d warmup steps + >= 50 ms spin-up; each region "
+                         "bracketed by barrier + torch.cuda.synchronize, max over ranks" % (SAMPLES, args.steps, args.warmup),
+               "verified": bool(verified_what), "verified_how": verified_what,
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": "forward NTT, n = 2^%d, batch %d, p = 2^64 - 2^32 + 1, natural order in/out, device resident"
                           % (log2n, batch) if wl in ("ntt22", "batch16") else wl,
@@ -291,6 +481,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline(log2n)
         if not args.no_cpu and world == 1 and wl in ("batch16", "rs16"):
             res["cpu_baseline"] = cpu_baseline_batched(log2n)
+        if not args.no_cpu and world == 1 and wl == "mul22":
+            res["cpu_baseline"] = cpu_baseline_mul(log2n)
+        if not args.no_cpu and world == 1 and wl == "roundtrip16":
+            res["cpu_baseline"] = cpu_baseline_roundtrip(log2n)
         print(json.dumps(res), flush=True)
     for p_ in plans + [lat_plan]:
         p_.close()

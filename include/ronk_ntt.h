@@ -100,6 +100,11 @@ int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, ui
 int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                            int tile_log2_columns, int twiddle_matrix_log2_max);
 int ronk_plan_destroy(ronk_plan* plan);
+/* Which kernel family the plan runs on: 1 = the tiled Goldilocks path (p = 2^64 - 2^32 + 1 with the explicit generator 7,
+ * 2^4 <= n <= 2^30) -- the tuned one; 0 = the generic radix-2 path (any other odd prime, Goldilocks with another
+ * generator, n < 16 or n > 2^30: Montgomery arithmetic, one HBM pass per stage, n <= 2^32 -- a parity vehicle for the
+ * reference's small-field vectors, an order of magnitude slower per coefficient). */
+int ronk_plan_path(const ronk_plan* plan);
 
 /* Polynomial::<Monomial,F,D>::fft() (polynomial/mod.rs:273-323; same values as dft() :240-258).
  * `nodes`, if non-NULL, receives Lagrange::nodes = [omega^i] (mod.rs:358-365), n elements. */

@@ -18,7 +18,8 @@ except Exception:  # noqa: BLE001  (no torch: nothing to order)
     pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libronk_ntt.so")
+# RONK_LIB_PATH: developer A/B runs against another build of the SAME C ABI (e.g. last round's .so on the same box)
+LIB_PATH = os.environ.get("RONK_LIB_PATH") or os.path.join(_HERE, "libronk_ntt.so")
 
 GOLDILOCKS_P = 0xFFFFFFFF00000001
 GOLDILOCKS_G = 7
@@ -66,6 +67,7 @@ _SIG = {
     "ronk_plan_create": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int]),
     "ronk_plan_create_tuned": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int, _int, _int]),
     "ronk_plan_destroy": (_int, [_vp]),
+    "ronk_plan_path": (_int, [_vp]),
     "ronk_ntt_forward": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_ntt_inverse": (_int, [_vp, _vp, _vp]),
     "ronk_ntt_forward_dev": (_int, [_vp, _vp, _vp, _vp]),
@@ -100,6 +102,8 @@ _SIG = {
     "ronk_dev_sync": (_int, []),
 }
 for _name, (_res, _args) in _SIG.items():
+    if os.environ.get("RONK_LIB_PATH") and not hasattr(lib, _name):
+        continue              # an older build in an A/B run may lack the newest entry points
     _f = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
     _f.restype, _f.argtypes = _res, _args
 
@@ -153,6 +157,10 @@ class Plan:
 
     def num_passes(self):
         return lib.ronk_plan_num_passes(self.h)
+
+    def path(self):
+        """1 = tiled Goldilocks kernels, 0 = generic radix-2 path (ronk_plan_path)"""
+        return lib.ronk_plan_path(self.h)
 
     def forward(self, x, nodes=False):
         x = arr(x)

@@ -11,7 +11,8 @@
 // The forms below are chosen by VALU instruction count on gfx950 (tools/instr_rate.hip,
 // tools/isa_loop_count.py): every 64-bit add / compare / select / v_mad_u64_u32 costs the
 // same ~1.6 issue slots, so "value + (cond ? EPS : 0)" (5 VALU per add) beats a 64-bit
-// select between two candidates (6), and a borrow chain beats subtract + compare for sub.
+// select between two candidates (6), and a borrow chain with the +p folded into the limbs (4 VALU) beats
+// subtract + compare for sub; a product is 4 mads + one combined final correction (18 VALU).
 // Plain C++ on uint32/uint64 only, so the same header also builds for the host-side
 // kernel emulator under tests/emu (test infrastructure; never part of the product .so).
 #pragma once
@@ -23,6 +24,13 @@
 #else
 #define RONK_HD inline
 #endif
+#endif
+
+// Experiment switch (tools/ubench only; the product always builds the default): bit 0 = sub() with the +p folded into the
+// limbs (4 VALU + s_xor) instead of mask-and-subtract (5 VALU); bit 1 = mad_eps_canon as the 4-instruction asm block
+// (v_mad_u64_u32 carry-out); bit 2 = sub32 as the asm block.
+#ifndef RONK_GL64_VARIANT
+#define RONK_GL64_VARIANT 7
 #endif
 
 namespace gl64 {
@@ -43,17 +51,76 @@ RONK_HD u64 add(u64 a, u64 b) {
   return s + ((s < a || s >= P) ? EPS : 0);
 }
 
+// h*EPS + t for a 32-bit h and ANY 64-bit t, canonical.  The sum wraps at most once (h*EPS <= 2^64 - 2^33 + 1) and
+// one correction covers both cases: after a wrap r < 2^64 - 2^33 + 1, so r + EPS < p (no second wrap); without a
+// wrap, r >= p gives r + EPS - 2^64 = r - p < 2^32.  On the device this is 4 VALU: v_mad_u64_u32 takes the addend and
+// delivers the wrap as its carry-out (the compiler never uses that output, and splits mad + add when the wrap is
+// tested in C), the correction is a second mad by a 0/1 lane value.  SGPR timing inside the block: the mad's carry is
+// read by SALU (no hazard) and by the v_cndmask two instructions later (the gfx950 VALU-writes-SGPR -> VALU-reads
+// rule wants 2 wait states, which the v_cmp and the s_or supply).
+RONK_HD u64 mad_eps_canon(u32 h, u64 t) {
+#if defined(__HIP_DEVICE_COMPILE__) && (RONK_GL64_VARIANT & 2)
+  u64 r, sc;
+  u32 m;
+  const u64 pm1 = P - 1;
+  asm("v_mad_u64_u32 %0, %2, %3, -1, %4\n\t"
+      "v_cmp_lt_u64_e32 vcc, %5, %0\n\t"
+      "s_or_b64 %2, vcc, %2\n\t"
+      "v_cndmask_b32_e64 %1, 0, 1, %2\n\t"
+      "v_mad_u64_u32 %0, vcc, %1, -1, %0"
+      : "=&v"(r), "=&v"(m), "=&s"(sc)
+      : "v"(h), "v"(t), "s"(pm1)
+      : "vcc", "scc");
+  return r;
+#else
+  u64 r = (u64)h * 0xFFFFFFFFu + t;
+  return r + ((r < t || r >= P) ? EPS : 0);
+#endif
+}
+
+RONK_HD u64 sub(u64 a, u64 b);
+
+// a - h (+ p on borrow) for a 32-bit h: the upper limb only sees the borrow.  (Written out because the compiler turns
+// "hi - 0 - borrow" into v_cndmask + v_sub_co; v_subbrev_co with the borrow as carry-in is one instruction.)
+RONK_HD u64 sub32(u64 a, u32 h) {
+#if defined(__HIP_DEVICE_COMPILE__) && (RONK_GL64_VARIANT & 4)
+  u32 lo, hi;
+  u64 sc;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %4, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32_e64 %0, %2, 0, %0, vcc\n\t"
+      "s_xor_b64 vcc, vcc, %2\n\t"
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(lo), "=&v"(hi), "=&s"(sc)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"(h)
+      : "vcc", "scc");
+  return ((u64)hi << 32) | lo;
+#else
+  return sub(a, (u64)h);
+#endif
+}
+
 // a - b, + p on borrow (prime/arithmetic.rs:19-28).  Also valid for ANY a < 2^64 and b <= p; the
 // result is then some representative in [0, 2^64).
 RONK_HD u64 sub(u64 a, u64 b) {
-#if defined(__clang__)
-  // borrow chain: the borrow of the 64-bit subtract comes out of v_subb_co_u32 for free
+#if defined(__clang__) && !(RONK_GL64_VARIANT & 1)
   u32 b1, b2, b3, b4;
   u32 lo = __builtin_subc((u32)a, (u32)b, 0u, &b1);
   u32 hi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b1, &b2);
   u32 e = 0u - b2;  // 0xFFFFFFFF on borrow: d + p == d - EPS (mod 2^64)
   lo = __builtin_subc(lo, e, 0u, &b3);
   hi = __builtin_subc(hi, 0u, b3, &b4);
+  return ((u64)hi << 32) | lo;
+#elif defined(__clang__)
+  // borrow chain, then d + B*p = d + B - B*2^32 on the limbs: lo + B (carry c2 only if lo == 2^32-1), hi - B + c2
+  // = hi - (B xor c2).  4 VALU (v_sub_co, v_subb_co, v_addc_co, v_subbrev_co) + one s_xor on the carry masks.
+  u32 b1, b2, c2, b4;
+  u32 lo = __builtin_subc((u32)a, (u32)b, 0u, &b1);
+  u32 hi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b1, &b2);
+  lo = __builtin_addc(lo, 0u, b2, &c2);
+  hi = __builtin_subc(hi, 0u, b2 ^ c2, &b4);
   return ((u64)hi << 32) | lo;
 #else
   u64 d = a - b;
@@ -68,10 +135,8 @@ RONK_HD u64 neg(u64 a) { return a ? P - a : 0; }
 //   x = lo - hh + hl*(2^32-1)   (mod p)
 RONK_HD u64 reduce128(u64 lo, u64 hi) {
   u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-  u64 t0 = sub(lo, (u64)hh);                  // any representative; borrow -> + p
-  u64 r = (u64)hl * 0xFFFFFFFFu + t0;         // one v_mad_u64_u32; hl*EPS < p, so at most one wrap
-  r += (r < t0) ? EPS : 0;                    // 2^64 = EPS; cannot wrap twice
-  return canon(r);
+  u64 t0 = sub32(lo, hh);                     // any representative; borrow -> + p
+  return mad_eps_canon(hl, t0);
 }
 
 // prime/arithmetic.rs:34-38.  Schoolbook on 32-bit limbs; each line is one v_mad_u64_u32.
@@ -112,29 +177,23 @@ RONK_HD u64 mul_2exp(u64 x) {
   static_assert(K >= 0 && K < 96, "shift out of range");
   if (K == 0) return x;
   constexpr int q = K / 32, s = K % 32;
-  u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-  u32 y0, y1, y2;
-  if constexpr (s == 0) {
-    y0 = x0; y1 = x1; y2 = 0;
-  } else {
-    // 96-bit shift on 32-bit limbs: shift, funnel shift (v_alignbit_b32), shift -- 3 instructions
-    y0 = x0 << s;
-    y1 = (x1 << s) | (x0 >> (32 - s));
-    y2 = x1 >> (32 - s);
-  }
+  // x << s as limbs (y2, y1, y0): n = (y1:y0) is one 64-bit shift, m = (y2:y1) the complementary one
   if constexpr (q == 0) {
-    u64 n = ((u64)y1 << 32) | y0;            // may be >= p
-    u64 r = (u64)y2 * 0xFFFFFFFFu + n;       // y2*EPS + n: one mad, at most one wrap
-    r += (r < n) ? EPS : 0;
-    return canon(r);
+    u64 n = x << s;                                           // may be >= p
+    u32 y2 = (u32)(x >> 32) >> ((32 - s) & 31);               // s >= 1 here (K == 0 returned above)
+    return mad_eps_canon(y2, n);                              // + y2*EPS
   } else if constexpr (q == 1) {
-    u64 n = (u64)y0 << 32;                   // < p
-    u64 t = ((u64)y1 << 32) - y1;            // y1*EPS < p
-    return sub(add(n, t), (u64)y2);
+    u32 y0 = (u32)x << s;
+    u32 y1 = s ? (u32)(x >> (32 - s)) : (u32)(x >> 32);
+    u32 y2 = s ? (u32)(x >> 32) >> (32 - s) : 0u;
+    u64 n = (u64)y0 << 32;                                    // y0*phi
+    u64 r = mad_eps_canon(y1, n);                             // + y1*EPS, canonical
+    return s ? sub32(r, y2) : r;
   } else {
-    u64 t = (u64)y0 * 0xFFFFFFFFu;           // y0*EPS < p
-    u64 m = ((u64)y2 << 32) | y1;            // y2 < 2^31 -> < p
-    return sub(t, m);                        // canonical: t, m < p
+    u32 y0 = (u32)x << s;
+    u64 t = (u64)y0 * 0xFFFFFFFFu;                            // y0*EPS < p
+    u64 m = s ? x >> (32 - s) : x >> 32;                      // (y2:y1) < 2^63 < p
+    return sub(t, m);                                         // canonical: t, m < p
   }
 }
 

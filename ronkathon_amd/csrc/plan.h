@@ -311,6 +311,8 @@ inline bool dist_shape(int log2n, int world, DistShape* s) {
   s->log2n = log2n; s->logC = log2n / 2; s->logR = log2n - s->logC; s->logW = lw;
   s->n = (u64)1 << log2n; s->R = (u64)1 << s->logR; s->C = (u64)1 << s->logC; s->W = (u64)world;
   if (s->logC < lw + 4 || s->logR > 24 || s->logC > 24) return false;  // >= 16 columns and rows per rank
+  // two-pass phase 2 (logC > 12) splits the received row index at logC - logW - kb bits, kb = floor(logC/2)
+  if (s->logC > 12 && s->logC - lw < s->logC / 2) return false;
   s->Rw = s->R / s->W; s->Cw = s->C / s->W;
   return true;
 }

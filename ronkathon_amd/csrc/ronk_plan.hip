@@ -25,6 +25,8 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
   return ronk_plan_create_tuned(out, p, g, log2n, batch, device, -1, -1);
 }
 
+extern "C" int ronk_plan_path(const ronk_plan* pl) { return pl ? (pl->fast ? 1 : 0) : RONK_ERR_INVALID; }
+
 extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                                       int tile_log2_columns, int twiddle_matrix_log2_max) {
   if (!out || batch == 0 || log2n > 36) return RONK_ERR_INVALID;
@@ -44,6 +46,8 @@ extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, u
   // grids below 2^31 workgroups); anything else takes the generic radix-2 path
   pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4 && log2n <= 30 &&
               batch < ((u64)1 << 31) && (double)batch * (double)n / 2048.0 < 2.0e9);
+  // generic radix-2 path: 32-bit bit reversal and element indices (field_kernels.h bitrev32)
+  if (!pl->fast && log2n > 32) { delete pl; return RONK_ERR_UNSUPPORTED; }
   if (pl->fast) {
     // columns per tile = 2^max_logc at most (4 = 128-byte segments, 1 workgroup per CU at 2^11 rows; 2 = 32-byte
     // segments but two workgroups per CU, better when several transforms are in flight); RONK_MAX_LOGC overrides

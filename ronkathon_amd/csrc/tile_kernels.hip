@@ -23,12 +23,18 @@ __global__ void __launch_bounds__(1024) ntt_tile_kernel(const TileArgs a) {
 
 template <int LOGR, bool INV>
 static hipError_t launch_one(const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s) {
-  static bool attr_done = false;  // benign race: the attribute call is idempotent
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_tile_kernel<LOGR, INV>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // HIP keeps this attribute per (kernel, DEVICE): one flag per device ordinal (benign race: the call is idempotent)
+  static bool attr_done[64] = {};
+  if (lds > 48 * 1024) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      e = hipFuncSetAttribute((const void*)ntt_tile_kernel<LOGR, INV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
   }
   hipLaunchKernelGGL((ntt_tile_kernel<LOGR, INV>), dim3(grid), dim3(block), lds, s, a);
   return hipGetLastError();

@@ -28,7 +28,12 @@ class Lagrange:
 
 def _coeffs(field, c):
     if isinstance(c, np.ndarray) and c.dtype == np.uint64:
-        return np.ascontiguousarray(c)
+        c = np.ascontiguousarray(c)
+        # the kernels assume canonical residues (include/ronk_ntt.h); PrimeField::new reduces with `% P`
+        # (prime/mod.rs:48-51), so do the same for raw 64-bit values instead of returning wrong sums
+        if c.size and int(c.max()) >= field.ORDER:
+            c = c % np.uint64(field.ORDER)
+        return c
     return L.arr([int(x) % field.ORDER for x in c])
 
 

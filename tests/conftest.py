@@ -19,11 +19,33 @@ def pytest_sessionstart(session):
     """A fresh checkout has no built artefacts (they are git-ignored): build the product library (hipcc cross-compiles
     gfx950 without a GPU) and the oracle once, exactly as __graft_entry__.build() does.  On the GPU box the
     prebuilt files travel with the snapshot and nothing is rebuilt."""
-    need = [os.path.join(ROOT, "ronkathon_amd", "libronk_ntt.so"), os.path.join(ROOT, "oracle", "libronk_oracle.so")]
-    if all(os.path.exists(f) for f in need):
-        return
+    import shutil
     import subprocess
-    subprocess.check_call(["make", "-C", ROOT, "-j8"])
+    need = [os.path.join(ROOT, "ronkathon_amd", "libronk_ntt.so"), os.path.join(ROOT, "oracle", "libronk_oracle.so")]
+    on_gpu_box = os.path.exists("/dev/kfd") and all(os.path.exists(f) for f in need)   # snapshot ships the built files
+    if on_gpu_box or os.environ.get("RONK_NO_REBUILD") == "1":
+        return
+    if shutil.which("hipcc") and shutil.which("make"):
+        # incremental: a no-op when nothing changed, and never a stale binary after an edit under csrc/
+        subprocess.check_call(["make", "-C", ROOT, "-j8", "-s"])
+    elif not all(os.path.exists(f) for f in need):
+        raise RuntimeError("built libraries missing and no hipcc/make to build them")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu`-marked tests skip (instead of erroring) when no HIP device is visible, e.g. a plain `pytest` in the CPU-only
+    container; on the GPU box nothing is skipped."""
+    try:
+        import ronkathon_amd
+        have = ronkathon_amd.device_count() >= 1
+    except Exception:  # noqa: BLE001
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (MI355X)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

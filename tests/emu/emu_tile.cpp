@@ -6,7 +6,8 @@
 // in the CPU-only container.  It is built and run by tests/test_emu_kernel.py only; the
 // product library never contains or calls it.
 //
-// usage: emu_tile <log2n> <batch> <inverse 0|1> <max_logc>   (prints OK or the first mismatch)
+// usage: emu_tile <log2n> <batch> <inverse 0|1> <max_logc> [twf_max_log] [three_pass_from] [in_valid] [out_valid] [auto_tiles]
+//        (prints OK or the first mismatch)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -152,8 +153,9 @@ int main(int argc, char** argv) {
   u64 n = (u64)1 << log2n;
   int twf = argc > 5 ? atoi(argv[5]) : 0;
   int three_from = argc > 6 ? atoi(argv[6]) : 25;
-  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from);
   u64 in_valid = argc > 7 ? strtoull(argv[7], 0, 10) : 0, out_valid = argc > 8 ? strtoull(argv[8], 0, 10) : 0;
+  bool auto_tiles = argc > 9 && atoi(argv[9]) != 0;   // the planner's own per-pass tile rules (ronk_plan_create's default)
+  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
   u64 s = 0x5EED0000ull + log2n;

@@ -42,6 +42,25 @@ def test_two_pass(emu, k, batch, inv, logc):
     run(emu, k, batch, inv, logc)
 
 
+@pytest.mark.parametrize("k", [20, 21, 22, 23])
+@pytest.mark.parametrize("logc", [0, 1, 2, 3])
+def test_tuned_tile_widths(emu, k, logc):
+    """ronk_plan_create_tuned(tile_log2_columns = c): bench.py times c = 2 plans on two streams; 2^23 is a three-pass plan"""
+    run(emu, k, 1, (k + logc) & 1, logc, 0, 23)
+
+
+@pytest.mark.parametrize("k,batch", [(19, 32), (20, 16), (22, 4)])
+def test_planner_many_tiles_branch(emu, k, batch):
+    """build_plan(auto_tiles): >= 4 large tiles per CU -> 8192-coefficient tiles for the 2^10 / 2^11-row passes (the
+    library default for big batches)"""
+    run(emu, k, batch, 0, 4, 0, 23, 0, 0, 1)
+
+
+def test_three_pass_batched(emu):
+    run(emu, 23, 3, 0, 4, 0, 23)
+    run(emu, 23, 2, 1, 3, 0, 23)
+
+
 @pytest.mark.parametrize("k,batch,inv", [(13, 2, 0), (16, 2, 1), (18, 1, 0)])
 def test_two_pass_full_twiddle_matrix(emu, k, batch, inv):
     """plans whose inter-pass twiddle is the full matrix laid out like the output tile (plan.h maybe_full_table)"""

@@ -185,6 +185,68 @@ def test_batched_ragged_vs_oracle(R, orc, k, batch):
     plan.close()
 
 
+# ---------------------------------------------------------------- plan variants: what bench.py times and what the planner picks
+@pytest.mark.parametrize("k", [20, 21, 22, 23])
+def test_tuned_tile_widths_vs_oracle(R, orc, k):
+    """ronk_plan_create_tuned(tile_log2_columns = c), c = 0..3 (bench.py's throughput line runs c = 2 plans on two
+    streams), plus the default plan: forward AND inverse against the oracle's fft / ifft (reference
+    src/polynomial/mod.rs:273-323, :430-484); adversarial vectors at 2^22."""
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    x = splitmix_field(0x5EED0200 + k, n)
+    cases = [x] + (adversarial(n) if k == 22 else [])
+    refs = [(c, orc.fft(GP, GG, c), orc.ifft(GP, GG, c)) for c in cases]
+    for c in (-1, 0, 1, 2, 3):
+        plan = L.Plan(GP, GG, k, tile_log2_columns=c)
+        for xin, yf, yi in refs:
+            assert np.array_equal(plan.forward(xin), yf), ("forward", k, c)
+            assert np.array_equal(plan.inverse(xin), yi), ("inverse", k, c)
+        plan.close()
+
+
+@pytest.mark.parametrize("k,batch", [(19, 32), (20, 16), (22, 4), (23, 3)])
+def test_planner_default_for_big_batches_vs_oracle(R, orc, k, batch):
+    """the planner's many_tiles branch (batch*n >= 2^24 with 2^10 / 2^11-row passes -> 8192-coefficient tiles) and a
+    batched three-pass plan: every polynomial against the oracle, forward and inverse"""
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    x = splitmix_field(0x5EED0300 + k, n * batch)
+    plan = L.Plan(GP, GG, k, batch)
+    y = plan.forward(x)
+    z = plan.inverse(x)
+    for b in range(batch):
+        assert np.array_equal(y[b * n:(b + 1) * n], orc.fft(GP, GG, x[b * n:(b + 1) * n])), ("forward", k, b)
+        if b in (0, batch - 1):
+            assert np.array_equal(z[b * n:(b + 1) * n], orc.ifft(GP, GG, x[b * n:(b + 1) * n])), ("inverse", k, b)
+    assert np.array_equal(plan.inverse(y), x)
+    plan.close()
+
+
+def test_field_mul_carry_paths_on_gpu(R, orc):
+    """gl64::mul / mul_2exp use v_mad_u64_u32's carry-out and hand-written borrow chains (csrc/gl64.h): products of
+    edge values that hit every wrap/borrow branch, through the element-wise C ABI, against the oracle."""
+    F = R.GoldilocksField
+    e = np.array([0, 1, 2, 0xFFFFFFFF, 0x100000000, 0x100000001, 0xFFFFFFFE00000001, 0xFFFFFFFEFFFFFFFF,
+                  0xFFFFFFFF00000000, GP - 1, GP - 2, GP - 0xFFFFFFFF, GP - 0x100000000, GP // 2, GP // 2 + 1,
+                  0x0000FFFF00000001, 0xFFFF0000FFFF0000, 0x00000001FFFFFFFF, 0xFFFFFFFDFFFFFFFF, 0x8000000000000000,
+                  0x7FFFFFFFFFFFFFFF, 0xFFFFFFFE00000000], dtype=np.uint64)
+    rnd = splitmix_field(0xC0FFEE, 4096 - e.size)
+    v = np.concatenate([e, rnd])
+    a = np.repeat(v[:64], 64); b = np.tile(v[:64], 64)
+    a = np.concatenate([a, v]); b = np.concatenate([b, v[::-1]])
+    want_mul = np.array([orc.mul(GP, int(p), int(q)) for p, q in zip(a, b)], dtype=np.uint64)
+    want_add = np.array([orc.add(GP, int(p), int(q)) for p, q in zip(a, b)], dtype=np.uint64)
+    want_sub = np.array([orc.sub(GP, int(p), int(q)) for p, q in zip(a, b)], dtype=np.uint64)
+    assert np.array_equal(F.vec_mul(a, b), want_mul)
+    assert np.array_equal(F.vec_add(a, b), want_add)
+    assert np.array_equal(F.vec_sub(a, b), want_sub)
+    # a 16-point transform of edge values exercises every shift twiddle (mul_2exp<K>) on the same inputs
+    from ronkathon_amd import _lib as L
+    plan = L.Plan(GP, GG, 4, batch=v.size // 16)
+    assert np.array_equal(plan.forward(v), np.concatenate([orc.fft(GP, GG, v[i:i + 16]) for i in range(0, v.size, 16)]))
+    plan.close()
+
+
 def test_config2_roundtrip_2_16(R, orc):
     """BASELINE configs[1]: forward+inverse NTT, degree 2^16, bit-exact round trip"""
     from ronkathon_amd import _lib as L

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs into a small text/JSON report.
 
-usage: rocprof_summary.py <dir with trace/ fetch/ write/ sq/ sub-runs> <out prefix>
+usage: rocprof_summary.py <dir with trace/ fetch/ write/ sq/ sub-runs> <out prefix> [source label]
+The JSON records the sha256 of the tile-kernel sources (bench.kernel_source_hash): bench.py refuses counters taken on
+other sources.
   trace/  rocprofv3 --kernel-trace --stats      -> per-kernel calls / average duration
   fetch/  rocprofv3 --pmc FETCH_SIZE             (own pass: TCC slot budget, MI355X_MICROARCH.md)
   write/  rocprofv3 --pmc WRITE_SIZE             (own pass)
@@ -24,7 +26,10 @@ def db_of(d):
 
 def main():
     root, out = sys.argv[1], sys.argv[2]
-    rep = {"kernels": [], "counters": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rep = {"kernel_source_hash": bench.kernel_source_hash(), "source": sys.argv[3] if len(sys.argv) > 3 else os.path.basename(out) + ".txt",
+           "kernels": [], "counters": {}}
     db = db_of(os.path.join(root, "trace"))
     if db:
         for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
@@ -37,7 +42,10 @@ def main():
              "group by kernel_name, counter_name")
         for k, c, n, a, lo, hi in db.execute(q):
             rep["counters"].setdefault(k, {})[c] = {"launches": n, "avg": a, "min": lo, "max": hi}
+    avg_us = {k["name"]: k["avg_us"] for k in rep["kernels"]}
     for k, c in rep["counters"].items():
+        if k in avg_us:
+            c["_avg_us"] = avg_us[k]
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             rd = c["FETCH_SIZE"]["avg"] * 1024 * 2
             wr = c["WRITE_SIZE"]["avg"] * 1024
@@ -52,6 +60,8 @@ def main():
         for k, c in rep["counters"].items():
             f.write("%s\n" % k)
             for name, v in sorted(c.items()):
+                if name == "_avg_us":
+                    continue
                 if name.startswith("_"):
                     f.write("    HBM bytes/launch: read %.0f (FETCH_SIZE KB x1024 x2 gfx950 correction) + write %.0f = %.0f\n"
                             % (v["read_corrected_x2"], v["write"], v["total"]))

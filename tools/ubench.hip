@@ -169,8 +169,29 @@ static void two_pass_ablation(int log2n, u64 batch, int max_logc, u64** keep_in,
   *keep_in = d_in; *keep_out = d_out;
 }
 
+// per-wave issue rate: the math-only body (ABL = 56) with 1 / 2 / 4 waves per SIMD -- one workgroup per CU (LDS request
+// forced to 136 KiB), 256 workgroups; every lane does the same work, so time ~ waves/SIMD when the VALU is saturated and
+// constant when a wave is latency-bound.
+template <int ABL>
+static void occupancy_sweep(const char* what) {
+  PlanDesc pd = build_plan(22, 1, false, 3, 18);
+  u64* d; CK(hipMalloc(&d, (size_t)8 << 22)); CK(hipMemset(d, 1, (size_t)8 << 22));
+  CK(hipFuncSetAttribute((const void*)abl_kernel<11, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int pass = 0; pass < 2; pass++)
+    for (int logc = 1; logc <= 3; logc++) {
+      TileArgs a = pd.passes[pass].args;
+      a.in = d; a.out = d; a.wr = d; a.tw_lo = d; a.tw_hi = d;
+      a.logc = (u32)logc; a.tiles = 256;
+      const u32 block = (2048u << logc) / 16;
+      float us = time_launch([&] { hipLaunchKernelGGL((abl_kernel<11, false, ABL>), dim3(256), dim3(block), 139264, 0, a); }, 20);
+      printf("  %s pass %d: %d wave(s)/SIMD (block %4u)  %8.2f us  -> %.2f us per wave/SIMD\n", what, pass, (int)block / 256, block, us, us / (block / 256));
+    }
+  CK(hipFree(d));
+}
+
 int main(int argc, char** argv) {
   int max_logc = argc > 1 ? atoi(argv[1]) : 4;
+  if (argc == 2 && atoi(argv[1]) == -1) { occupancy_sweep<56>("math only"); occupancy_sweep<120>("math only, no table loads"); return 0; }
   if (argc == 3) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
     const int k = atoi(argv[2]);
     if (k == 4) single_pass_ablation<4>(1048576, max_logc);
