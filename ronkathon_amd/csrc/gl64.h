@@ -80,6 +80,13 @@ RONK_HD u64 mad_eps_canon(u32 h, u64 t) {
 
 RONK_HD u64 sub(u64 a, u64 b);
 
+// a + b for canonical a, b when the consumer is a multiplication (mul / mul_2exp accept any 64-bit representative):
+// only the wrap is folded back (2^64 = EPS), the ">= p" test of add() is skipped.  Result in [0, 2^64), == a + b (mod p).
+RONK_HD u64 add_lazy(u64 a, u64 b) {
+  u64 s = a + b;
+  return s + ((s < a) ? EPS : 0);   // after a wrap s <= p - 2, so + EPS cannot wrap again
+}
+
 // a - h (+ p on borrow) for a 32-bit h: the upper limb only sees the borrow.  (Written out because the compiler turns
 // "hi - 0 - borrow" into v_cndmask + v_sub_co; v_subbrev_co with the borrow as carry-in is one instruction.)
 RONK_HD u64 sub32(u64 a, u32 h) {
@@ -177,22 +184,27 @@ RONK_HD u64 mul_2exp(u64 x) {
   static_assert(K >= 0 && K < 96, "shift out of range");
   if (K == 0) return x;
   constexpr int q = K / 32, s = K % 32;
-  // x << s as limbs (y2, y1, y0): n = (y1:y0) is one 64-bit shift, m = (y2:y1) the complementary one
-  if constexpr (q == 0) {
-    u64 n = x << s;                                           // may be >= p
-    u32 y2 = (u32)(x >> 32) >> ((32 - s) & 31);               // s >= 1 here (K == 0 returned above)
-    return mad_eps_canon(y2, n);                              // + y2*EPS
-  } else if constexpr (q == 1) {
-    u32 y0 = (u32)x << s;
-    u32 y1 = s ? (u32)(x >> (32 - s)) : (u32)(x >> 32);
-    u32 y2 = s ? (u32)(x >> 32) >> (32 - s) : 0u;
-    u64 n = (u64)y0 << 32;                                    // y0*phi
-    u64 r = mad_eps_canon(y1, n);                             // + y1*EPS, canonical
-    return s ? sub32(r, y2) : r;
+  // x << s as limbs (y2, y1, y0) on 32-bit registers (shift, funnel shift v_alignbit_b32, shift): the halves of x
+  // usually sit in unrelated registers (they come out of a borrow chain), where a 64-bit shift would need extra moves
+  const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+  u32 y0, y1, y2;
+  if constexpr (s == 0) {
+    y0 = x0; y1 = x1; y2 = 0;
   } else {
-    u32 y0 = (u32)x << s;
-    u64 t = (u64)y0 * 0xFFFFFFFFu;                            // y0*EPS < p
-    u64 m = s ? x >> (32 - s) : x >> 32;                      // (y2:y1) < 2^63 < p
+    y0 = x0 << s;
+    y1 = (x1 << s) | (x0 >> ((32 - s) & 31));
+    y2 = x1 >> ((32 - s) & 31);
+  }
+  if constexpr (q == 0) {
+    const u64 n = ((u64)y1 << 32) | y0;                       // may be >= p
+    return mad_eps_canon(y2, n);                              // + y2*EPS (phi^2 = phi - 1)
+  } else if constexpr (q == 1) {
+    const u64 n = (u64)y0 << 32;                              // y0*phi
+    const u64 r = mad_eps_canon(y1, n);                       // + y1*EPS, canonical
+    return s ? sub32(r, y2) : r;                              // - y2 (phi^3 = -1)
+  } else {
+    const u64 t = (u64)y0 * 0xFFFFFFFFu;                      // y0*EPS < p
+    const u64 m = ((u64)y2 << 32) | y1;                       // y2 < 2^31 -> < p
     return sub(t, m);                                         // canonical: t, m < p
   }
 }

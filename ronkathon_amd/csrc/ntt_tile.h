@@ -103,29 +103,39 @@ RONK_HD u64 sub_mul_root(u64 a, u64 b) {
   }
 }
 
-// one DIF stage on x[0..N): (a, b) -> (a + b, (a - b) * omega_N^j), j = J..N/2-1
-template <int N, bool INV, int J>
-RONK_HD void dif_stage(u64* x) {
+// one DIF stage on x[0..N): (a, b) -> (a + b, (a - b) * omega_N^j), j = J..N/2-1.
+// LAZY (last stage, N == 2, when every output but x[0] is multiplied next): the sums skip the canonicalising compare
+// (gl64::add_lazy); `keep0` says whether this pair contains element 0 of the whole sub-transform, which is stored /
+// parked without a multiplication and must stay canonical.
+template <int N, bool INV, int J, bool LAZY = false>
+RONK_HD void dif_stage(u64* x, bool keep0 = true) {
   if constexpr (J < N / 2) {
     u64 a = x[J], b = x[J + N / 2];
-    x[J] = gl64::add(a, b);
+    if constexpr (LAZY) x[J] = keep0 ? gl64::add(a, b) : gl64::add_lazy(a, b);
+    else x[J] = gl64::add(a, b);
     x[J + N / 2] = sub_mul_root<N, J, INV>(a, b);
-    dif_stage<N, INV, J + 1>(x);
+    dif_stage<N, INV, J + 1, LAZY>(x, keep0);
   }
 }
 
-// N-point DIF DFT in registers; x[t] ends up holding X[brev(t)]
-template <int N, bool INV>
+// N-point DIF DFT in registers; x[t] ends up holding X[brev(t)].
+// LAZY: outputs other than X[0] may be non-canonical representatives (see dif_stage); `first` = this sub-block starts at
+// element 0 of the whole transform.
+template <int N, bool INV, bool LAZY = false>
 struct Dif {
-  static RONK_HD void run(u64* x) {
-    dif_stage<N, INV, 0>(x);
-    Dif<N / 2, INV>::run(x);
-    Dif<N / 2, INV>::run(x + N / 2);
+  static RONK_HD void run(u64* x, bool first = true) {
+    if constexpr (N == 2) {
+      dif_stage<2, INV, 0, LAZY>(x, first);
+    } else {
+      dif_stage<N, INV, 0>(x);
+      Dif<N / 2, INV, LAZY>::run(x, first);
+      Dif<N / 2, INV, LAZY>::run(x + N / 2, false);
+    }
   }
 };
-template <bool INV>
-struct Dif<1, INV> {
-  static RONK_HD void run(u64*) {}
+template <bool INV, bool LAZY>
+struct Dif<1, INV, LAZY> {
+  static RONK_HD void run(u64*, bool = true) {}
 };
 
 // LDS row of tile row `row`: one dummy row after every 16 (see the header comment)
@@ -135,6 +145,10 @@ RONK_HD u32 swz_row(u32 row) { return row + (row >> 4); }
 // `global_load ... v_off, s[base:base+1]` form (one VALU shift) instead of a 64-bit per-lane address
 RONK_HD u64 ld_tab(const u64* table, u32 idx) {
   return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(table) + (u32)(idx << 3));
+}
+// the same with the BYTE offset given
+RONK_HD u64 ld_tabb(const u64* table, u32 byte_off) {
+  return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(table) + byte_off);
 }
 
 // Global store of one coefficient.  RONK_STORE_MODE: 0 plain (line stays dirty in the XCD's L2 and is written
@@ -152,20 +166,90 @@ RONK_HD void st_out(u64* p, u64 v) {
 #endif
 }
 
+// ---- compile-time knowledge about a pass -------------------------------------------------
+//
+// The generic body reads every stride and flag from TileArgs.  The passes of the two-pass plans (2^13 .. 2^24, the
+// headline 2^22 and the batched 2^16 among them) always have the same shape, so the launcher (tile_kernels.hip) picks
+// an instantiation that KNOWS it -- the compiler then folds the strides into immediates / SGPR constants and drops the
+// unused variants.  tile_cfg_matches() (below) is the host-side check; anything else runs the generic instantiation.
+//   KIND 0  generic
+//   KIND 1  "column pass" (first pass of a two-pass plan): flat rows, unit column stride on both sides, two-level
+//           inter-pass twiddle omega_N^{col * k}, no scale / second operand / limits, full tiles only
+//   KIND 2  "row pass" (second pass): rows blocked by the tiled scratch layout, unit row / output-column strides, no
+//           twiddle, no scale, full tiles only
+//   KIND 3  column pass whose inter-pass twiddle is the full matrix [k][col] (plan.h maybe_full_table; it stays
+//           L2-resident up to 2^18 entries: the batched 2^16 shape)
+// KIND != 0 also means NARROW addressing: every lane offset fits 32 bits IN BYTES (n*8 < 2^32), so global accesses
+// are the `global_load v, v_off, s[base:base+1]` form with offsets built from 32-bit adds.
+// LOGC >= 0 fixes the tile width (LDS addresses become immediates); -1 = run-time.
+template <int LOGC_, int KIND_>
+struct TileCfg {
+  static constexpr int LOGC = LOGC_;
+  static constexpr int KIND = KIND_;
+};
+
+inline bool tile_cfg_matches(const TileArgs& a, int logr, int logc, int kind) {
+  const u64 C = (u64)1 << a.logc, R = (u64)1 << logr;
+  if (logc >= 0 && a.logc != (u32)logc) return false;
+  if (kind == 0) return true;
+  const bool common = !a.stage_io && !a.in2 && a.in_valid == ~(u64)0 && a.out_valid == ~(u64)0 && a.scale == 1 &&
+                      a.nb2 == 1 && a.ncols % C == 0 && a.tiles == a.ncols / C;
+  if (!common) return false;
+  // largest lane offset (elements) on either side must stay below 2^29
+  const u64 span = R * a.ncols;
+  if (span >= ((u64)1 << 29)) return false;
+  const bool colpass = a.js_log == 31 && a.in_sc == 1 && a.out_sc == 1 && a.tw_log > 0 && a.tw_log <= 29 && a.xc == 1 &&
+                       a.yk == 1 && !a.xb1 && !a.xb2 && !a.x0 && !a.yb1 && !a.yb2 && !a.y0 && a.in_sj > 0 && a.out_sk > 0;
+  if (kind == 1) return colpass && !a.tw_full;
+  if (kind == 3) return colpass && a.tw_full && a.tf_sc == 1 && a.tf_sb2 == 0 && a.tf_sk == a.ncols;
+  if (kind == 2)
+    return !a.tw_full && a.js_log < 31 && (R / 16) >= ((u64)1 << a.js_log) && a.in_sj == 1 && a.out_sc == 1 &&
+           a.tw_log == 0 && a.in_sc > 0 && a.out_sk > 0;
+  return false;
+}
+
+// global access at a 32-bit offset: bytes (NARROW) or elements
+template <bool NARROW>
+RONK_HD u64 ld_g(const u64* base, u32 off) {
+  if constexpr (NARROW) return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(base) + off);
+  else return base[off];
+}
+template <bool NARROW>
+RONK_HD void st_g(u64* base, u32 off, u64 v) {
+  if constexpr (NARROW) st_out(reinterpret_cast<u64*>(reinterpret_cast<char*>(base) + off), v);
+  else st_out(base + off, v);
+}
+
 // ---- the tile body --------------------------------------------------------------------
 //
 // LOGR = 4*(Q-1) + LOGLAST, Q rounds; radices 16,..,16,2^LOGLAST.
 // ABL: ablation mask for tools/ubench only (wrong results by design; 0 in the product):
 //   1 no inter-pass twiddle   2 no round twiddles   4 no butterflies   8 no LDS exchange
 //   16 no global loads        32 no global stores        64 twiddle values without table loads
-template <int LOGR, bool INV, int ABL = 0, class Barrier>
-RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
   constexpr int R = 1 << LOGR;
   constexpr int Q = (LOGR + 3) / 4;              // rounds
   constexpr int LOGLAST = LOGR - 4 * (Q - 1);    // 1..4
   constexpr int RLAST = 1 << LOGLAST;
   constexpr int M = R / 16;                      // threads per column
+  constexpr int KIND = CFG::KIND;
+  constexpr bool NARROW = KIND != 0;
+  constexpr int SH = NARROW ? 3 : 0;             // lane offsets in bytes (NARROW) or elements
   static_assert(LOGR >= 4 && LOGR <= 12, "pass size");
+
+  TileArgs a = a_in;                             // what the instantiation knows replaces what the launch says
+  if constexpr (CFG::LOGC >= 0) a.logc = CFG::LOGC;
+  if constexpr (KIND != 0) {
+    a.stage_io = 0; a.in2 = nullptr; a.in_valid = a.out_valid = ~(u64)0; a.scale = 1;
+    if constexpr (KIND != 3) a.tw_full = nullptr;
+    a.nb2 = 1; a.in_sb2 = a.out_sb2 = 0; a.out_sc = 1;
+    a.xb1 = a.xb2 = a.x0 = a.yb1 = a.yb2 = a.y0 = 0;
+    a.ncols = (u64)a.tiles << a.logc;
+  }
+  if constexpr (KIND == 1 || KIND == 3) { a.js_log = 31; a.in_sc = 1; a.xc = 1; a.yk = 1; }
+  if constexpr (KIND == 3) { a.tf_sc = 1; a.tf_sb2 = 0; a.tf_sk = (u32)a.ncols; }
+  if constexpr (KIND == 2) { a.in_sj = 1; a.tw_log = 0; }
 
   const u32 logc = a.logc;
   const u32 C = 1u << logc;
@@ -173,7 +257,7 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   const u32 m = tid >> logc;  // [0, M)
 
   // block -> (tile, b1, b2).  Everything that depends only on the block is wave-uniform (SGPRs);
-  // per-lane addressing is a 32-bit element offset from that base (a sub-problem has < 2^32 elements).
+  // per-lane addressing is a 32-bit offset from that base (a sub-problem has < 2^32 elements; NARROW: bytes).
   const u32 t = bid % a.tiles;
   const u32 bb = bid / a.tiles;
   const u32 b1 = bb % a.nb1, b2 = bb / a.nb1;
@@ -181,21 +265,29 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   const u32 col = col0 + c;
   const u64* in = a.in + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st;
   u64* out = a.out + (i64)b1 * a.out_sb1 + (i64)b2 * a.out_sb2 + (i64)t * a.out_st;
-  const u32 in_sj = (u32)a.in_sj, out_sk = (u32)a.out_sk;
-  const u32 in_lane = c * (u32)a.in_sc, out_lane = c * (u32)a.out_sc;
+  const u32 in_sj = (u32)a.in_sj << SH, out_sk = (u32)a.out_sk << SH;
+  const u32 in_lane = c * ((u32)a.in_sc << SH), out_lane = c * ((u32)a.out_sc << SH);
 
-  const bool live = col < a.ncols;  // ragged last tile: dead columns compute on zeros
+  const bool live = KIND != 0 ? true : col < a.ncols;  // ragged last tile: dead columns compute on zeros
 
   u64 x[16];
 
   // ---- round 1: j = j1*M + m, straight from HBM
   u32 joff[16];
-  if (a.js_log < 31) {  // blocked rows (multi-GPU receive buffer)
-    const u32 jmask = (1u << a.js_log) - 1, hi = (u32)a.in_sj_hi;
+  if (a.js_log < 31) {  // blocked rows (tiled scratch of a two-pass plan, multi-GPU receive buffer)
+    const u32 jmask = (1u << a.js_log) - 1, hi = (u32)a.in_sj_hi << SH;
+    if ((u32)M >= (1u << a.js_log) || KIND == 2) {
+      // M = 2^(LOGR-4) rows between a lane's consecutive loads: whole blocks when M >= 2^js_log (always true for the
+      // two-pass plans: js_log <= 4 <= LOGR - 4), so the block index advances by a constant and the in-block row is fixed
+      const u32 j0 = in_lane + (m >> a.js_log) * hi + (m & jmask) * in_sj, step = ((u32)M >> a.js_log) * hi;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 j = i * M + m;
-      joff[i] = in_lane + (j >> a.js_log) * hi + (j & jmask) * in_sj;
+      for (int i = 0; i < 16; i++) joff[i] = j0 + i * step;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const u32 j = i * M + m;
+        joff[i] = in_lane + (j >> a.js_log) * hi + (j & jmask) * in_sj;
+      }
     }
   } else {
     const u32 j0 = in_lane + m * in_sj, step = M * in_sj;
@@ -224,10 +316,10 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   } else if (live && a.in_valid != ~(u64)0) {
     const u64 lin0 = (u64)b2 * (u64)a.in_sb2 + (u64)t * (u64)a.in_st;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = (lin0 + joff[i] < a.in_valid) ? in[joff[i]] : 0;
+    for (int i = 0; i < 16; i++) x[i] = (lin0 + joff[i] < a.in_valid) ? ld_g<NARROW>(in, joff[i]) : 0;
   } else if (live) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = in[joff[i]];
+    for (int i = 0; i < 16; i++) x[i] = ld_g<NARROW>(in, joff[i]);
   } else {
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = 0;
@@ -235,9 +327,10 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   if (a.in2 && live) {
     const u64* in2 = a.in2 + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], in2[joff[i]]);
+    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], ld_g<NARROW>(in2, joff[i]));
   }
-  if (!(ABL & 4)) Dif<16, INV>::run(x);
+  // rounds that are followed by a table twiddle on every output but X[0] take the lazy last stage
+  if (!(ABL & 4)) { if (Q > 1) Dif<16, INV, true>::run(x); else Dif<16, INV>::run(x); }
 
   if (Q > 1) {
     u64* const lc = lds + c;
@@ -245,22 +338,38 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
     // last round's group with natural output index kl = k1; it is parked at group slot (k1 mod M)*G + k1 div M so that
     // lane m' of the last round (rows 16m' .. 16m'+15) owns the groups kl = m' + g*M -- adjacent output rows come from
     // adjacent lanes of one store instruction (same reasoning as the parking of round 2 below).
+    // Table byte offsets (m*k1)*8 for k1 = 1..15 come from an add chain (full-rate v_add_u32) instead of 15 multiplies.
+    u32 tb[16];
+    tb[0] = 0; tb[1] = m << 3;
+#pragma unroll
+    for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
+    // LDS element index of (row, c) = (swz_row(row) << logc) + c.  Every access below is written as ONE per-lane base
+    // plus a compile-time row constant (<< logc), so the address costs no VALU beyond the base (immediate offsets when
+    // the tile width is a compile-time constant).  Q == 3: row k1*M + m, M a multiple of 16: swz = k1*(M + M/16) + m + m/16.
+    const u32 park1 = ((m + (m >> 4)) << logc) + c;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, m * k1)));
-      const u32 blk = (Q == 2) ? (k1 & (M - 1)) * (16 / RLAST) + k1 / M : k1;
-      if (!(ABL & 8)) lc[swz_row(blk * M + m) << logc] = x[i];
+      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1) : ld_tabb(a.wr, tb[k1])));
+      if (!(ABL & 8)) {
+        if (Q == 3) {
+          lds[park1 + ((u32)(k1 * (M + M / 16)) << logc)] = x[i];
+        } else {
+          const u32 blk = (k1 & (M - 1)) * (16 / RLAST) + k1 / M;
+          lc[swz_row(blk * M + m) << logc] = x[i];
+        }
+      }
     }
     if (!(ABL & 8)) barrier();
 
     if (Q == 3) {
       // ---- round 2: thread (d1, d3) = (m / RLAST, m % RLAST), register digit d2
       const u32 d1 = m >> LOGLAST, d3 = m & (RLAST - 1);
-      const u32 base = d1 * (16 * RLAST) + d3;
+      // rows d1*16*RLAST + d3 + i*RLAST: swz = (17*RLAST*d1 + d3) + (i*RLAST + i*RLAST/16)     (d3 + (i*RLAST mod 16) < 16)
+      const u32 rd2 = ((d1 * (17 * RLAST) + d3) << logc) + c;
 #pragma unroll
       for (int i = 0; i < 16; i++)
-        if (!(ABL & 8)) x[i] = lc[swz_row(base + i * RLAST) << logc];
+        if (!(ABL & 8)) x[i] = lds[rd2 + ((u32)(i * RLAST + (i * RLAST) / 16) << logc)];
       // The results are NOT parked back at the rows just read.  The sub-transform with natural output index
       // kl = k1 + 16*k2 (k1 = d1) goes to group slot s = (kl mod M)*G + kl div M, G = 16/RLAST groups per lane, i.e. rows
       // s*RLAST .. s*RLAST + RLAST-1.  Lane m, which owns rows 16m .. 16m+15 in the last round, then holds the groups
@@ -268,23 +377,29 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
       // with kl = (v >> 4) + 16*(v & 15) they were 16 rows apart, with kl = 2m + g a lane wrote the two halves of a
       // 128-byte line at different times: +37 % write traffic in pass 1).  Not in place: read everything, then write.
       if (!(ABL & 8)) barrier();
-      if (!(ABL & 4)) Dif<16, INV>::run(x);
-      const u32 tstep = 16 * d3;  // omega_{R/16}^{d3*k2} = omega_R^{16*d3*k2}
+      if (!(ABL & 4)) Dif<16, INV, true>::run(x);
+      // omega_{R/16}^{d3*k2} = omega_R^{16*d3*k2}: byte offsets (16*d3*k2)*8 by the same add chain
+      tb[1] = d3 << 7;
+#pragma unroll
+      for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
+      const u32 tstep = 16 * d3;
+      // slot row = 256*(k2 mod RLAST) + 16*d1 + RLAST*(k2 div RLAST) + d3 (M = 16*RLAST, G*RLAST = 16), and
+      // RLAST*(k2 div RLAST) + d3 < 16: swz = (17*d1 + d3) + (272*(k2 mod RLAST) + RLAST*(k2 div RLAST))
+      const u32 park2 = ((17 * d1 + d3) << logc) + c;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
-        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1) : ld_tab(a.wr, tstep * k2)));
-        const u32 klw = (u32)k2 * 16 + d1;
-        const u32 slot = (klw & (M - 1)) * (16 / RLAST) + (klw / M);
-        if (!(ABL & 8)) lc[swz_row((slot << LOGLAST) + d3) << logc] = x[i];
+        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1) : ld_tabb(a.wr, tb[k2])));
+        if (!(ABL & 8)) lds[park2 + ((u32)(272 * (k2 % RLAST) + RLAST * (k2 / RLAST)) << logc)] = x[i];
       }
       if (!(ABL & 8)) barrier();
     }
 
     // ---- last round: thread m owns rows 16m .. 16m+15; row = v*RLAST + d_last
+    const u32 rd3 = ((17 * m) << logc) + c;   // swz_row(16m + i) = 17m + i
 #pragma unroll
     for (int i = 0; i < 16; i++)
-      if (!(ABL & 8)) x[i] = lc[swz_row(16 * m + i) << logc];
+      if (!(ABL & 8)) x[i] = lds[rd3 + ((u32)i << logc)];
   }
 
   // ---- last sub-DFTs + output, one group of GSZ registers at a time (sub-DFT -> inter-pass twiddle -> scale ->
@@ -297,7 +412,8 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   const u32 twyk = (u32)a.yk;
   const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
   const u32 lmask = (1u << a.tw_lo_bits) - 1;
-  const u64* const tf = a.tw_full ? a.tw_full + (col * a.tf_sc + b2 * a.tf_sb2) : nullptr;
+  const u64* const tf = (KIND == 3 || a.tw_full) ? a.tw_full : nullptr;
+  const u32 tf_lane = (col * a.tf_sc + b2 * a.tf_sb2) << SH, tf_sk = a.tf_sk << SH;
   const u64 lin_out0 = (u64)b2 * (u64)a.out_sb2 + (u64)t * (u64)a.out_st;
   u64 keep = 0;
   if (a.stage_io && Q > 1) barrier();                      // every lane has read its last-round rows: LDS is free
@@ -305,31 +421,57 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
   for (int g = 0; g < 16 / GSZ; g++) {
     u64* xg = x + g * GSZ;
     u32 kg[GSZ];  // natural output row of each register of the group
+    // group g of lane m is the sub-transform with natural index kl = m + g*M (see the parking of rounds 1 / 2)
+    const u32 kl = (Q == 1) ? 0 : m + (u32)g * M;
     if (Q == 1) {
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = brev(i, 4);
     } else {
-      if (!(ABL & 4)) Dif<RLAST, INV>::run(xg);
-      // group g of lane m is the sub-transform with natural index kl = m + g*M (see the parking of rounds 1 / 2)
-      const u32 kl = m + (u32)g * M;
+      // column passes of known shape multiply EVERY output by the inter-pass twiddle next: lazy last stage throughout
+      if (!(ABL & 4)) Dif<RLAST, INV, (KIND == 1 || KIND == 3) && !(ABL & 1)>::run(xg, false);
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
     if (tf && !(ABL & 1)) {
       if (live) {  // dead columns of a ragged tile hold zeros anyway
         u64 w[GSZ];
+        const u32 tbase = tf_lane + kl * tf_sk;   // like the stores: per-lane base + wave-uniform constants
 #pragma unroll
-        for (int i = 0; i < GSZ; i++) w[i] = tf[kg[i] * a.tf_sk];
+        for (int i = 0; i < GSZ; i++) {
+          const u32 ci = (Q == 1) ? (u32)brev(i, 4) : (u32)((R / RLAST) * brev(i, LOGLAST));
+          w[i] = ld_g<NARROW>(tf, tbase + ci * tf_sk);
+        }
 #pragma unroll
         for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], w[i]);
       }
     } else if (a.tw_log && !(ABL & 1)) {
-      // exponent (X*Y) mod 2^tw_log with tw_log <= 32: the low 32 bits of a 32-bit product suffice
+      // exponent (X*Y) mod 2^tw_log with tw_log <= 32 (the low 32 bits of a 32-bit product suffice); Y is affine in the
+      // output row, so the exponents of a group are Ebase + j*Estep, j = natural position inside the group: one
+      // multiply per group and an add chain instead of one multiply per coefficient
+      constexpr int CSTEP = (Q == 1) ? 1 : (R / RLAST);
+      // NARROW (tw_log <= 29 there): the chain runs on exponents pre-scaled by 8, so the two table byte offsets are
+      // and / shift+and of full-rate 32-bit ops
+      constexpr int ES = NARROW ? 3 : 0;
+      u32 ej[GSZ];
+      ej[0] = (twX * (twyk * kl + twYb)) << ES;
+      const u32 estep = (twX * (twyk * (u32)CSTEP)) << ES;
+#pragma unroll
+      for (int j = 1; j < GSZ; j++) ej[j] = ej[j - 1] + estep;
+      const u32 lmask8 = lmask << 3, hmask8 = (nmask >> a.tw_lo_bits) << 3;
 #pragma unroll
       for (int i = 0; i < GSZ; i++) {
-        const u32 e = (twX * (twyk * kg[i] + twYb)) & nmask;
-        const u64 w = (ABL & 64) ? gl64::mul((u64)e * 0x9E3779B97F4A7C15ull >> 1, (u64)(e >> 3) * 0xC2B2AE3D27D4EB4Full >> 1)
-                                : gl64::mul(ld_tab(a.tw_lo, e & lmask), ld_tab(a.tw_hi, e >> a.tw_lo_bits));
+        const u32 ee = ej[brev(i, (Q == 1) ? 4 : LOGLAST)];
+        u64 wl, wh;
+        if constexpr (NARROW) {
+          wl = ld_tabb(a.tw_lo, ee & lmask8);
+          wh = ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8);
+        } else {
+          const u32 e = ee & nmask;
+          wl = ld_tab(a.tw_lo, e & lmask);
+          wh = ld_tab(a.tw_hi, e >> a.tw_lo_bits);
+        }
+        const u64 w = (ABL & 64) ? gl64::mul((u64)ee * 0x9E3779B97F4A7C15ull >> 1, (u64)(ee >> 3) * 0xC2B2AE3D27D4EB4Full >> 1)
+                                : gl64::mul(wl, wh);
         xg[i] = gl64::mul(xg[i], w);
       }
     }
@@ -346,15 +488,16 @@ RONK_HD void tile_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& 
     } else if (ABL & 32) {
 #pragma unroll
       for (int i = 0; i < GSZ; i++) keep ^= xg[i];
-    } else if (live && a.out_valid != ~(u64)0) {
+    } else if (live) {
+      // offset = out_lane + kg*out_sk = (out_lane + kl*out_sk) + const_i*out_sk: one per-lane base per group, the rest is
+      // wave-uniform (SALU)
+      const u32 obase = out_lane + kl * out_sk;
 #pragma unroll
       for (int i = 0; i < GSZ; i++) {
-        const u32 off = out_lane + kg[i] * out_sk;
-        if (lin_out0 + off < a.out_valid) st_out(outp + off, xg[i]);
+        const u32 ci = (Q == 1) ? (u32)brev(i, 4) : (u32)((R / RLAST) * brev(i, LOGLAST));
+        const u32 off = obase + ci * out_sk;
+        if (a.out_valid == ~(u64)0 || lin_out0 + off < a.out_valid) st_g<NARROW>(outp, off, xg[i]);
       }
-    } else if (live) {
-#pragma unroll
-      for (int i = 0; i < GSZ; i++) st_out(outp + (out_lane + kg[i] * out_sk), xg[i]);
     }
   }
   if (a.stage_io && !(ABL & 32)) {

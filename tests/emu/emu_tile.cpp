@@ -17,6 +17,7 @@
 
 #include "../../oracle/ronk_oracle.h"
 #include "../../ronkathon_amd/csrc/plan.h"
+#include "../../ronkathon_amd/csrc/tile_cfg_table.h"
 
 using namespace ronk;
 
@@ -36,8 +37,26 @@ static void fiber_barrier() { swapcontext(&g_ctx[g_cur], &g_sched); }
 template <int LOGR, bool INV>
 static void run_body(u32 tid) { tile_body<LOGR, INV, 0>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); }
 
+// the compile-time-specialised instantiations the library launches for recognised pass shapes (tile_kernels.hip):
+// same selection rule, same table
+static int g_cfg_used = 0;
+template <bool INV>
+static bool dispatch_cfg(int logr, u32 tid) {
+  const TileArgs& a = *g_fa.a;
+#define EMU_CFG_CASE(LR, LC, KD)                                                                 \
+  if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
+    tile_body<LR, INV, 0, TileCfg<LC, KD>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier);           \
+    g_cfg_used = KD;                                                                             \
+    return true;                                                                                 \
+  }
+  RONK_CFG_TABLE(EMU_CFG_CASE)
+#undef EMU_CFG_CASE
+  return false;
+}
+
 template <bool INV>
 static void dispatch(int logr, u32 tid) {
+  if (!getenv("RONK_NO_CFG_KERNELS") && dispatch_cfg<INV>(logr, tid)) return;
   switch (logr) {
     case 4: run_body<4, INV>(tid); break;
     case 5: run_body<5, INV>(tid); break;
@@ -176,12 +195,14 @@ int main(int argc, char** argv) {
     if (in_valid && p.in_buf == BUF_IN) a.in_valid = in_valid;
     if (out_valid && p.out_buf == BUF_OUT) a.out_valid = out_valid;
     lds.assign(p.lds_bytes / 8 + 1, 0);
-    printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu\n", p.logr, a.logc, a.tiles,
-           a.nb1, a.nb2, p.grid, p.block, p.lds_bytes);
+    g_cfg_used = 0;
     for (u32 bid = 0; bid < p.grid; bid++) {
       g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
       run_block(p.block);
     }
+    printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
+           a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
+           g_cfg_used == 2 ? "cfg:row" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
   for (u64 b = 0; b < batch; b++) {

@@ -15,7 +15,7 @@ EXE = os.path.join(ROOT, "build", "emu_tile")
 def emu():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "emu", "emu_tile.cpp")]
-    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "plan.h", "gl64.h")]
+    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "plan.h", "gl64.h", "tile_cfg_table.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
         subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
@@ -47,6 +47,22 @@ def test_two_pass(emu, k, batch, inv, logc):
 def test_tuned_tile_widths(emu, k, logc):
     """ronk_plan_create_tuned(tile_log2_columns = c): bench.py times c = 2 plans on two streams; 2^23 is a three-pass plan"""
     run(emu, k, 1, (k + logc) & 1, logc, 0, 23)
+
+
+def test_specialised_kernels_are_selected_and_generic_bodies_still_match(emu):
+    """the hot two-pass shapes run the compile-time-specialised bodies (tile_cfg_table.h; same selection rule as
+    tile_kernels.hip); with RONK_NO_CFG_KERNELS the generic body computes the same plans"""
+    for args, kinds in (((22, 1, 0, 4), ("cfg:column/two-level", "cfg:row")), ((22, 1, 1, 2), ("cfg:column/two-level", "cfg:row")),
+                        ((16, 3, 0, 4, 18), ("cfg:column/matrix", "cfg:row")), ((18, 1, 1, 4, 18), ("cfg:column/matrix", "cfg:row"))):
+        out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+        lines = out.stdout.strip().splitlines()
+        assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+        assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == list(kinds), out.stdout
+        env = dict(os.environ, RONK_NO_CFG_KERNELS="1")
+        out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+        lines = out.stdout.strip().splitlines()
+        assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+        assert all(l.endswith("kernel=generic") for l in lines if l.startswith("pass"))
 
 
 @pytest.mark.parametrize("k,batch", [(19, 32), (20, 16), (22, 4)])

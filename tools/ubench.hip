@@ -15,13 +15,14 @@ using namespace ronk;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-template <int LOGR, bool INV, int ABL>
+// LOGC / KIND: the compile-time pass shape (TileCfg, ntt_tile.h); -1 / 0 = the generic body
+template <int LOGR, bool INV, int ABL, int LOGC = -1, int KIND = 0>
 __global__ void __launch_bounds__(1024) abl_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 nb = gridDim.x, b = blockIdx.x;
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tile_body<LOGR, INV, ABL>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+  tile_body<LOGR, INV, ABL, TileCfg<LOGC, KIND>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
 }
 
 template <int K>
@@ -74,12 +75,26 @@ static float time_launch(std::function<void()> f, int iters) {
   return ms * 1e3f / iters;  // us
 }
 
+template <int ABL, int LOGR, int LOGC, int KIND>
+static float run_abl_k(const PassDesc& ps, const TileArgs& a) {
+  CK(hipFuncSetAttribute((const void*)abl_kernel<LOGR, false, ABL, LOGC, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return time_launch([&] { hipLaunchKernelGGL((abl_kernel<LOGR, false, ABL, LOGC, KIND>), dim3(ps.grid), dim3(ps.block), ps.lds_bytes, 0, a); }, 50);
+}
+static bool g_generic = false;   // ubench ... with RONK_NO_CFG_KERNELS set: generic bodies everywhere
 template <int ABL, int LOGR = 11>
 static void run_abl(const PlanDesc& pd, int pass, TileArgs a, const char* label) {
   const PassDesc& ps = pd.passes[pass];
-  CK(hipFuncSetAttribute((const void*)abl_kernel<LOGR, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  float us = time_launch([&] { hipLaunchKernelGGL((abl_kernel<LOGR, false, ABL>), dim3(ps.grid), dim3(ps.block), ps.lds_bytes, 0, a); }, 50);
-  printf("  pass %d  ABL=%2d  %-42s %8.2f us\n", pass, ABL, label, us);
+  float us;
+  const char* k = "generic";
+  // the shapes the library specialises at 2^22 (C = 8 and C = 4) and 2^16 (C = 16); ABL & 1 keeps the column pass generic
+  if (!g_generic && LOGR == 11 && a.logc == 3 && tile_cfg_matches(a, 11, 3, 1)) { us = run_abl_k<ABL, LOGR == 11 ? 11 : 11, 3, 1>(ps, a); k = "cfg1"; }
+  else if (!g_generic && LOGR == 11 && a.logc == 3 && tile_cfg_matches(a, 11, 3, 2)) { us = run_abl_k<ABL, 11, 3, 2>(ps, a); k = "cfg2"; }
+  else if (!g_generic && LOGR == 11 && a.logc == 2 && tile_cfg_matches(a, 11, 2, 1)) { us = run_abl_k<ABL, 11, 2, 1>(ps, a); k = "cfg1"; }
+  else if (!g_generic && LOGR == 11 && a.logc == 2 && tile_cfg_matches(a, 11, 2, 2)) { us = run_abl_k<ABL, 11, 2, 2>(ps, a); k = "cfg2"; }
+  else if (!g_generic && LOGR == 8 && a.logc == 4 && tile_cfg_matches(a, 8, 4, 3)) { us = run_abl_k<ABL, 8, 4, 3>(ps, a); k = "cfg3"; }
+  else if (!g_generic && LOGR == 8 && a.logc == 4 && tile_cfg_matches(a, 8, 4, 2)) { us = run_abl_k<ABL, 8, 4, 2>(ps, a); k = "cfg2"; }
+  else us = run_abl_k<ABL, LOGR, -1, 0>(ps, a);
+  printf("  pass %d  ABL=%3d  %-42s %8.2f us  [%s]\n", pass, ABL, label, us, k);
 }
 
 // single-pass batched transforms (n = 2^LOGR, the batch is the column axis): the same ablation
@@ -190,6 +205,7 @@ static void occupancy_sweep(const char* what) {
 }
 
 int main(int argc, char** argv) {
+  g_generic = getenv("RONK_NO_CFG_KERNELS") != nullptr;
   int max_logc = argc > 1 ? atoi(argv[1]) : 4;
   if (argc == 2 && atoi(argv[1]) == -1) { occupancy_sweep<56>("math only"); occupancy_sweep<120>("math only, no table loads"); return 0; }
   if (argc == 3) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
