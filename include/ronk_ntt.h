@@ -199,12 +199,39 @@ int ronk_curve_msm(const ronk_curve* curve, const uint64_t* points, size_t n_poi
 typedef struct ronk_dist_plan ronk_dist_plan;
 int ronk_dist_plan_create(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world, int device);
 int ronk_dist_plan_destroy(ronk_dist_plan* plan);
+/* The same with the exchange split in `chunks` column chunks (a power of two, >= 16 columns per chunk): phase 1 of
+ * chunk j writes the contiguous piece d_send[j*R*Cwc ..), Cwc = C/world/chunks, as `world` blocks [R/world][Cwc] (block h
+ * for rank h), so the caller can ship chunk j while chunk j+1 is computed; the receiver stores the block of (source rank g,
+ * chunk j) at d_recv[(g*chunks + j)*(R/world)*Cwc ..).  chunks = 1 is ronk_dist_plan_create. */
+int ronk_dist_plan_create_chunked(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world, int device,
+                                  int chunks);
+int ronk_dist_phase1_chunk_dev(ronk_dist_plan* plan, int chunk, const uint64_t* d_in, uint64_t* d_send, void* stream);
 /* phase 1: R-point NTTs down the local columns, times omega_n^{c*k1}; output is written as `world`
  * consecutive send blocks, block h = rows k1 in h's range, layout [R/world][C/world] */
 int ronk_dist_phase1_dev(ronk_dist_plan* plan, const uint64_t* d_in, uint64_t* d_send, void* stream);
 /* phase 2: d_recv holds `world` blocks [R/world][C/world] (block g from rank g); C-point NTTs along
  * each local row k1; d_out[k2*(R/world) + (k1 - k1_0)] = X[k1 + R*k2] */
 int ronk_dist_phase2_dev(ronk_dist_plan* plan, const uint64_t* d_recv, uint64_t* d_out, void* stream);
+
+/* ---- the sharded transform as ONE call for a single-process host (the Rust host of BASELINE config 5): rank g of
+ *      ndev = devices[g]; the exchange is a mesh of peer copies over xGMI issued by the library on per-device copy
+ *      streams, in `chunks` column chunks so that a chunk travels while the next one is computed (chunks <= 0: default,
+ *      up to 4).  The reference has no counterpart: `Polynomial<B, F, D>` holds its coefficients inline
+ *      (src/polynomial/mod.rs:34-44), so a degree this large never exists there.
+ *      Errors: RONK_ERR_UNSUPPORTED (fewer than 16 rows / columns per rank and chunk, ndev not a power of two),
+ *      RONK_ERR_INVALID (device ordinal out of range), RONK_ERR_HIP. */
+typedef struct ronk_sharded_plan ronk_sharded_plan;
+int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev, int chunks);
+int ronk_sharded_plan_destroy(ronk_sharded_plan* plan);
+/* R, C (n = R*C), elements per rank (n / ndev) and the number of column chunks in use; any pointer may be NULL */
+int ronk_sharded_plan_info(const ronk_sharded_plan* plan, uint64_t* rows, uint64_t* cols, uint64_t* per_rank, int* chunks);
+/* device-resident: d_in[g] = rank g's [R][C/ndev] column block on devices[g], d_out[g] = its [C][R/ndev] block of the
+ * natural-order result (layouts as for ronk_dist_*).  Enqueues on the plan's own streams and returns; the buffers may
+ * be reused after ronk_sharded_sync().  Successive calls pipeline (events guard the plan's send/receive buffers). */
+int ronk_ntt_sharded_dev(ronk_sharded_plan* plan, const uint64_t* const* d_in, uint64_t* const* d_out);
+int ronk_sharded_sync(ronk_sharded_plan* plan);
+/* host pointers, natural order in and out (n elements each): scatter, transform, gather; synchronous */
+int ronk_ntt_sharded(ronk_sharded_plan* plan, const uint64_t* in, uint64_t* out);
 
 /* ---- small device-memory helpers so a non-HIP host (ctypes, cgo, JNI) can stay device-resident ---- */
 int ronk_dev_alloc(void** ptr, size_t bytes);

@@ -93,8 +93,16 @@ _SIG = {
     "ronk_curve_msm": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
     "ronk_dist_plan_destroy": (_int, [_vp]),
+    "ronk_dist_plan_create_chunked": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int, _int]),
+    "ronk_dist_phase1_chunk_dev": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_dist_phase2_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_sharded_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int]),
+    "ronk_sharded_plan_destroy": (_int, [_vp]),
+    "ronk_sharded_plan_info": (_int, [_vp, _pu, _pu, _pu, C.POINTER(_int)]),
+    "ronk_ntt_sharded_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ronk_sharded_sync": (_int, [_vp]),
+    "ronk_ntt_sharded": (_int, [_vp, _vp, _vp]),
     "ronk_dev_alloc": (_int, [C.POINTER(_vp), _sz]),
     "ronk_dev_free": (_int, [_vp]),
     "ronk_memcpy_h2d": (_int, [_vp, _vp, _sz]),
@@ -192,3 +200,45 @@ class Plan:
         ms = (C.c_float * np_)()
         check(lib.ronk_plan_time_passes(self.h, d_in, d_out, int(inverse), iters, ms, stream))
         return [float(v) for v in ms]
+
+
+class ShardedPlan:
+    """ronk_sharded_plan: the four-step NTT sharded over `devices` inside the library (single process; peer copies over
+    xGMI in column chunks).  Rank g = devices[g]; the same ordinal may appear several times (logical ranks sharing a GPU:
+    how the single-GPU tests drive this path)."""
+
+    def __init__(self, log2n, devices, inverse=False, chunks=0):
+        self.h = None
+        h = _vp()
+        devs = (_int * len(devices))(*devices)
+        check(lib.ronk_sharded_plan_create(C.byref(h), log2n, int(inverse), devs, len(devices), chunks))
+        self.h, self.n, self.ndev = h, 1 << log2n, len(devices)
+        r, c, per, ch = _u64(0), _u64(0), _u64(0), _int(0)
+        check(lib.ronk_sharded_plan_info(h, C.byref(r), C.byref(c), C.byref(per), C.byref(ch)))
+        self.R, self.C, self.per_rank, self.chunks = r.value, c.value, per.value, ch.value
+
+    def transform(self, x):
+        """host natural-order vector -> natural-order result (ronk_ntt_sharded)"""
+        x = arr(x)
+        assert x.size == self.n
+        out = np.empty_like(x)
+        check(lib.ronk_ntt_sharded(self.h, ptr(x), ptr(out)))
+        return out
+
+    def transform_dev(self, d_in, d_out):
+        """device pointers per rank (lists of ints); asynchronous, see sync()"""
+        a = (_vp * self.ndev)(*d_in)
+        b = (_vp * self.ndev)(*d_out)
+        check(lib.ronk_ntt_sharded_dev(self.h, a, b))
+
+    def sync(self):
+        check(lib.ronk_sharded_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.ronk_sharded_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        if lib is not None:
+            self.close()

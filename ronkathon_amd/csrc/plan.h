@@ -317,17 +317,38 @@ inline bool dist_shape(int log2n, int world, DistShape* s) {
   return true;
 }
 
-inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0) {
+// Column chunks (exchange overlap): a rank's C/W columns are split in `chunks` groups of Cwc = C/W/chunks
+// columns; phase 1 of chunk j reads columns [j*Cwc, (j+1)*Cwc) of the local [R][C/W] input and writes a CONTIGUOUS
+// [R][Cwc] piece of the send buffer at offset j*R*Cwc, i.e. W blocks [R/W][Cwc], block h for rank h -- so chunk j can
+// be shipped (W contiguous blocks) while chunk j+1 is still being computed.  The receiver stores block (g, j) at
+// (g*chunks + j)*(R/W)*Cwc: with b = c / Cwc the global column c = g*C/W + j*Cwc + cc lives at b*(R/W)*Cwc + k1*Cwc + cc,
+// which is the two-level row addressing of TileArgs (js_log = log2 Cwc).  chunks == 1 is the plain layout.
+inline bool dist_chunks_ok(const DistShape& sh, int chunks) {
+  if (chunks < 1 || (chunks & (chunks - 1))) return false;
+  if (sh.Cw % (u64)chunks) return false;
+  const u64 cwc = sh.Cw / (u64)chunks;
+  if (cwc < 16) return false;
+  if (sh.logC > 12) {   // two-pass phase 2: the received row index splits at log2(cwc) - kb bits
+    int lcwc = 0; while (((u64)1 << lcwc) < cwc) lcwc++;
+    if (lcwc < sh.logC / 2) return false;
+  }
+  return true;
+}
+
+inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0,
+                                  int chunk = 0, int chunks = 1) {
   DistShape sh;
   PlanBuilder b;
   b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.inverse = inverse;
-  if (!dist_shape(log2n, world, &sh)) return b.d;
-  const u64 Cw = sh.Cw, g0 = (u64)rank * Cw;
+  if (!dist_shape(log2n, world, &sh) || !dist_chunks_ok(sh, chunks) || chunk < 0 || chunk >= chunks) return b.d;
+  const u64 Cw = sh.Cw, Cwc = Cw / (u64)chunks;       // input row stride / columns of this chunk = output row stride
+  const u64 g0 = (u64)rank * Cw + (u64)chunk * Cwc;   // global index of the chunk's first column
   const u64 scale = inverse ? gl64::inv(sh.n % gl64::P) : 1;   // folded into the global twiddle of phase 1
+  // the launcher adds chunk*Cwc to the input pointer and chunk*R*Cwc to the output pointer (ronk_dist.hip)
   if (sh.logR <= 12) {
-    PassDesc& p = b.add_pass(sh.logR, Cw, max_logc);
-    p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)Cw; p.args.out_sc = 1;
+    PassDesc& p = b.add_pass(sh.logR, Cwc, max_logc);
+    p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)Cwc; p.args.out_sc = 1;
     p.tw_id = b.tw_table(log2n, scale);
     p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
     p.args.xc = 1; p.args.x0 = g0; p.args.yk = 1;            // omega_n^{(g0 + cl) * k1}
@@ -337,9 +358,9 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
     const int ka = (sh.logR + 1) / 2, kb = sh.logR - ka;
     const u64 A = (u64)1 << ka, B = (u64)1 << kb;
     {
-      PassDesc& p = b.add_pass(ka, Cw, max_logc);             // r = a*B + b: A-point over a, batch b
-      p.args.in_sj = (i64)(B * Cw); p.args.in_sc = 1; p.args.out_sk = (i64)(B * Cw); p.args.out_sc = 1;
-      p.args.nb2 = (u32)B; p.args.in_sb2 = p.args.out_sb2 = (i64)Cw;
+      PassDesc& p = b.add_pass(ka, Cwc, max_logc);            // r = a*B + b: A-point over a, batch b; tmp is [R][Cwc]
+      p.args.in_sj = (i64)(B * Cw); p.args.in_sc = 1; p.args.out_sk = (i64)(B * Cwc); p.args.out_sc = 1;
+      p.args.nb2 = (u32)B; p.args.in_sb2 = (i64)Cw; p.args.out_sb2 = (i64)Cwc;
       p.tw_id = b.tw_table(sh.logR);
       p.args.tw_log = sh.logR; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
       p.args.xb2 = 1; p.args.yk = 1;                          // omega_R^{b * ka}
@@ -347,9 +368,9 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
       b.finish(p);
     }
     {
-      PassDesc& p = b.add_pass(kb, Cw, max_logc);             // B-point over b, batch ka; k1 = ka + A*kb
-      p.args.in_sj = (i64)Cw; p.args.in_sc = 1; p.args.out_sk = (i64)(A * Cw); p.args.out_sc = 1;
-      p.args.nb2 = (u32)A; p.args.in_sb2 = (i64)(B * Cw); p.args.out_sb2 = (i64)Cw;
+      PassDesc& p = b.add_pass(kb, Cwc, max_logc);            // B-point over b, batch ka; k1 = ka + A*kb
+      p.args.in_sj = (i64)Cwc; p.args.in_sc = 1; p.args.out_sk = (i64)(A * Cwc); p.args.out_sc = 1;
+      p.args.nb2 = (u32)A; p.args.in_sb2 = (i64)(B * Cwc); p.args.out_sb2 = (i64)Cwc;
       p.tw_id = b.tw_table(log2n, scale);
       p.args.tw_log = log2n; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;
       p.args.xc = 1; p.args.x0 = g0; p.args.yk = A; p.args.yb2 = 1;   // omega_n^{c * (ka + A*kb)}
@@ -361,19 +382,21 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
   return b.d;
 }
 
-inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0) {
+inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0,
+                                  int chunks = 1) {
   (void)rank;
   DistShape sh;
   PlanBuilder b;
   b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.inverse = inverse;
-  if (!dist_shape(log2n, world, &sh)) return b.d;
-  const u64 Cw = sh.Cw, Rw = sh.Rw, C = sh.C;
+  if (!dist_shape(log2n, world, &sh) || !dist_chunks_ok(sh, chunks)) return b.d;
+  const u64 Cw = sh.Cw, Rw = sh.Rw, C = sh.C, Cwc = Cw / (u64)chunks;
+  int lcwc = 0; while (((u64)1 << lcwc) < Cwc) lcwc++;
   const u64 scale = 1;  // the inverse's n^-1 is applied by phase 1 (folded into its global twiddle)
   if (sh.logC <= 12) {
     PassDesc& p = b.add_pass(sh.logC, Rw, max_logc);          // columns = local rows k1, rows j = c (blocked)
-    p.args.in_sc = (i64)Cw; p.args.in_sj = 1;
-    p.args.js_log = (u32)(sh.logC - sh.logW); p.args.in_sj_hi = (i64)(Rw * Cw);
+    p.args.in_sc = (i64)Cwc; p.args.in_sj = 1;
+    p.args.js_log = (u32)lcwc; p.args.in_sj_hi = (i64)(Rw * Cwc);
     p.args.out_sk = (i64)Rw; p.args.out_sc = 1;
     p.args.scale = scale;
     p.in_buf = BUF_IN; p.out_buf = BUF_OUT;
@@ -384,8 +407,8 @@ inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, 
     {
       PassDesc& p = b.add_pass(ka, B2, max_logc);             // c = a2*B2 + b2: A2-point over a2; batch k1
       p.args.in_sc = 1; p.args.in_sj = (i64)B2;
-      p.args.js_log = (u32)(sh.logC - sh.logW - kb); p.args.in_sj_hi = (i64)(Rw * Cw);
-      p.args.nb2 = (u32)Rw; p.args.in_sb2 = (i64)Cw;
+      p.args.js_log = (u32)(lcwc - kb); p.args.in_sj_hi = (i64)(Rw * Cwc);
+      p.args.nb2 = (u32)Rw; p.args.in_sb2 = (i64)Cwc;
       p.args.out_sb2 = (i64)C; p.args.out_sk = (i64)B2; p.args.out_sc = 1;   // tmp: natural [k1][a2][b2]
       p.tw_id = b.tw_table(sh.logC);
       p.args.tw_log = sh.logC; p.args.tw_lo_bits = b.d.tw[p.tw_id].lo_bits;

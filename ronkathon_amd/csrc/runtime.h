@@ -125,8 +125,10 @@ struct CompiledPlan {
   // launch pass idx: BUF_IN -> in (and in2), BUF_OUT -> out, BUF_TMP -> tmp
   // in_valid / out_valid: implicit zero padding of the input / truncation of the output (TileArgs), ~0 = none
   // in_poly_stride (multi-pass plans, 0 = n): element stride between the polynomials of a batched input
+  // x0_add: added to the X offset of passes whose inter-pass twiddle depends on the column (column chunks of the
+  // sharded four-step: chunk j starts j*Cwc columns further right, ronk_dist.hip)
   int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0) const {
+             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0) const {
     const PassDesc& ps = pd.passes[idx];
     TileArgs a = ps.args;
     const u64* bufs_in[3] = {in, out, tmp};
@@ -139,6 +141,7 @@ struct CompiledPlan {
       if (in_poly_stride) a.in_sb1 = (i64)in_poly_stride;   // nb1 is the batch axis of every multi-pass plan (plan.h)
     }
     if (ps.out_buf == BUF_OUT) a.out_valid = out_valid;
+    if (x0_add && a.tw_log && a.xc) a.x0 += x0_add * a.xc;
     if (in_valid != ~(u64)0 || out_valid != ~(u64)0 || in_poly_stride) a.stage_io = 0;   // staged I/O copies whole tiles
     a.wr = d_wr[ps.wr_id];
     if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
@@ -148,9 +151,9 @@ struct CompiledPlan {
     return RONK_OK;
   }
   int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0) const {
+          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0) const {
     for (size_t i = 0; i < pd.passes.size(); i++)
-      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride));
+      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add));
     return RONK_OK;
   }
 };

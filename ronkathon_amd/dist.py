@@ -50,14 +50,17 @@ def place_output(out_global, local_out, rank, world):
 class HipEngine:
     """the product local engine: ronk_dist_plan over the C ABI (HIP kernels); torch tensors only carry memory"""
 
-    def __init__(self, log2n, inverse, rank, world, device=-1):
+    def __init__(self, log2n, inverse, rank, world, device=-1, chunks=1):
         self.h = None
         h = C.c_void_p()
-        L.check(L.lib.ronk_dist_plan_create(C.byref(h), log2n, int(inverse), rank, world, device))
+        L.check(L.lib.ronk_dist_plan_create_chunked(C.byref(h), log2n, int(inverse), rank, world, device, chunks))
         self.h = h
 
     def phase1(self, d_in, d_send, stream=0):
         L.check(L.lib.ronk_dist_phase1_dev(self.h, d_in, d_send, stream))
+
+    def phase1_chunk(self, chunk, d_in, d_send, stream=0):
+        L.check(L.lib.ronk_dist_phase1_chunk_dev(self.h, chunk, d_in, d_send, stream))
 
     def phase2(self, d_recv, d_out, stream=0):
         L.check(L.lib.ronk_dist_phase2_dev(self.h, d_recv, d_out, stream))
@@ -75,7 +78,9 @@ class FourStepNTT:
     implementation; the default (and only product) engine is HipEngine -- the CPU/gloo tests inject
     a checker engine to exercise the exchange logic without a GPU."""
 
-    def __init__(self, log2n, inverse=False, group=None, engine=None):
+    def __init__(self, log2n, inverse=False, group=None, engine=None, chunks=1):
+        """chunks > 1: the exchange is split in column chunks (csrc/plan.h): chunk j's all-to-all is issued on a side
+        stream as soon as its part of phase 1 is done, so it travels over xGMI while chunk j+1 is computed."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -84,7 +89,15 @@ class FourStepNTT:
         self.log2n = log2n
         self.R, self.C, self.Rw, self.Cw = shape(log2n, self.world)
         self.per_rank = (1 << log2n) // self.world
-        self.engine = engine if engine is not None else HipEngine(log2n, inverse, self.rank, self.world)
+        self.chunks = chunks
+        assert chunks >= 1 and chunks & (chunks - 1) == 0 and self.Cw // chunks >= 16, "chunks: a power of two, >= 16 columns each"
+        if engine is not None:
+            self.engine = engine
+            if chunks > 1:
+                engine.chunks = chunks
+        else:
+            self.engine = HipEngine(log2n, inverse, self.rank, self.world, chunks=chunks)
+        self._side = None
 
     def _ptr(self, t):
         return t.data_ptr()
@@ -97,6 +110,10 @@ class FourStepNTT:
         recv = torch.empty_like(local_in) if recv is None else recv
         out = torch.empty_like(local_in) if out is None else out
         stream = torch.cuda.current_stream().cuda_stream if local_in.is_cuda else 0
+        if self.chunks > 1 and self.world > 1:
+            self._exchange_chunked(local_in, send, recv, stream)
+            self.engine.phase2(self._ptr(recv), self._ptr(out), stream)
+            return out
         self.engine.phase1(self._ptr(local_in), self._ptr(send), stream)
         if self.world > 1:
             if local_in.is_cuda and self.dist.get_backend(self.group) != "nccl":
@@ -114,6 +131,46 @@ class FourStepNTT:
             recv = send
         self.engine.phase2(self._ptr(recv), self._ptr(out), stream)
         return out
+
+
+def _exchange_chunked(self, local_in, send, recv, stream):
+    """phase 1 chunk by chunk, each chunk's all-to-all in flight while the next chunk is computed.
+    send piece j = [W][Rw][Cwc] (block h for rank h); the block from (rank g, chunk j) lands at recv[(g*chunks + j)]."""
+    import torch
+    W, K = self.world, self.chunks
+    blk = self.Rw * (self.Cw // K)
+    sview = send.view(K, W, blk)
+    rview = recv.view(W, K, blk)
+    nccl = local_in.is_cuda and self.dist.get_backend(self.group) == "nccl"
+    works = []
+    if nccl:
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+    for j in range(K):
+        self.engine.phase1_chunk(j, self._ptr(local_in), self._ptr(send), stream)
+        if nccl:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                outs = [rview[g, j] for g in range(W)]
+                ins = [sview[j, h] for h in range(W)]
+                works.append(self.dist.all_to_all(outs, ins, group=self.group, async_op=True))   # RCCL over xGMI
+        else:
+            # backends without device collectives / list all-to-all (gloo): per-chunk all_to_all_single through host
+            # memory -- the control-flow and layout test path, not the product configuration
+            if local_in.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            h_send = sview[j].cpu().contiguous()
+            h_recv = torch.empty_like(h_send)
+            self.dist.all_to_all_single(h_recv.view(-1), h_send.view(-1), group=self.group)
+            rview[:, j].copy_(h_recv)
+    for w in works:
+        w.wait()          # makes the current (main) stream wait for the collective
+
+
+FourStepNTT._exchange_chunked = _exchange_chunked
 
 
 def fourstep_single_process(x, world, inverse=False):

@@ -127,12 +127,13 @@ static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64*
   }
 }
 
-// dist mode: simulate all W ranks of the four-step in one process (the all-to-all is a memcpy)
+// dist mode: simulate all W ranks of the four-step in one process (the all-to-all is a memcpy); `chunks` > 1 = the
+// column-chunked exchange layout (plan.h: chunk j of rank g is shipped as W contiguous blocks [R/W][Cwc])
 static int g_twf = 0;
-static int dist_main(int log2n, int world, bool inv) {
+static int dist_main(int log2n, int world, bool inv, int chunks) {
   DistShape sh;
-  if (!dist_shape(log2n, world, &sh)) { printf("bad dist shape\n"); return 2; }
-  const u64 n = sh.n, per = n / sh.W;
+  if (!dist_shape(log2n, world, &sh) || !dist_chunks_ok(sh, chunks)) { printf("bad dist shape\n"); return 2; }
+  const u64 n = sh.n, per = n / sh.W, Cwc = sh.Cw / (u64)chunks;
   std::vector<u64> x(n), ref(n), got(n);
   u64 s = 0x5EED0005ull + log2n;
   for (auto& v : x) { do v = splitmix(s); while (v >= gl64::P); }
@@ -141,14 +142,20 @@ static int dist_main(int log2n, int world, bool inv) {
     loc[g].resize(per); snd[g].assign(per, 1); rcv[g].resize(per); res[g].assign(per, 2); tmp[g].assign(per, 3);
     for (u64 r = 0; r < sh.R; r++)
       for (u64 cl = 0; cl < sh.Cw; cl++) loc[g][r * sh.Cw + cl] = x[r * sh.C + g * sh.Cw + cl];
-    PlanDesc p1 = build_dist_phase1(log2n, inv, g, world, 4, g_twf);
-    run_plan(p1, inv, loc[g].data(), snd[g].data(), tmp[g].data());
+    for (int j = 0; j < chunks; j++) {
+      PlanDesc p1 = build_dist_phase1(log2n, inv, g, world, 4, g_twf, j, chunks);
+      if (p1.passes.empty()) { printf("no phase-1 plan\n"); return 2; }
+      run_plan(p1, inv, loc[g].data() + (u64)j * Cwc, snd[g].data() + (u64)j * sh.R * Cwc, tmp[g].data());
+    }
   }
-  const u64 blk = sh.Rw * sh.Cw;
+  const u64 blk = sh.Rw * Cwc;   // one (source rank, chunk) block on the receiver
   for (int g = 0; g < world; g++)
-    for (int h = 0; h < world; h++) memcpy(&rcv[h][g * blk], &snd[g][h * blk], blk * 8);  // all_to_all_single
+    for (int j = 0; j < chunks; j++)
+      for (int h = 0; h < world; h++)
+        memcpy(&rcv[h][((u64)g * chunks + j) * blk], &snd[g][(u64)j * sh.R * Cwc + (u64)h * blk], blk * 8);
   for (int h = 0; h < world; h++) {
-    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world, 4, g_twf);
+    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world, 4, g_twf, chunks);
+    if (p2.passes.empty()) { printf("no phase-2 plan\n"); return 2; }
     run_plan(p2, inv, rcv[h].data(), res[h].data(), tmp[h].data());
     for (u64 k2 = 0; k2 < sh.C; k2++)
       for (u64 k1l = 0; k1l < sh.Rw; k1l++) got[(h * sh.Rw + k1l) + sh.R * k2] = res[h][k2 * sh.Rw + k1l];
@@ -157,13 +164,14 @@ static int dist_main(int log2n, int world, bool inv) {
   if (rc) return 1;
   for (u64 i = 0; i < n; i++)
     if (got[i] != ref[i]) { printf("DIST MISMATCH at %llu\n", (unsigned long long)i); return 1; }
-  printf("OK dist log2n=%d world=%d inv=%d\n", log2n, world, (int)inv);
+  printf("OK dist log2n=%d world=%d inv=%d chunks=%d\n", log2n, world, (int)inv, chunks);
   return 0;
 }
 
 int main(int argc, char** argv) {
   if (argc >= 6 && !strcmp(argv[1], "dist")) g_twf = atoi(argv[5]);
-  if (argc >= 5 && !strcmp(argv[1], "dist")) return dist_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0);
+  if (argc >= 5 && !strcmp(argv[1], "dist"))   // emu_tile dist <log2n> <world> <inverse> [twf_max_log] [chunks]
+    return dist_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0, argc >= 7 ? atoi(argv[6]) : 1);
   if (argc < 5) { fprintf(stderr, "usage: emu_tile log2n batch inverse max_logc\n"); return 2; }
   int log2n = atoi(argv[1]);
   u64 batch = strtoull(argv[2], 0, 10);

@@ -49,9 +49,29 @@ class OracleEngine:
             tw = np.array([orc.pow_(GP, w, (c * k1) % n) for k1 in range(self.R)], dtype=np.uint64)
             out[:, cl] = orc.vec_mul(GP, col, tw)
 
+    chunks = 1
+
+    def phase1_chunk(self, j, in_ptr, send_ptr, stream=0):
+        """column chunk j: columns [j*Cwc, (j+1)*Cwc) -> the contiguous piece [R][Cwc] at send[j*R*Cwc ..)"""
+        orc, n = self.orc, 1 << self.log2n
+        cwc = self.Cw // self.chunks
+        x = self._view(in_ptr).reshape(self.R, self.Cw)
+        piece = self._view(send_ptr)[j * self.R * cwc:(j + 1) * self.R * cwc].reshape(self.R, cwc)
+        w = orc.primitive_root_of_unity(GP, GG, n)
+        if self.inv:
+            w = orc.inverse(GP, w)
+        for cc in range(cwc):
+            cl = j * cwc + cc
+            col = self._unscale(self._ntt(np.ascontiguousarray(x[:, cl])), self.R)
+            c = self.rank * self.Cw + cl
+            tw = np.array([orc.pow_(GP, w, (c * k1) % n) for k1 in range(self.R)], dtype=np.uint64)
+            piece[:, cc] = orc.vec_mul(GP, col, tw)
+
     def phase2(self, recv_ptr, out_ptr, stream=0):
         n = 1 << self.log2n
-        r = self._view(recv_ptr).reshape(self.world, self.Rw, self.Cw)
+        cwc = self.Cw // self.chunks
+        # block (g, j) = [Rw][Cwc]; global column c = g*Cw + j*Cwc + cc
+        r = self._view(recv_ptr).reshape(self.world, self.chunks, self.Rw, cwc).transpose(0, 2, 1, 3).reshape(self.world, self.Rw, self.Cw)
         out = self._view(out_ptr).reshape(self.C, self.Rw)
         for k1l in range(self.Rw):
             row = np.ascontiguousarray(r[:, k1l, :]).reshape(-1)          # c = g*Cw + cl
@@ -61,7 +81,7 @@ class OracleEngine:
             out[:, k1l] = y
 
 
-def _worker(rank, world, port, log2n, inverse, q):
+def _worker(rank, world, port, log2n, inverse, q, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -70,7 +90,7 @@ def _worker(rank, world, port, log2n, inverse, q):
         from conftest import splitmix_field
         from ronkathon_amd import dist as rdist
         x = splitmix_field(0xD157 + log2n, 1 << log2n)
-        fs = rdist.FourStepNTT(log2n, inverse=inverse, engine=OracleEngine(log2n, inverse, rank, world))
+        fs = rdist.FourStepNTT(log2n, inverse=inverse, engine=OracleEngine(log2n, inverse, rank, world), chunks=chunks)
         loc = torch.from_numpy(rdist.scatter_input(x, rank, world).view(np.int64).copy())
         out = fs.transform(loc)
         got = np.zeros(1 << log2n, dtype=np.uint64)
@@ -93,12 +113,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("log2n,world,inverse", [(10, 2, False), (11, 2, True), (12, 4, False)])
-def test_fourstep_gloo(log2n, world, inverse):
+@pytest.mark.parametrize("log2n,world,inverse,chunks", [(10, 2, False, 1), (11, 2, True, 1), (12, 4, False, 1),
+                                                        (12, 2, False, 2), (14, 2, True, 4)])
+def test_fourstep_gloo(log2n, world, inverse, chunks):
+    """chunks > 1: the column-chunked exchange (one all-to-all per chunk, receive layout [source rank][chunk])"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, log2n, inverse, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log2n, inverse, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

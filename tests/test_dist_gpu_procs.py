@@ -14,7 +14,7 @@ from test_dist_gloo import _free_port
 GP, GG = 0xFFFFFFFF00000001, 7
 
 
-def _worker(rank, world, port, log2n, inverse, q):
+def _worker(rank, world, port, log2n, inverse, q, chunks=1):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -26,7 +26,7 @@ def _worker(rank, world, port, log2n, inverse, q):
         from ronkathon_amd import dist as rdist
         torch.cuda.set_device(0)
         x = splitmix_field(0xD15C + log2n, 1 << log2n)
-        fs = rdist.FourStepNTT(log2n, inverse=inverse)                 # default engine: HipEngine
+        fs = rdist.FourStepNTT(log2n, inverse=inverse, chunks=chunks)  # default engine: HipEngine
         loc = torch.from_numpy(rdist.scatter_input(x, rank, world).view(np.int64).copy()).cuda()
         out = fs.transform(loc)
         torch.cuda.synchronize()
@@ -42,12 +42,12 @@ def _worker(rank, world, port, log2n, inverse, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log2n,world,inverse", [(16, 2, False), (18, 4, True), (20, 8, False)])
-def test_fourstep_hip_engine_rank_processes(log2n, world, inverse):
+@pytest.mark.parametrize("log2n,world,inverse,chunks", [(16, 2, False, 1), (18, 4, True, 1), (20, 8, False, 1), (20, 4, False, 4)])
+def test_fourstep_hip_engine_rank_processes(log2n, world, inverse, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, log2n, inverse, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, log2n, inverse, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

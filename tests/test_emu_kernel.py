@@ -94,6 +94,9 @@ def test_dist_phases(emu):
     for k, w, inv in ((12, 1, 0), (13, 2, 0), (16, 4, 1), (20, 8, 0)):
         run(emu, "dist", k, w, inv)
     run(emu, "dist", 16, 4, 0, 24)
+    # column-chunked exchange layout (ronk_sharded_*, ronk_dist_plan_create_chunked): emu_tile dist k W inv twf chunks
+    for k, w, inv, chunks in ((16, 4, 0, 2), (16, 2, 1, 4), (20, 8, 0, 4), (20, 2, 1, 8)):
+        run(emu, "dist", k, w, inv, 0, chunks)
 
 
 def test_gl64_field_arithmetic_edges():

@@ -360,6 +360,69 @@ def test_dist_fourstep_single_gpu(R, orc):
         assert np.array_equal(got, ref), (log2n, world, inv)
 
 
+def test_sharded_transform_inside_the_library(R, orc):
+    """ronk_sharded_*: the whole four-step (phase 1 in column chunks, peer-copy exchange on copy streams, phase 2) behind
+    the C ABI.  Logical ranks share the one GPU here (devices = [0]*W: a peer copy to the same device is a plain copy), so
+    the stream/event choreography, the chunked block layout and the scatter/gather run exactly as on a node; with >= 2
+    devices the same test also runs on distinct ones."""
+    from ronkathon_amd import _lib as L
+    ndev = R.device_count()
+    cases = [(12, 1, 1, False), (16, 2, 0, False), (16, 4, 2, True), (18, 8, 1, False), (20, 8, 4, False), (20, 4, 0, True),
+             (26, 8, 2, False)]
+    for log2n, W, chunks, inv in cases:
+        x = splitmix_field(0x5EED0500 + log2n + W, 1 << log2n)
+        ref = orc.ifft(GP, GG, x) if inv else orc.fft(GP, GG, x)
+        layouts = [[0] * W] + ([[g % ndev for g in range(W)]] if ndev >= 2 else [])
+        for devs in layouts:
+            sp = L.ShardedPlan(log2n, devs, inverse=inv, chunks=chunks)
+            assert sp.R * sp.C == 1 << log2n and sp.per_rank * W == 1 << log2n
+            assert np.array_equal(sp.transform(x), ref), (log2n, W, chunks, inv, devs)
+            if log2n <= 20:
+                assert np.array_equal(sp.transform(x), ref)     # second call reuses the send/receive buffers (event guards)
+            sp.close()
+    with pytest.raises(R.RonkPanic) as e:
+        L.ShardedPlan(10, [0] * 8)          # 32 columns over 8 ranks: fewer than 16 per rank
+    assert e.value.code == -9
+    with pytest.raises(R.RonkPanic) as e:
+        L.ShardedPlan(16, [0, 99])
+    assert e.value.code == -7
+
+
+def test_sharded_device_api_pipelines_calls(R, orc):
+    """ronk_ntt_sharded_dev: device-resident column blocks in, [C][R/W] blocks out; two transforms enqueued back to back
+    on the plan's own streams, then one sync"""
+    import ctypes as C
+    from ronkathon_amd import _lib as L
+    from ronkathon_amd.dist import scatter_input, place_output
+    log2n, W = 18, 4
+    sp = L.ShardedPlan(log2n, [0] * W, chunks=2)
+    xs = [splitmix_field(0x5EED0600 + i, 1 << log2n) for i in range(2)]
+    per = sp.per_rank
+    bufs = []
+    for x in xs:
+        din, dout = [], []
+        for g in range(W):
+            a, b = C.c_void_p(), C.c_void_p()
+            L.check(L.lib.ronk_dev_alloc(C.byref(a), per * 8)); L.check(L.lib.ronk_dev_alloc(C.byref(b), per * 8))
+            loc = scatter_input(x, g, W)
+            L.check(L.lib.ronk_memcpy_h2d(a, L.ptr(loc), per * 8))
+            din.append(a.value); dout.append(b.value)
+        bufs.append((din, dout))
+    for din, dout in bufs:
+        sp.transform_dev(din, dout)
+    sp.sync()
+    for x, (din, dout) in zip(xs, bufs):
+        got = np.zeros(1 << log2n, dtype=np.uint64)
+        for g in range(W):
+            o = np.empty(per, dtype=np.uint64)
+            L.check(L.lib.ronk_memcpy_d2h(L.ptr(o), dout[g], per * 8))
+            place_output(got, o, g, W)
+        assert np.array_equal(got, orc.fft(GP, GG, x))
+        for q in din + dout:
+            L.lib.ronk_dev_free(q)
+    sp.close()
+
+
 def test_determinism(R):
     from ronkathon_amd import _lib as L
     x = splitmix_field(1234, 1 << 20)

@@ -184,6 +184,53 @@ static void two_pass_ablation(int log2n, u64 batch, int max_logc, u64** keep_in,
   *keep_in = d_in; *keep_out = d_out;
 }
 
+// staggered start: the second workgroup of a CU (HW_ID.tg_id odd) sleeps `delay` x 64 cycles before it touches memory, so
+// that its load/store phases fall under the other workgroup's arithmetic (C = 4 tiles: two workgroups per CU)
+template <int LOGR, int LOGC, int KIND>
+__global__ void __launch_bounds__(1024) stagger_kernel(const TileArgs a, int delay, u32* hist) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u32 nb = gridDim.x, b = blockIdx.x;
+  const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+  const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const u32 tg = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);   // HW_REG_HW_ID[19:16] = workgroup slot on the CU
+  if (hist && threadIdx.x == 0) atomicAdd(&hist[tg & 15], 1u);
+  if ((tg & 1) && delay > 0)
+    for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(1);
+  tile_body<LOGR, false, 0, TileCfg<LOGC, KIND>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+}
+static void stagger_sweep() {
+  u64 *d_in = nullptr, *d_out = nullptr;
+  PlanDesc pd = build_plan(22, 1, false, 2, 18);
+  const size_t n = (size_t)1 << 22;
+  u64 *din, *dtmp, *dout; CK(hipMalloc(&din, n * 8)); CK(hipMalloc(&dtmp, n * 8)); CK(hipMalloc(&dout, n * 8));
+  CK(hipMemset(din, 1, n * 8)); CK(hipMemset(dtmp, 1, n * 8));
+  std::vector<u64*> d_wr;
+  for (auto& t : pd.wr) { u64* d; CK(hipMalloc(&d, t.size() * 8)); CK(hipMemcpy(d, t.data(), t.size() * 8, hipMemcpyHostToDevice)); d_wr.push_back(d); }
+  u64 *lo, *hi;
+  CK(hipMalloc(&lo, pd.tw[0].lo.size() * 8)); CK(hipMemcpy(lo, pd.tw[0].lo.data(), pd.tw[0].lo.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&hi, pd.tw[0].hi.size() * 8)); CK(hipMemcpy(hi, pd.tw[0].hi.data(), pd.tw[0].hi.size() * 8, hipMemcpyHostToDevice));
+  u32* hist; CK(hipMalloc(&hist, 64)); CK(hipMemset(hist, 0, 64));
+  CK(hipFuncSetAttribute((const void*)stagger_kernel<11, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)stagger_kernel<11, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  TileArgs a0 = pd.passes[0].args, a1 = pd.passes[1].args;
+  a0.in = din; a0.out = dtmp; a0.wr = d_wr[pd.passes[0].wr_id]; a0.tw_lo = lo; a0.tw_hi = hi;
+  a1.in = dtmp; a1.out = dout; a1.wr = d_wr[pd.passes[1].wr_id];
+  printf("== staggered start, 2^22, C = 4 tiles (grid %u x %u threads, %zu B LDS): delay in units of 64 cycles\n", pd.passes[0].grid, pd.passes[0].block, pd.passes[0].lds_bytes);
+  hipLaunchKernelGGL((stagger_kernel<11, 2, 1>), dim3(pd.passes[0].grid), dim3(pd.passes[0].block), pd.passes[0].lds_bytes, 0, a0, 0, hist);
+  CK(hipDeviceSynchronize());
+  u32 h[16]; CK(hipMemcpy(h, hist, 64, hipMemcpyDeviceToHost));
+  printf("  tg_id histogram:"); for (int i = 0; i < 16; i++) printf(" %u", h[i]); printf("\n");
+  for (int delay : {0, 20, 40, 60, 80, 100, 140, 180}) {
+    float p0 = time_launch([&] { hipLaunchKernelGGL((stagger_kernel<11, 2, 1>), dim3(pd.passes[0].grid), dim3(pd.passes[0].block), pd.passes[0].lds_bytes, 0, a0, delay, (u32*)nullptr); }, 50);
+    float p1 = time_launch([&] { hipLaunchKernelGGL((stagger_kernel<11, 2, 2>), dim3(pd.passes[1].grid), dim3(pd.passes[1].block), pd.passes[1].lds_bytes, 0, a1, delay, (u32*)nullptr); }, 50);
+    float both = time_launch([&] {
+      hipLaunchKernelGGL((stagger_kernel<11, 2, 1>), dim3(pd.passes[0].grid), dim3(pd.passes[0].block), pd.passes[0].lds_bytes, 0, a0, delay, (u32*)nullptr);
+      hipLaunchKernelGGL((stagger_kernel<11, 2, 2>), dim3(pd.passes[1].grid), dim3(pd.passes[1].block), pd.passes[1].lds_bytes, 0, a1, delay, (u32*)nullptr); }, 50);
+    printf("  delay %3d (%.2f us)  pass 0 %7.2f  pass 1 %7.2f  transform %7.2f us\n", delay, delay * 64 / 2400.0, p0, p1, both);
+  }
+  (void)d_in; (void)d_out;
+}
+
 // per-wave issue rate: the math-only body (ABL = 56) with 1 / 2 / 4 waves per SIMD -- one workgroup per CU (LDS request
 // forced to 136 KiB), 256 workgroups; every lane does the same work, so time ~ waves/SIMD when the VALU is saturated and
 // constant when a wave is latency-bound.
@@ -207,6 +254,7 @@ static void occupancy_sweep(const char* what) {
 int main(int argc, char** argv) {
   g_generic = getenv("RONK_NO_CFG_KERNELS") != nullptr;
   int max_logc = argc > 1 ? atoi(argv[1]) : 4;
+  if (argc == 2 && atoi(argv[1]) == -2) { stagger_sweep(); return 0; }
   if (argc == 2 && atoi(argv[1]) == -1) { occupancy_sweep<56>("math only"); occupancy_sweep<120>("math only, no table loads"); return 0; }
   if (argc == 3) {   // ubench <max_logc> <log2n in {8, 10, 12}>: single-pass batched ablation over 2^24 coefficients
     const int k = atoi(argv[2]);
