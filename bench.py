@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="polynomials per launch (default: 1, batch16: 1024)")
     ap.add_argument("--streams", type=int, default=2, help="independent transforms in flight (HIP streams)")
+    ap.add_argument("--ranks", type=int, default=0, help="sharded: logical ranks (default: one per visible GPU)")
+    ap.add_argument("--chunks", type=int, default=0, help="sharded: column chunks of the exchange (0 = default, up to 4)")
     ap.add_argument("--samples", type=int, default=5, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed plans")
     args = ap.parse_args()
@@ -224,6 +226,44 @@ def main():
             print(json.dumps(res))
         if world > 1:
             dist.destroy_process_group()
+        return
+
+    if wl == "sharded":
+        # the in-library sharded transform (ronk_sharded_*): ONE process drives every visible GPU (or --ranks logical ranks
+        # on the GPUs there are), peer-copy exchange in column chunks; device-resident blocks, K transforms pipelined
+        import ctypes as C
+        ndev = torch.cuda.device_count()
+        W = args.ranks or ndev
+        lg = args.log2n or 26
+        sp = L.ShardedPlan(lg, [g % ndev for g in range(W)], chunks=args.chunks)
+        per = sp.per_rank
+        din, dout = [], []
+        for g in range(W):
+            torch.cuda.set_device(g % ndev)
+            a_ = torch.from_numpy(synth(per, 0x5EED3000 + g).view(np.int64)).cuda()
+            din.append(a_); dout.append(torch.empty_like(a_))
+        ip, op = [t.data_ptr() for t in din], [t.data_ptr() for t in dout]
+        for _ in range(args.warmup):
+            sp.transform_dev(ip, op)
+        sp.sync()
+        dts = []
+        for _ in range(max(1, args.samples)):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sp.transform_dev(ip, op)
+            sp.sync()
+            dts.append(time.perf_counter() - t0)
+        dt = float(np.median(dts))
+        nn = 1 << lg
+        print(json.dumps({"metric": "sharded four-step forward NTTs/s (in-library, single process), degree 2^%d" % lg,
+                          "value": args.steps / dt, "unit": "NTT/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": min(dts) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                          "config": {"workload": "four-step NTT n = 2^%d over %d rank(s) on %d GPU(s), hipMemcpyPeerAsync mesh, "
+                                                 "%d column chunk(s)" % (lg, W, ndev, sp.chunks), "ranks": W, "chunks": sp.chunks},
+                          "roofline": {"bound": "hbm", "achieved": 16.0 * nn / ndev / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": 16.0 * nn / ndev / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None}}))
+        sp.close()
         return
 
     wl_log2n, wl_batch, wl_bytes_per_n, wl_unit, wl_kernel = WORKLOADS[wl]

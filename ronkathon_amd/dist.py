@@ -213,13 +213,20 @@ def fourstep_single_process(x, world, inverse=False):
     return out
 
 
-def bench_fourstep(log2n, steps, warmup):
-    """one sharded forward NTT per step across all ranks of the default process group"""
+def bench_fourstep(log2n, steps, warmup, chunks=None):
+    """one sharded forward NTT per step across all ranks of the default process group; the exchange runs in column
+    chunks (default: up to 4) so that it overlaps phase 1"""
+    import os
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    fs = FourStepNTT(log2n)
+    if chunks is None:
+        chunks = int(os.environ.get("RONK_FOURSTEP_CHUNKS", "4"))
+    Cw = shape(log2n, world)[3]
+    while chunks > 1 and (Cw // chunks < 16 or world == 1):
+        chunks //= 2
+    fs = FourStepNTT(log2n, chunks=max(1, chunks))
     rng = np.random.default_rng(1000 + rank)
     loc = torch.from_numpy((rng.integers(0, 2**63, size=fs.per_rank, dtype=np.uint64)).view(np.int64)).cuda()
     send, recv, out = torch.empty_like(loc), torch.empty_like(loc), torch.empty_like(loc)
@@ -245,6 +252,7 @@ def bench_fourstep(log2n, steps, warmup):
     return {"metric": "sharded four-step forward NTTs/s, degree 2^%d" % log2n, "value": steps / dt, "unit": "NTT/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "four-step NTT n = 2^%d sharded over %d GPUs, RCCL all-to-all transpose" % (log2n, world)},
+            "config": {"workload": "four-step NTT n = 2^%d sharded over %d GPUs, RCCL all-to-all transpose in %d column chunk(s)"
+                                   % (log2n, world, fs.chunks), "chunks": fs.chunks},
             "roofline": {"bound": "hbm", "achieved": 16.0 * n / world / (dt / steps) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": 16.0 * n / world / (dt / steps) / 1e9 / 8000.0, "traffic": None}}

@@ -1,0 +1,22 @@
+//! ronk-goldilocks: the reference-side binding of libronk_ntt.so (MI355X-native NTT / polynomial engine).
+//!
+//! * [`field::Goldilocks`] -- a 64-bit implementor of ronkathon's `Finite` / `Field` / `FiniteField`
+//!   (src/algebra/mod.rs:8-13, src/algebra/field/mod.rs:17-76) with every operator, conversion, `Display`, `FromStr` and
+//!   `Distribution` impl `PrimeField<P>` has (src/algebra/field/prime/{mod,arithmetic}.rs).  Generic code --
+//!   `Polynomial<B, F, D>`, `src/kzg`, `src/codes` -- compiles against it unchanged.
+//! * [`polynomial::Accelerated`] / [`polynomial::AcceleratedLagrange`] -- `fft` / `ifft` / `dft` / `Mul` / `Div` / `Rem` /
+//!   `evaluate` on the GPU through the C ABI (include/ronk_ntt.h), bit-exact with the reference's CPU results.
+//! * `in_tree/` -- how the same bodies become specialisations when vendored inside ronkathon, so call sites do not change.
+//!
+//! The nightly features mirror ronkathon's own (src/lib.rs:15-24); `generic_const_exprs` is needed for `D + D2 - 1`.
+#![allow(incomplete_features)]
+#![feature(generic_const_exprs)]
+#![feature(const_trait_impl)]
+#![feature(effects)]
+
+pub mod ffi;
+pub mod field;
+pub mod polynomial;
+
+pub use field::Goldilocks;
+pub use polynomial::{rs_decode, Accelerated, AcceleratedLagrange};
