@@ -13,6 +13,7 @@
 // a pool block reused across calls -- 4 of 12 test runs -- while plain allocations never did.)
 struct WsSlot {
   void* p = nullptr;
+  u32* ctl = nullptr;   // 64 bytes of control words, ZERO whenever the slot is not in use (fused scan kernels)
   size_t bytes = 0;
   int device = -1;
   hipEvent_t done = nullptr;
@@ -54,8 +55,10 @@ struct WsLease {
     if (!slot) {
       WsSlot* w = new WsSlot();
       hipError_t e = hipMalloc(&w->p, need);
+      if (e == hipSuccess) e = hipMalloc((void**)&w->ctl, 64);
+      if (e == hipSuccess) e = hipMemset(w->ctl, 0, 64);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
-      if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); delete w; return hip_fail(e, "workspace"); }
+      if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); if (w->ctl) (void)hipFree(w->ctl); delete w; return hip_fail(e, "workspace"); }
       w->bytes = need; w->device = dev;
       g_ws.push_back(w);
       slot = w;
@@ -64,7 +67,22 @@ struct WsLease {
     return RONK_OK;
   }
   u64* u() const { return (u64*)slot->p; }
+  u32* ctl() const { return slot->ctl; }
 };
+static void make_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
+  u64 x = 1 % p;
+  for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
+  t->z256 = x;
+  u64 y = t->zt[8];
+  for (int s = 0; s < 8; s++) { t->z8p[s] = y; y = h_mulmod(y, y, p); }
+  y = h_powmod(z, FCH, p);
+  for (int s = 0; s < 20; s++) { t->Yp[s] = y; y = h_mulmod(y, y, p); }
+  t->z = z % p;
+  t->scale = scale;
+}
+// fused paths (scan_kernels.h): evaluate in one launch up to 2^20 chunks; division in two launches up to 4096 chunks
+static const size_t FUSED_EVAL_MAX = (size_t)FCH << 20, FUSED_DIV_MAX = (size_t)FCH * 4096;
+static const bool g_no_fused_scans = getenv("RONK_NO_FUSED_SCANS") != nullptr;   // experiments / A-B
 static void make_horner_tab(u64 p, u64 z, u64 scale, HornerTab* t) {
   u64 x = 1 % p;
   for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
@@ -98,6 +116,19 @@ extern "C" int ronk_poly_eval_dev(uint64_t p, const uint64_t* d_c, size_t d, uin
   RCHK(make_field(p, &f));
   hipStream_t s = (hipStream_t)stream;
   if (d == 0) { HIPCHK(hipMemsetAsync(d_out, 0, 8, s)); return RONK_OK; }
+  if (d <= FUSED_EVAL_MAX && !g_no_fused_scans) {   // weighted chunk sums + a plain sum
+    const size_t nch = (d + FCH - 1) / FCH;
+    HornerTab2 tab2;
+    make_horner_tab2(p, x % p, 1, &tab2);
+    WsLease ws;
+    RCHK(ws.acquire(nch * 8, s));
+    FIELD_DISPATCH(f, {
+      hipLaunchKernelGGL((weighted_chunk_sum8_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d, tab2, ws.u());
+      hipLaunchKernelGGL((partial_sum_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ws.u(), nch, d_out);
+    });
+    HIPCHK(hipGetLastError());
+    return RONK_OK;
+  }
   const size_t nchunks = (d + HCHUNK - 1) / HCHUNK;
   HornerTab tab;
   make_horner_tab(p, x % p, 1, &tab);
@@ -135,6 +166,20 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
   hipStream_t s = (hipStream_t)stream;
   const u64 b1inv = h_powmod(b1, p - 2, p);
   const u64 z = h_mulmod((p - b0) % p, b1inv, p);        // -b0 / b1
+  if (d <= FUSED_DIV_MAX && !g_no_fused_scans) {   // two launches: chunk sums, then carry + recurrence per chunk
+    const size_t nch = (d + FCH - 1) / FCH;
+    HornerTab2 tab2;
+    make_horner_tab2(p, z, b1inv, &tab2);
+    WsLease ws;
+    RCHK(ws.acquire(nch * 8, s));
+    FIELD_DISPATCH(f, {
+      hipLaunchKernelGGL((chunk_sum8_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d, tab2, ws.u());
+      hipLaunchKernelGGL((lindiv_fused_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d, tab2, ws.u(), d_quot,
+                         d_rem);
+    });
+    HIPCHK(hipGetLastError());
+    return RONK_OK;
+  }
   const size_t nchunks = (d + HCHUNK - 1) / HCHUNK;
   HornerTab tab;
   make_horner_tab(p, z, b1inv, &tab);
@@ -175,6 +220,76 @@ extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t*
   return RONK_OK;
 }
 
+// ------------------------------------------------------------------------------ fast general division (Goldilocks)
+// quotient_and_remainder (polynomial/mod.rs:170-225) in O(n log n) on the NTT path, for divisors that are not linear:
+//   Q = rev( rev(a) * inv(rev(b)) mod x^L ),  L = deg a - deg b + 1,   inv by Newton iteration g <- g + g*(1 - f*g),
+// every product through ronk_poly_mul_dev (cached plans).  Used only when the divisor's last coefficient is non-zero
+// (D2 = deg b + 1): then the reference's loop -- which compares the remainder's trimmed length with the divisor's
+// UNTRIMMED length (mod.rs:184-186) and indexes p_coeffs[diff + i] over all D2 divisor entries -- is plain Euclidean
+// division.  A divisor with trailing zero coefficients makes the reference stop early or panic (index out of bounds in
+// its second iteration); those inputs stay on poly_divrem_kernel, which follows the loop statement by statement.
+__global__ void __launch_bounds__(256) dv_reverse_kernel(const u64* __restrict__ in, size_t top, u64* __restrict__ out, size_t len) {
+  // out[i] = in[top - i] for i < len (coefficients above the source read as ZERO: top - i < 0 never happens, len <= top + 1)
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = in[top - i];
+}
+__global__ void __launch_bounds__(256) dv_neg_kernel(const u64* __restrict__ in, u64* __restrict__ out, size_t len) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = gl64::neg(in[i]);
+}
+__global__ void __launch_bounds__(256) dv_fill_kernel(u64* __restrict__ out, size_t len, u64 v0) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = i == 0 ? v0 : 0;
+}
+// quot[i] = (i >= t && i < L) ? qrev[L - 1 - i] : 0   for i < d     (reverse back, clear below t)
+__global__ void __launch_bounds__(256) dv_quot_kernel(const u64* __restrict__ qrev, size_t L, size_t t, u64* __restrict__ quot, size_t d) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < d; i += (size_t)gridDim.x * blockDim.x)
+    quot[i] = (i >= t && i < L) ? qrev[L - 1 - i] : 0;
+}
+// rem[i] = a[i] - prod[i] (prod has plen entries)
+__global__ void __launch_bounds__(256) dv_rem_kernel(const u64* __restrict__ a, const u64* __restrict__ prod, size_t plen, u64* __restrict__ rem, size_t d) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < d; i += (size_t)gridDim.x * blockDim.x)
+    rem[i] = i < plen ? gl64::sub(a[i], prod[i]) : a[i];
+}
+
+// a: d coefficients with degree n (a[n] != 0), b: degree m (b[m] != 0), n >= m.  d_quot / d_rem: d coefficients each.
+static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b, size_t d2, size_t m, u64 lead_inv, u64* d_quot,
+                             u64* d_rem, hipStream_t s) {
+  const u64 P = RONK_GOLDILOCKS_P, G = RONK_GOLDILOCKS_G;
+  const size_t L = n - m + 1;                       // coefficients of the true quotient
+  size_t Lp = 1; while (Lp < L) Lp <<= 1;           // Newton runs to a power-of-two precision
+  DevBuf f, g, e, h, t1, ar;
+  RCHK(f.alloc(Lp * 8)); RCHK(g.alloc(2 * Lp * 8)); RCHK(e.alloc(4 * Lp * 8)); RCHK(h.alloc(Lp * 8));
+  RCHK(t1.alloc(2 * Lp * 8)); RCHK(ar.alloc((L > d ? L : d) * 8 + 8));
+  // f = rev(b) mod x^Lp: f[i] = b[m - i] for i <= min(m, Lp - 1), ZERO above
+  HIPCHK(hipMemsetAsync(f.p, 0, Lp * 8, s));
+  const size_t flen = (m + 1 < Lp) ? m + 1 : Lp;
+  hipLaunchKernelGGL(dv_reverse_kernel, dim3(grid_for(flen)), dim3(256), 0, s, d_b, m, f.u(), flen);
+  // g = 1 / f[0] = 1 / lead(b)   (precision 1)
+  hipLaunchKernelGGL(dv_fill_kernel, dim3(grid_for(2 * Lp)), dim3(256), 0, s, g.u(), 2 * Lp, lead_inv);
+  for (size_t k = 1; k < Lp; k <<= 1) {
+    // e = f[0:2k] * g[0:k]: coefficients [k, 2k) are the error term (the low k are [1, 0, ..])
+    RCHK(ronk_poly_mul_dev(P, G, f.u(), 2 * k, g.u(), k, e.u(), s));
+    hipLaunchKernelGGL(dv_neg_kernel, dim3(grid_for(k)), dim3(256), 0, s, e.u() + k, h.u(), k);
+    // g[k:2k] = (g[0:k] * h)[0:k]
+    RCHK(ronk_poly_mul_dev(P, G, g.u(), k, h.u(), k, t1.u(), s));
+    HIPCHK(hipMemcpyAsync(g.u() + k, t1.p, k * 8, hipMemcpyDeviceToDevice, s));
+  }
+  // qrev = (rev(a)[0:L] * g[0:L])[0:L]
+  hipLaunchKernelGGL(dv_reverse_kernel, dim3(grid_for(L)), dim3(256), 0, s, d_a, n, ar.u(), L);
+  DevBuf qr;
+  RCHK(qr.alloc(2 * L * 8));
+  RCHK(ronk_poly_mul_dev(P, G, ar.u(), L, g.u(), L, qr.u(), s));
+  const size_t t = 0;                               // d2 == m + 1: every quotient coefficient is produced
+  (void)d2;
+  hipLaunchKernelGGL(dv_quot_kernel, dim3(grid_for(d)), dim3(256), 0, s, qr.u(), L, t, d_quot, d);
+  // rem = a - quot[0:L] * b[0:m+1]
+  DevBuf prod;
+  RCHK(prod.alloc((L + m + 1) * 8));
+  RCHK(ronk_poly_mul_dev(P, G, d_quot, L, d_b, m + 1, prod.u(), s));
+  hipLaunchKernelGGL(dv_rem_kernel, dim3(grid_for(d)), dim3(256), 0, s, d_a, prod.u(), L + m, d_rem, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));                  // the DevBufs above are freed on return
+  return RONK_OK;
+}
+
 extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,
                                 uint64_t* rem) {
   if (!a || !b || !quot || !rem || d == 0 || d2 == 0) return RONK_ERR_INVALID;
@@ -191,6 +306,26 @@ extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const u
     memset(rem, 0, d * 8);
     HIPCHK(hipMemcpy(rem, dr.p, 8, hipMemcpyDeviceToHost));
     return RONK_OK;
+  }
+  // general divisor over Goldilocks, large enough for the O(n log n) form to win: Newton inversion on the NTT path.
+  // Zero operands, short dividends and the reference's panics keep going through the long-division kernel below,
+  // which follows the reference loop statement by statement.
+  if (f.kind == F_GL && d >= d2) {
+    size_t n = d, m = d2;
+    while (n > 0 && a[n - 1] % p == 0) n--;        // n = degree + 1 of the dividend (0: zero polynomial)
+    while (m > 0 && b[m - 1] % p == 0) m--;
+    if (n > 0 && m == d2 && n >= m && (n - m + 1) >= 2048 && m >= 64 && d <= ((size_t)1 << 27)) {
+      const size_t dn = n - 1, dm = m - 1;
+      DevBuf da, db2, dq2, dr2;
+      RCHK(da.alloc(d * 8)); RCHK(db2.alloc(d2 * 8)); RCHK(dq2.alloc(d * 8)); RCHK(dr2.alloc(d * 8));
+      HIPCHK(hipMemcpy(da.p, a, d * 8, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(db2.p, b, d2 * 8, hipMemcpyHostToDevice));
+      const u64 lead_inv = h_powmod(b[dm] % p, p - 2, p);   // rhs.leading_coefficient().inverse().unwrap(), mod.rs:181,196
+      RCHK(newton_divrem_dev(da.u(), d, dn, db2.u(), d2, dm, lead_inv, dq2.u(), dr2.u(), 0));
+      HIPCHK(hipMemcpy(quot, dq2.p, d * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(rem, dr2.p, d * 8, hipMemcpyDeviceToHost));
+      return RONK_OK;
+    }
   }
   DevBuf drem, db, dq, dst;
   RCHK(drem.alloc(d * 8)); RCHK(db.alloc(d2 * 8)); RCHK(dq.alloc(d * 8)); RCHK(dst.alloc(4));

@@ -423,6 +423,85 @@ def test_sharded_device_api_pipelines_calls(R, orc):
     sp.close()
 
 
+def test_fast_general_division_newton_vs_oracle(R, orc):
+    """ronk_poly_divrem for non-linear divisors over Goldilocks: Newton inversion on the NTT path (O(n log n)) against the
+    oracle's statement-by-statement restatement of quotient_and_remainder (reference src/polynomial/mod.rs:170-225),
+    including its quirks: with trailing zero coefficients in the divisor the reference's loop (which compares with and
+    indexes over the divisor's UNTRIMMED length) stops early or panics -- same code from the library."""
+    from ronkathon_amd import _lib as L
+    import ctypes as C
+
+    def divrem(a, b):
+        a, b = L.arr(a), L.arr(b)
+        q, r = np.empty_like(a), np.empty_like(a)
+        L.check(L.lib.ronk_poly_divrem(GP, L.ptr(a), a.size, L.ptr(b), b.size, L.ptr(q), L.ptr(r)))
+        return q, r
+
+    def z(v, k):
+        return np.concatenate([v, np.zeros(k, dtype=np.uint64)])
+
+    cases = [
+        (splitmix_field(1, 40000), splitmix_field(2, 9000)),                       # plain
+        (splitmix_field(3, 30000), z(splitmix_field(4, 3000), 500)),               # divisor with trailing zeros: early stop
+        (z(splitmix_field(5, 20000), 1234), splitmix_field(6, 700)),               # dividend with leading zeros
+        (z(splitmix_field(7, 6000), 4000), z(splitmix_field(8, 101), 7899)),       # short dividend, D >= D2: ONE step
+        (splitmix_field(9, 8192), splitmix_field(10, 4096)),
+        (splitmix_field(11, 5000), np.concatenate([np.zeros(99, dtype=np.uint64), np.ones(1, dtype=np.uint64), np.zeros(100, dtype=np.uint64)])),  # x^99
+    ]
+    for a, b in cases:
+        try:
+            oq, o_r = orc.poly_divrem(GP, a, b)
+        except orc.OraclePanic as e:
+            with pytest.raises(R.RonkPanic) as e2:
+                divrem(a, b)
+            assert e2.value.code == e.code, (a.size, b.size)
+            continue
+        q, r = divrem(a, b)
+        assert np.array_equal(q, oq) and np.array_equal(r, o_r), (a.size, b.size)
+    # 2^20 / 2^19: a == q b + r at random points, deg r < deg b, and the top quotient coefficients exactly
+    a, b = splitmix_field(21, 1 << 20), splitmix_field(22, 1 << 19)
+    q, r = divrem(a, b)
+    assert not r[b.size - 1:].any()
+    for pt in (5, 0xABCDEF0123456789 % GP):
+        lhs = orc.poly_eval(GP, a, pt)
+        rhs = orc.add(GP, orc.mul(GP, orc.poly_eval(GP, q, pt), orc.poly_eval(GP, b, pt)), orc.poly_eval(GP, r, pt))
+        assert lhs == rhs
+    top = orc.div(GP, int(a[-1]), int(b[-1]))
+    assert int(q[a.size - b.size]) == top and not q[a.size - b.size + 1:].any()
+
+
+def test_scan_paths_fused_and_three_kernel(R, orc):
+    """evaluate / division by a linear factor: the fused kernels (one / two launches, up to 2^23 coefficients for the
+    division) and the three-kernel form with the serial carry scan beyond that -- remainder == evaluation == oracle,
+    quotient through p(t) == q(t)(t - z) + r at a random point, sizes either side of the switch and ragged chunk tails"""
+    import ctypes as C
+    from ronkathon_amd import _lib as L
+    z = 0x0123456789ABCDEF % GP
+    for d in (1, 7, 2047, 2048, 2049, 4096 * 3 + 5, (1 << 20) + 123, (1 << 23) - 1, (1 << 23) + 17):
+        x = splitmix_field(0x5CA0 + d % 1000, d)
+        dc, dq, dr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        for h, nbytes in ((dc, d * 8), (dq, d * 8), (dr, 8)):
+            L.check(L.lib.ronk_dev_alloc(C.byref(h), nbytes))
+        L.check(L.lib.ronk_memcpy_h2d(dc, L.ptr(x), d * 8))
+        L.check(L.lib.ronk_poly_div_linear_dev(GP, dc, d, GP - z, 1, dq, dr, None))
+        L.check(L.lib.ronk_dev_sync())
+        q = np.empty(d, dtype=np.uint64); r = np.empty(1, dtype=np.uint64)
+        L.check(L.lib.ronk_memcpy_d2h(L.ptr(q), dq, d * 8)); L.check(L.lib.ronk_memcpy_d2h(L.ptr(r), dr, 8))
+        val = orc.poly_eval(GP, x, z)
+        assert int(r[0]) == val, d
+        assert int(q[d - 1]) == 0
+        t = 0xFEEDFACE12345 % GP
+        assert orc.poly_eval(GP, x, t) == orc.add(GP, orc.mul(GP, orc.poly_eval(GP, q, t), orc.sub(GP, t, z)), val), d
+        if d <= 5000:
+            assert np.array_equal(q, orc.kzg_open_quotient(GP, x, z)), d
+        L.check(L.lib.ronk_poly_eval_dev(GP, dc, d, z, dr, None))
+        L.check(L.lib.ronk_dev_sync())
+        L.check(L.lib.ronk_memcpy_d2h(L.ptr(r), dr, 8))
+        assert int(r[0]) == val, d
+        for h in (dc, dq, dr):
+            L.lib.ronk_dev_free(h)
+
+
 def test_determinism(R):
     from ronkathon_amd import _lib as L
     x = splitmix_field(1234, 1 << 20)
