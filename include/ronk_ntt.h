@@ -20,9 +20,11 @@
  *    synchronising;
  *  - the reference reports errors by panicking; here every function returns 0 or a negative
  *    RONK_ERR_* code, and the Rust shim turns a non-zero code back into the same panic;
- *  - re-entrant: plans are immutable after creation; concurrent calls on ONE plan must use
- *    different streams only if they do not share the plan's scratch buffer (see
- *    ronk_plan_create).
+ *  - re-entrant: plans are immutable after creation.  A plan owns ONE scratch buffer: calls on one stream are
+ *    ordered by the stream, and a `_dev` call that arrives on another stream than the plan's previous call is made
+ *    to wait (event) for that call, so concurrent streams never corrupt each other -- they serialise on the plan.
+ *    For transforms that should overlap, use one plan per stream.  (While a stream is being captured into a
+ *    hipGraph the guard is skipped: a captured graph must own its plan.)
  *  - the 64-bit hot path is the Goldilocks field p = 2^64 - 2^32 + 1 with generator g = 7;
  *    any other odd prime p < 2^64 (e.g. the reference's F_101, F_17, F_127) runs through a
  *    generic Montgomery path so that the reference's own test vectors pass on the GPU.

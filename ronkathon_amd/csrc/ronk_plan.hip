@@ -17,6 +17,7 @@ extern "C" int ronk_plan_destroy(ronk_plan* pl) {
   if (pl->d_stage_out) (void)hipFree(pl->d_stage_out);
   if (pl->d_wtab_f) (void)hipFree(pl->d_wtab_f);
   if (pl->d_wtab_i) (void)hipFree(pl->d_wtab_i);
+  if (pl->scratch_ev) (void)hipEventDestroy(pl->scratch_ev);
   delete pl;
   return RONK_OK;
 }
@@ -131,6 +132,22 @@ static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* ou
 int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s, u64 in_valid,
                   u64 out_valid) {
   if (!pl || !in || !out) return RONK_ERR_INVALID;
+  // The plan's scratch buffer is shared by every call on the plan.  Calls on ONE stream are ordered by the stream; when a
+  // call arrives on a different stream than the previous one, it is made to wait for that stream's tail (an event recorded
+  // there now, i.e. after the previous transform), so two streams can never interleave inside the scratch.  Costs
+  // nothing while a plan stays on one stream (the benchmarked pattern: one plan per stream).
+  if (pl->d_tmp && (pl->fast ? (inverse ? pl->inv : pl->fwd).pd.needs_tmp : true)) {
+    std::lock_guard<std::mutex> lk(pl->stream_mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (pl->scratch_used && pl->scratch_stream != s) (void)hipStreamIsCapturing(s, &cap);
+    // (a capturing stream cannot wait for an event recorded outside its capture: a captured graph owns its plan)
+    if (pl->scratch_used && pl->scratch_stream != s && cap == hipStreamCaptureStatusNone) {
+      if (!pl->scratch_ev) HIPCHK(hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(pl->scratch_ev, pl->scratch_stream));
+      HIPCHK(hipStreamWaitEvent(s, pl->scratch_ev, 0));
+    }
+    pl->scratch_stream = s; pl->scratch_used = true;
+  }
   if (pl->fast) {
     // in == out is safe: a single-pass plan rewrites exactly the tile it read; multi-pass plans
     // read BUF_IN only in pass 1 and write BUF_OUT only in the last pass.
@@ -250,42 +267,47 @@ struct CacheEntry {
   u64 *fa = nullptr, *fb = nullptr;  // poly_mul operands, n elements each (lazy)
   hipEvent_t done = nullptr;
   uint64_t stamp = 0;
+  int pins = 0;                      // users outside g_cache_mu (never evicted while pinned)
 };
 static std::mutex g_cache_mu;
-static std::vector<CacheEntry> g_cache;
+static std::vector<CacheEntry*> g_cache;   // heap entries: addresses stay valid while the vector changes
 static uint64_t g_cache_clock = 0;
 
-static void cache_entry_free(CacheEntry& e) {
-  if (e.pl) ronk_plan_destroy(e.pl);
-  if (e.fa) (void)hipFree(e.fa);
-  if (e.fb) (void)hipFree(e.fb);
-  if (e.done) (void)hipEventDestroy(e.done);
-  e = CacheEntry();
+static void cache_entry_free(CacheEntry* e) {
+  if (e->pl) ronk_plan_destroy(e->pl);
+  if (e->fa) (void)hipFree(e->fa);
+  if (e->fb) (void)hipFree(e->fb);
+  if (e->done) (void)hipEventDestroy(e->done);
+  delete e;
 }
 // caller holds g_cache_mu
 static int cache_get(u64 p, u64 g, u32 log2n, CacheEntry** out) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
-  for (auto& e : g_cache)
-    if (e.pl && e.pl->p == p && e.pl->g == g % p && e.pl->log2n == log2n && e.pl->batch == 1 && e.pl->device == dev) {
-      e.stamp = ++g_cache_clock;
-      *out = &e;
+  for (CacheEntry* e : g_cache)
+    if (e->pl && e->pl->p == p && e->pl->g == g % p && e->pl->log2n == log2n && e->pl->batch == 1 && e->pl->device == dev) {
+      e->stamp = ++g_cache_clock;
+      *out = e;
       return RONK_OK;
     }
-  if (g_cache.size() >= 8) {  // evict the least recently used entry (its work must have drained)
-    size_t lru = 0;
-    for (size_t i = 1; i < g_cache.size(); i++) if (g_cache[i].stamp < g_cache[lru].stamp) lru = i;
-    if (g_cache[lru].done) (void)hipEventSynchronize(g_cache[lru].done);
-    cache_entry_free(g_cache[lru]);
-    g_cache.erase(g_cache.begin() + lru);
+  if (g_cache.size() >= 8) {  // evict the least recently used entry nobody holds (its work must have drained)
+    size_t lru = g_cache.size();
+    for (size_t i = 0; i < g_cache.size(); i++)
+      if (g_cache[i]->pins == 0 && (lru == g_cache.size() || g_cache[i]->stamp < g_cache[lru]->stamp)) lru = i;
+    if (lru < g_cache.size()) {
+      if (g_cache[lru]->done) (void)hipEventSynchronize(g_cache[lru]->done);
+      cache_entry_free(g_cache[lru]);
+      g_cache.erase(g_cache.begin() + lru);
+    }
   }
-  CacheEntry e;
-  RCHK(ronk_plan_create(&e.pl, p, g, log2n, 1, -1));
-  hipError_t he = hipEventCreateWithFlags(&e.done, hipEventDisableTiming);
+  CacheEntry* e = new CacheEntry();
+  int rc = ronk_plan_create(&e->pl, p, g, log2n, 1, -1);
+  if (rc) { cache_entry_free(e); return rc; }
+  hipError_t he = hipEventCreateWithFlags(&e->done, hipEventDisableTiming);
   if (he != hipSuccess) { cache_entry_free(e); return hip_fail(he, "hipEventCreate"); }
-  e.stamp = ++g_cache_clock;
+  e->stamp = ++g_cache_clock;
   g_cache.push_back(e);
-  *out = &g_cache.back();
+  *out = e;
   return RONK_OK;
 }
 
@@ -297,12 +319,20 @@ static int fft_oneshot(bool inverse, u64 p, u64 g, const u64* in, u64* out, u64*
   if (p < 2) return RONK_ERR_INVALID;
   if ((p - 1) % n != 0) return RONK_ERR_NO_ROOT;
   RCHK(need_device());
+  // The cache lock covers the lookup only: the entry is pinned, the PCIe copies and the transform run under the plan's
+  // own lock (transform_host), so threads using different sizes (`cargo test`) do not serialise on one mutex.
+  CacheEntry* e = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    CacheEntry* e = nullptr;
     RCHK(cache_get(p, g, (u32)ilog2(n), &e));
-    RCHK(inverse ? ronk_ntt_inverse(e->pl, in, out) : ronk_ntt_forward(e->pl, in, out, nullptr));
+    e->pins++;
   }
+  const int rc = inverse ? ronk_ntt_inverse(e->pl, in, out) : ronk_ntt_forward(e->pl, in, out, nullptr);
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    e->pins--;
+  }
+  RCHK(rc);
   if (nodes) RCHK(ronk_lagrange_nodes(p, g, nodes, n));
   return RONK_OK;
 }

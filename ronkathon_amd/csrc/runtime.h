@@ -173,6 +173,11 @@ struct ronk_plan {
   u64* d_wtab_f = nullptr; u64* d_wtab_i = nullptr;
   u64 w_f = 0, w_i = 0, n_inv = 1;
   std::mutex mu;
+  // cross-stream guard of d_tmp (transform_dev)
+  std::mutex stream_mu;
+  hipStream_t scratch_stream = nullptr;
+  hipEvent_t scratch_ev = nullptr;
+  bool scratch_used = false;
 };
 
 // ronk_plan.hip

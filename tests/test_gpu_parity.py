@@ -550,6 +550,29 @@ def test_device_pointer_api_inplace_and_streams(R, orc):
     assert np.array_equal(dz.cpu().numpy().view(np.uint64), orc.vec_mul(GP, a, a))
 
 
+def test_one_plan_many_streams_is_safe(R, orc):
+    """one plan (one scratch buffer) driven from four streams at once without any host synchronisation in between:
+    the library orders the calls on the plan by events (include/ronk_ntt.h, "re-entrant"), so every result is exact"""
+    import torch
+    from ronkathon_amd import _lib as L
+    k = 20
+    n = 1 << k
+    plan = L.Plan(GP, GG, k)
+    xs = [splitmix_field(0x57A0 + i, n) for i in range(4)]
+    refs = [orc.fft(GP, GG, x) for x in xs]
+    dxs = [torch.from_numpy(x.view(np.int64)).cuda() for x in xs]
+    dys = [torch.empty_like(d) for d in dxs]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for i in range(4):
+            plan.forward_dev(dxs[i].data_ptr(), dys[i].data_ptr(), streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(dys[i].cpu().numpy().view(np.uint64), refs[i]), i
+    plan.close()
+
+
 def test_hipgraph_capture_of_dev_entry_points(R, orc):
     """the _dev entry points only enqueue kernels on the caller's stream, so they can be captured in a hipGraph
     (here through torch.cuda.CUDAGraph) and replayed; results equal the oracle on every replay"""
