@@ -19,3 +19,20 @@ clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean
+
+# Sanitizer builds of the host-side code: the oracle under ASan+UBSan, the field header and the
+# tile kernel body + planner (the host emulator) under UBSan (ASan does not follow the emulator's ucontext fibers).
+SAN = -g -O1 -fno-omit-frame-pointer -fno-sanitize-recover=all
+sanitize:
+	@mkdir -p build/san
+	gcc $(SAN) -fsanitize=address,undefined -o build/san/oracle_san tests/emu/oracle_san.c oracle/ronk_oracle.c
+	g++ $(SAN) -std=c++17 -fsanitize=address,undefined -o build/san/test_gl64_host tests/emu/test_gl64_host.cpp
+	gcc -O1 -c -o build/san/orc.o oracle/ronk_oracle.c
+	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_tile tests/emu/emu_tile.cpp build/san/orc.o
+	./build/san/oracle_san
+	./build/san/test_gl64_host
+	./build/san/emu_tile 12 3 0 4 | tail -1
+	./build/san/emu_tile 16 2 1 4 18 | tail -1
+	./build/san/emu_tile 20 1 0 3 | tail -1
+	./build/san/emu_tile dist 16 4 0 0 2 | tail -1
+.PHONY: sanitize
