@@ -215,6 +215,30 @@ int ronk_dist_phase1_dev(ronk_dist_plan* plan, const uint64_t* d_in, uint64_t* d
  * each local row k1; d_out[k2*(R/world) + (k1 - k1_0)] = X[k1 + R*k2] */
 int ronk_dist_phase2_dev(ronk_dist_plan* plan, const uint64_t* d_recv, uint64_t* d_out, void* stream);
 
+/* ---- device-resident forms of the callers above: no allocation, copy or synchronisation per call (workspace from an
+ *      event-guarded pool), asynchronous on `stream`.  Conditions the reference reports by panicking are reported through a
+ *      caller-owned device word `d_status` (the caller zeroes it and reads it when it synchronises; NULL where noted =
+ *      "do not care"): non-zero = RONK_ERR_ZERO_INVERSE unless stated otherwise.  Inputs must be canonical residues. ---- */
+int ronk_vec_neg_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_out, size_t n, void* stream);
+int ronk_vec_pow_dev(uint64_t p, const uint64_t* d_a, uint64_t e, uint64_t* d_out, size_t n, void* stream);
+int ronk_vec_inv_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_out, size_t n, int* d_status, void* stream);
+/* Polynomial::dft (polynomial/mod.rs:240-258) for any n | p-1; see ronk_dft for the size limits */
+int ronk_dft_dev(uint64_t p, uint64_t g, const uint64_t* d_in, uint64_t* d_out, size_t n, void* stream);
+/* Polynomial::<Lagrange<F>>::evaluate (polynomial/mod.rs:382-415); d_out = ONE element; d_status may be NULL */
+int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uint64_t* d_nodes, size_t n, uint64_t x, uint64_t* d_out,
+                           int* d_status, void* stream);
+/* quotient_and_remainder (polynomial/mod.rs:170-225) by the long-division kernel (any divisor); *d_status (required)
+ * receives 0 or the RONK_ERR_* code of the reference's panic; d_rem may alias d_a */
+int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2, uint64_t* d_quot,
+                         uint64_t* d_rem, int* d_status, void* stream);
+/* Message::decode (src/codes/reed_solomon.rs:54-106); d_status may be NULL */
+int ronk_rs_decode_dev(uint64_t p, const uint64_t* d_xs, const uint64_t* d_ys, size_t k, uint64_t* d_out, int* d_status,
+                       void* stream);
+/* kzg::commit (src/kzg/setup.rs:45-60); *d_status (required): bit 0 = RONK_ERR_NOT_ON_CURVE, bit 1 = RONK_ERR_ZERO_INVERSE.
+ * With ronk_poly_div_linear_dev, kzg::open (setup.rs:63-78) never leaves the device. */
+int ronk_curve_msm_dev(const ronk_curve* curve, const uint64_t* d_points, size_t n_points, const uint64_t* d_scalars, size_t n,
+                       uint64_t* d_out, int* d_status, void* stream);
+
 /* ---- the sharded transform as ONE call for a single-process host (the Rust host of BASELINE config 5): rank g of
  *      ndev = devices[g]; the exchange is a mesh of peer copies over xGMI issued by the library on per-device copy
  *      streams, in `chunks` column chunks so that a chunk travels while the next one is computed (chunks <= 0: default,

@@ -97,6 +97,14 @@ _SIG = {
     "ronk_dist_phase1_chunk_dev": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_dist_phase2_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "ronk_vec_neg_dev": (_int, [_u64, _vp, _vp, _sz, _vp]),
+    "ronk_vec_pow_dev": (_int, [_u64, _vp, _u64, _vp, _sz, _vp]),
+    "ronk_vec_inv_dev": (_int, [_u64, _vp, _vp, _sz, _vp, _vp]),
+    "ronk_dft_dev": (_int, [_u64, _u64, _vp, _vp, _sz, _vp]),
+    "ronk_lagrange_eval_dev": (_int, [_u64, _vp, _vp, _sz, _u64, _vp, _vp, _vp]),
+    "ronk_poly_divrem_dev": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "ronk_rs_decode_dev": (_int, [_u64, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "ronk_curve_msm_dev": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "ronk_sharded_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int]),
     "ronk_sharded_plan_destroy": (_int, [_vp]),
     "ronk_sharded_plan_info": (_int, [_vp, _pu, _pu, _pu, C.POINTER(_int)]),

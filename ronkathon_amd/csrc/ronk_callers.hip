@@ -192,27 +192,39 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
   return RONK_OK;
 }
 
-// Polynomial::<Lagrange<F>,F,D>::evaluate (polynomial/mod.rs:382-415)
-extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, size_t n, uint64_t x, uint64_t* out) {
-  if (!c || !nodes || !out || n == 0) return RONK_ERR_INVALID;
+// Polynomial::<Lagrange<F>,F,D>::evaluate (polynomial/mod.rs:382-415), device resident.  d_status (may be NULL): set
+// non-zero when two nodes coincide (the reference's F::ONE.div(ZERO) -> unwrap on None = RONK_ERR_ZERO_INVERSE).
+extern "C" int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uint64_t* d_nodes, size_t n, uint64_t x,
+                                      uint64_t* d_out, int* d_status, void* stream) {
+  if (!d_c || !d_nodes || !d_out || n == 0) return RONK_ERR_INVALID;
   if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;  // O(n^2) weights, as in the reference
   RCHK(need_device());
   FieldCtx f;
   RCHK(make_field(p, &f));
+  hipStream_t s = (hipStream_t)stream;
   const u32 blocks = (u32)((n + 255) / 256);
-  DevBuf dc, dn, ds, dp, dres, dflag;
-  RCHK(dc.alloc(n * 8)); RCHK(dn.alloc(n * 8)); RCHK(ds.alloc(blocks * 8)); RCHK(dp.alloc(blocks * 8));
-  RCHK(dres.alloc(8)); RCHK(dflag.alloc(4));
+  WsLease ws;
+  RCHK(ws.acquire((size_t)blocks * 16 + 64, s));
+  u64* ds = ws.u(); u64* dp = ws.u() + blocks;
+  int* flag = d_status ? d_status : (int*)(ws.u() + 2 * (size_t)blocks);   // a scratch word when the caller does not ask
+  FIELD_DISPATCH(f, {
+    hipLaunchKernelGGL((lagrange_terms_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, s, ops, d_c, d_nodes, n, x % p,
+                       ds, dp, flag);
+    hipLaunchKernelGGL((lagrange_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ds, dp, (size_t)blocks, d_out);
+  });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, size_t n, uint64_t x, uint64_t* out) {
+  if (!c || !nodes || !out || n == 0) return RONK_ERR_INVALID;
+  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  DevBuf dc, dn, dres, dflag;
+  RCHK(dc.alloc(n * 8)); RCHK(dn.alloc(n * 8)); RCHK(dres.alloc(8)); RCHK(dflag.alloc(4));
   HIPCHK(hipMemcpy(dc.p, c, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dn.p, nodes, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dflag.p, 0, 4));
-  FIELD_DISPATCH(f, {
-    hipLaunchKernelGGL((lagrange_terms_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, 0, ops, dc.u(), dn.u(), n, x % p,
-                       ds.u(), dp.u(), (int*)dflag.p);
-    hipLaunchKernelGGL((lagrange_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, 0, ops, ds.u(), dp.u(), (size_t)blocks,
-                       dres.u());
-  });
-  HIPCHK(hipGetLastError());
+  RCHK(ronk_lagrange_eval_dev(p, dc.u(), dn.u(), n, x, dres.u(), (int*)dflag.p, 0));
   int hflag = 0;
   HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
   if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: F::ONE.div(ZERO) -> unwrap on None
@@ -290,6 +302,26 @@ static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b,
   return RONK_OK;
 }
 
+// quotient_and_remainder on device-resident operands: the long-division kernel that follows the reference's loop
+// (any prime, any divisor).  d_quot / d_rem receive d coefficients each (d_rem may alias d_a); *d_status (device int, required) receives 0 or the RONK_ERR_* code of the reference's panic.
+// The O(n log n) Newton form needs the operands' degrees on the host, so it is reached through ronk_poly_divrem
+// (host pointers) and, for linear divisors, through ronk_poly_div_linear_dev.
+extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2,
+                                    uint64_t* d_quot, uint64_t* d_rem, int* d_status, void* stream) {
+  if (!d_a || !d_b || !d_quot || !d_rem || !d_status || d == 0 || d2 == 0) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  hipStream_t s = (hipStream_t)stream;
+  if (d_rem != d_a) HIPCHK(hipMemcpyAsync(d_rem, d_a, d * 8, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(d_status, 0, 4, s));
+  const u32 T = d2 >= 1024 ? 1024 : d2 > 256 ? 512 : 256;
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_divrem_kernel<decltype(ops)>), dim3(1), dim3(T), 0, s, ops, d_rem, d, d_b, d2,
+                                        d_quot, d_status); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+
 extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,
                                 uint64_t* rem) {
   if (!a || !b || !quot || !rem || d == 0 || d2 == 0) return RONK_ERR_INVALID;
@@ -355,33 +387,44 @@ extern "C" int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_
   return ronk_dft(p, g, padded.data(), ys, n);
 }
 
-// Message::decode (codes/reed_solomon.rs:54-106): the first k coordinates -> the k message coefficients
+// Message::decode (codes/reed_solomon.rs:54-106): the first k coordinates -> the k message coefficients.
+// Device resident: d_xs / d_ys hold CANONICAL residues; d_status (may be NULL) is set non-zero for coincident nodes.
+extern "C" int ronk_rs_decode_dev(uint64_t p, const uint64_t* d_xs, const uint64_t* d_ys, size_t k, uint64_t* d_out,
+                                  int* d_status, void* stream) {
+  if (k == 0) return RONK_OK;
+  if (!d_xs || !d_ys || !d_out) return RONK_ERR_INVALID;
+  if (k > RS_DECODE_MAX_K) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  hipStream_t s = (hipStream_t)stream;
+  const u32 nblk = (u32)((k + 255) / 256);
+  WsLease ws;
+  RCHK(ws.acquire((k + (k + 1) + (size_t)nblk * k + 8) * 8, s));
+  u64* dw = ws.u(); u64* dm = dw + k; u64* dpart = dm + (k + 1);
+  int* flag = d_status ? d_status : (int*)(dpart + (size_t)nblk * k);
+  FIELD_DISPATCH(f, {
+    hipLaunchKernelGGL((rs_weights_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, d_xs, d_ys, k, dw, flag);
+    hipLaunchKernelGGL((master_poly_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, s, ops, d_xs, k, dm);
+    hipLaunchKernelGGL((rs_accumulate_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, d_xs, dw, dm, k, dpart);
+    hipLaunchKernelGGL((rs_finish_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, dpart, (size_t)nblk, k, d_out);
+  });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
 extern "C" int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out) {
   if (k == 0) return RONK_OK;
   if (!xs || !ys || !out) return RONK_ERR_INVALID;
   if (k > RS_DECODE_MAX_K) return RONK_ERR_UNSUPPORTED;
   RCHK(need_device());
-  FieldCtx f;
-  RCHK(make_field(p, &f));
-  const u32 nblk = (u32)((k + 255) / 256);
   std::vector<u64> hx(k), hy(k);
   for (size_t i = 0; i < k; i++) { hx[i] = xs[i] % p; hy[i] = ys[i] % p; }
-  DevBuf dx, dy, dw, dm, dpart, dout, dflag;
-  RCHK(dx.alloc(k * 8)); RCHK(dy.alloc(k * 8)); RCHK(dw.alloc(k * 8)); RCHK(dm.alloc((k + 1) * 8));
-  RCHK(dpart.alloc((size_t)nblk * k * 8)); RCHK(dout.alloc(k * 8)); RCHK(dflag.alloc(4));
+  DevBuf dx, dy, dout, dflag;
+  RCHK(dx.alloc(k * 8)); RCHK(dy.alloc(k * 8)); RCHK(dout.alloc(k * 8)); RCHK(dflag.alloc(4));
   HIPCHK(hipMemcpy(dx.p, hx.data(), k * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dy.p, hy.data(), k * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dflag.p, 0, 4));
-  FIELD_DISPATCH(f, {
-    hipLaunchKernelGGL((rs_weights_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, 0, ops, dx.u(), dy.u(), k, dw.u(),
-                       (int*)dflag.p);
-    hipLaunchKernelGGL((master_poly_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, 0, ops, dx.u(), k, dm.u());
-    hipLaunchKernelGGL((rs_accumulate_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, 0, ops, dx.u(), dw.u(), dm.u(), k,
-                       dpart.u());
-    hipLaunchKernelGGL((rs_finish_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, 0, ops, dpart.u(), (size_t)nblk, k,
-                       dout.u());
-  });
-  HIPCHK(hipGetLastError());
+  RCHK(ronk_rs_decode_dev(p, dx.u(), dy.u(), k, dout.u(), (int*)dflag.p, 0));
   int hflag = 0;
   HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
   if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: numerator / ZERO
@@ -389,33 +432,56 @@ extern "C" int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys
   return RONK_OK;
 }
 
-// kzg::commit (src/kzg/setup.rs:45-60): sum_i points[i] * scalars[i] on y^2 = x^3 + a x + b over F_p[u]/(u^2 - nr)
-extern "C" int ronk_curve_msm(const ronk_curve* cv, const uint64_t* points, size_t n_points, const uint64_t* scalars,
-                              size_t n, uint64_t out[5]) {
-  if (!cv || !out || (n && (!points || !scalars))) return RONK_ERR_INVALID;
+// kzg::commit (src/kzg/setup.rs:45-60): sum_i points[i] * scalars[i] on y^2 = x^3 + a x + b over F_p[u]/(u^2 - nr).
+// Device resident: d_points = n_points x 5 words (x0, x1, y0, y1, infinity flag; coordinates canonical), d_scalars = n
+// words, d_out = 5 words.  *d_status (device int, required; the caller zeroes it): bit 0 = a point is not on the curve
+// (AffinePoint::new's panic), bit 1 = a division by zero inside the group law.  With ronk_poly_div_linear_dev the whole of
+// kzg::open (src/kzg/setup.rs:63-78: quotient, then commit) stays on the device.
+extern "C" int ronk_curve_msm_dev(const ronk_curve* cv, const uint64_t* d_points, size_t n_points, const uint64_t* d_scalars,
+                                  size_t n, uint64_t* d_out, int* d_status, void* stream) {
+  if (!cv || !d_out || !d_status || (n && (!d_points || !d_scalars))) return RONK_ERR_INVALID;
   if (cv->p < 3 || cv->p >= ((u64)1 << 32)) return RONK_ERR_UNSUPPORTED;   // products of residues must fit 64 bits
   RCHK(ronk_check_prime(cv->p));
   if (n_points < n) return RONK_ERR_INDEX;          // assert!(g1_srs.len() >= coeffs.len())
+  RCHK(need_device());
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {                                     // empty sum -> Infinity
+    const u64 inf[5] = {0, 0, 0, 0, 1};
+    HIPCHK(hipMemcpyAsync(d_out, inf, 40, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                // `inf` lives on this stack frame
+    return RONK_OK;
+  }
+  const u64 p = cv->p;
+  CurveCtx c{p, cv->nr % p, cv->a % p, cv->b % p};
+  const u32 nblk = (u32)((n + 255) / 256);
+  WsLease ws;
+  RCHK(ws.acquire((size_t)nblk * 5 * 8, s));
+  hipLaunchKernelGGL(msm_terms_kernel, dim3(nblk), dim3(256), 0, s, c, d_points, d_scalars, n, ws.u(), d_status);
+  hipLaunchKernelGGL(msm_reduce_kernel, dim3(1), dim3(256), 0, s, c, ws.u(), (size_t)nblk, d_out, d_status);
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_curve_msm(const ronk_curve* cv, const uint64_t* points, size_t n_points, const uint64_t* scalars,
+                              size_t n, uint64_t out[5]) {
+  if (!cv || !out || (n && (!points || !scalars))) return RONK_ERR_INVALID;
+  if (cv->p < 3 || cv->p >= ((u64)1 << 32)) return RONK_ERR_UNSUPPORTED;
+  RCHK(ronk_check_prime(cv->p));
+  if (n_points < n) return RONK_ERR_INDEX;
   if (n == 0) { out[0] = out[1] = out[2] = out[3] = 0; out[4] = 1; return RONK_OK; }   // empty sum -> Infinity
   RCHK(need_device());
   const u64 p = cv->p;
-  CurveCtx c{p, cv->nr % p, cv->a % p, cv->b % p};
   std::vector<u64> hp(5 * n), hs(n);
   for (size_t i = 0; i < n; i++) {
     for (int w = 0; w < 4; w++) hp[5 * i + w] = points[5 * i + w] % p;
     hp[5 * i + 4] = points[5 * i + 4] ? 1 : 0;
     hs[i] = scalars[i];
   }
-  const u32 nblk = (u32)((n + 255) / 256);
-  DevBuf dp, ds, dpart, dout, dflag;
-  RCHK(dp.alloc(5 * n * 8)); RCHK(ds.alloc(n * 8)); RCHK(dpart.alloc((size_t)nblk * 5 * 8)); RCHK(dout.alloc(5 * 8));
-  RCHK(dflag.alloc(4));
+  DevBuf dp, ds, dout, dflag;
+  RCHK(dp.alloc(5 * n * 8)); RCHK(ds.alloc(n * 8)); RCHK(dout.alloc(5 * 8)); RCHK(dflag.alloc(4));
   HIPCHK(hipMemcpy(dp.p, hp.data(), 5 * n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ds.p, hs.data(), n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dflag.p, 0, 4));
-  hipLaunchKernelGGL(msm_terms_kernel, dim3(nblk), dim3(256), 0, 0, c, dp.u(), ds.u(), n, dpart.u(), (int*)dflag.p);
-  hipLaunchKernelGGL(msm_reduce_kernel, dim3(1), dim3(256), 0, 0, c, dpart.u(), (size_t)nblk, dout.u(), (int*)dflag.p);
-  HIPCHK(hipGetLastError());
+  RCHK(ronk_curve_msm_dev(cv, dp.u(), n, ds.u(), n, dout.u(), (int*)dflag.p, 0));
   int hflag = 0;
   HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
   if (hflag & CURVE_ERR_NOT_ON_CURVE) return RONK_ERR_NOT_ON_CURVE;   // AffinePoint::new: "Point is not on curve"
@@ -423,4 +489,3 @@ extern "C" int ronk_curve_msm(const ronk_curve* cv, const uint64_t* points, size
   HIPCHK(hipMemcpy(out, dout.p, 5 * 8, hipMemcpyDeviceToHost));
   return RONK_OK;
 }
-

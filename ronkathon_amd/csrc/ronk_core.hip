@@ -145,6 +145,39 @@ extern "C" int ronk_poly_sub(uint64_t p, const uint64_t* a, size_t d, const uint
   return vec_binary_host<VEC_SUB>(p, a, d, b, d2 < d ? d2 : d, out);
 }
 
+// device-resident Neg / pow / inverse over arrays; in == out allowed.  ronk_vec_inv_dev: *d_status (may be NULL) is set
+// non-zero when an element is ZERO (Field::inverse returns None, prime/mod.rs:62-72; unwrap = RONK_ERR_ZERO_INVERSE).
+extern "C" int ronk_vec_neg_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_out, size_t n, void* st) {
+  if (!d_a || !d_out) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  if (n) FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_neg_kernel<decltype(ops)>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)st,
+                                               ops, d_a, d_out, n); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_vec_pow_dev(uint64_t p, const uint64_t* d_a, uint64_t e, uint64_t* d_out, size_t n, void* st) {
+  if (!d_a || !d_out) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  if (n) FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_pow_kernel<decltype(ops)>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)st,
+                                               ops, d_a, e, d_out, n, (int*)nullptr); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_vec_inv_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_out, size_t n, int* d_status, void* st) {
+  if (!d_a || !d_out || p < 2) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  if (n) FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_pow_kernel<decltype(ops)>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)st,
+                                               ops, d_a, p - 2, d_out, n, d_status); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+
 extern "C" int ronk_vec_neg(uint64_t p, const uint64_t* a, uint64_t* out, size_t n) {
   if (!a || !out) return RONK_ERR_INVALID;
   RCHK(need_device());

@@ -369,6 +369,37 @@ static int bluestein_dev(u64 p, u64 g, u64 w, const u64* d_x, u64* d_out, size_t
   return RONK_OK;
 }
 
+// Polynomial::dft on device-resident data (any n | p-1): powers of two over Goldilocks run the cached NTT plan, other
+// n >= 512 over Goldilocks Bluestein on the NTT path (synchronises `stream` once: its temporaries), the rest the direct
+// O(n^2) kernel (n <= 2^16).  d_in == d_out allowed for the power-of-two path only.
+extern "C" int ronk_dft_dev(uint64_t p, uint64_t g, const uint64_t* d_in, uint64_t* d_out, size_t n, void* st) {
+  if (!d_in || !d_out || n == 0) return RONK_ERR_INVALID;
+  u64 w;
+  RCHK(ronk_root_of_unity(p, g % p, n, &w));
+  RCHK(need_device());
+  hipStream_t s = (hipStream_t)st;
+  const bool gl = p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G;
+  if (is_pow2(n) && gl && n >= 16 && n <= ((size_t)1 << 30)) {
+    CacheEntry* e = nullptr;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    RCHK(cache_get(p, g, (u32)ilog2(n), &e));
+    HIPCHK(hipStreamWaitEvent(s, e->done, 0));
+    RCHK(transform_dev(e->pl, false, d_in, nullptr, d_out, s));
+    HIPCHK(hipEventRecord(e->done, s));
+    return RONK_OK;
+  }
+  if (d_in == d_out) return RONK_ERR_INVALID;
+  const bool chirp = gl && n >= 512 && n <= ((size_t)1 << 29);
+  if (chirp) return bluestein_dev(p, g % p, w, d_in, d_out, n, s);
+  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((dft_naive_kernel<decltype(ops)>), dim3((u32)((n + 255) / 256)), dim3(256), 0, s,
+                                        ops, d_in, d_out, n, w); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+
 extern "C" int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* out, size_t n) {
   if (!in || !out || n == 0) return RONK_ERR_INVALID;
   u64 w;

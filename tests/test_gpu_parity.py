@@ -833,6 +833,86 @@ def test_kzg_commit_msm_vs_reference_vectors_and_oracle(R, orc, refvec):
     assert e.value.code == -6
 
 
+def test_device_resident_callers(R, orc, refvec):
+    """the `_dev` forms of the callers (no host round trip between steps): kzg::open entirely on the device -- quotient by
+    the linear-divisor scan, then the commitment MSM on the quotient still in HBM (src/kzg/setup.rs:63-78) -- against the
+    reference's own opening vector; dft / vec / Lagrange-evaluate / RS-decode / general division `_dev` against the oracle"""
+    import ctypes as C
+    import torch
+    from ronkathon_amd import _lib as L
+    from ronkathon_amd import callers as K
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.uint64)).view(np.int64)).cuda()
+
+    def host(t):
+        return t.cpu().numpy().view(np.uint64)
+
+    v = refvec["curve"]
+    cv = K.Curve(v["p"], v["nr"], v["a"], v["b"])
+    o = refvec["kzg_commit"]["opening"]
+    q_ord = 17                                                       # scalar field of the reference's curve
+    coeffs = dev([c % q_ord for c in o["coeffs"]])
+    d = coeffs.numel()
+    quot = torch.zeros(d, dtype=torch.int64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pts = dev(np.array(v["g1_srs"], dtype=np.uint64).reshape(-1))
+    out = torch.zeros(5, dtype=torch.int64, device="cuda")
+    z = o["z"] % q_ord
+    L.check(L.lib.ronk_poly_div_linear_dev(q_ord, coeffs.data_ptr(), d, (q_ord - z) % q_ord, 1, quot.data_ptr(), None, None))
+    L.check(L.lib.ronk_curve_msm_dev(C.byref(cv), pts.data_ptr(), len(v["g1_srs"]), quot.data_ptr(), d, out.data_ptr(),
+                                     status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and host(out).tolist() == list(o["open"])
+    # vec neg / pow / inv
+    a = splitmix_field(71, 5000); a[17] = 1
+    da = dev(a); dout = torch.empty_like(da)
+    L.check(L.lib.ronk_vec_neg_dev(GP, da.data_ptr(), dout.data_ptr(), a.size, None)); torch.cuda.synchronize()
+    assert np.array_equal(host(dout), orc.vec_neg(GP, a))
+    L.check(L.lib.ronk_vec_pow_dev(GP, da.data_ptr(), 65537, dout.data_ptr(), a.size, None)); torch.cuda.synchronize()
+    assert np.array_equal(host(dout), orc.vec_pow(GP, a, 65537))
+    status.zero_()
+    L.check(L.lib.ronk_vec_inv_dev(GP, da.data_ptr(), dout.data_ptr(), a.size, status.data_ptr(), None)); torch.cuda.synchronize()
+    assert int(status.item()) == 0 and np.array_equal(orc.vec_mul(GP, host(dout), a), np.ones(a.size, dtype=np.uint64))
+    a0 = a.copy(); a0[3] = 0
+    da0 = dev(a0)
+    L.check(L.lib.ronk_vec_inv_dev(GP, da0.data_ptr(), dout.data_ptr(), a.size, status.data_ptr(), None)); torch.cuda.synchronize()
+    assert int(status.item()) != 0
+    # dft: power of two (cached plan), Bluestein, direct kernel
+    for n in (1 << 14, 3 * 512, 15):
+        x = splitmix_field(72 + n, n); dx = dev(x); dy = torch.empty_like(dx)
+        L.check(L.lib.ronk_dft_dev(GP, GG, dx.data_ptr(), dy.data_ptr(), n, None)); torch.cuda.synchronize()
+        assert np.array_equal(host(dy), orc.dft(GP, GG, x) if n <= 2048 else orc.fft(GP, GG, x)), n
+    # Lagrange evaluate + RS decode on the device
+    n = 256
+    vals = splitmix_field(73, n); nodes = orc.lagrange_nodes(GP, GG, n)
+    res = torch.zeros(1, dtype=torch.int64, device="cuda")
+    dvals, dnodes = dev(vals), dev(nodes)          # (kept alive: a temporary's memory would be reused by the next one)
+    L.check(L.lib.ronk_lagrange_eval_dev(GP, dvals.data_ptr(), dnodes.data_ptr(), n, 12345, res.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    assert int(host(res)[0]) == orc.lagrange_eval(GP, vals, nodes, 12345)
+    k = 300
+    xs = splitmix_field(74, k); ys = splitmix_field(75, k)
+    dmsg = torch.zeros(k, dtype=torch.int64, device="cuda"); status.zero_()
+    dxs, dys = dev(xs), dev(ys)
+    L.check(L.lib.ronk_rs_decode_dev(GP, dxs.data_ptr(), dys.data_ptr(), k, dmsg.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and np.array_equal(host(dmsg), orc.rs_decode(GP, xs, ys, k))
+    # general division on the device (long-division kernel) incl. the zero-divisor panic code
+    a = splitmix_field(76, 700); b = splitmix_field(77, 33)
+    dq = torch.zeros(700, dtype=torch.int64, device="cuda"); dr = torch.zeros(700, dtype=torch.int64, device="cuda")
+    da_, db_, dz_ = dev(a), dev(b), dev(np.zeros(4, dtype=np.uint64))
+    L.check(L.lib.ronk_poly_divrem_dev(GP, da_.data_ptr(), 700, db_.data_ptr(), 33, dq.data_ptr(), dr.data_ptr(),
+                                       status.data_ptr(), None))
+    torch.cuda.synchronize()
+    oq, o_r = orc.poly_divrem(GP, a, b)
+    assert int(status.item()) == 0 and np.array_equal(host(dq), oq) and np.array_equal(host(dr), o_r)
+    L.check(L.lib.ronk_poly_divrem_dev(GP, da_.data_ptr(), 700, dz_.data_ptr(), 4, dq.data_ptr(),
+                                       dr.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(status.item()) == -6
+
+
 def test_dft_non_power_of_two_bluestein(R, orc):
     """Polynomial::dft for n | p-1 that is not a power of two (polynomial/mod.rs:240-258): chirp-z on the NTT path
     for n >= 512, the O(n^2) kernel below; both against the oracle's definition-by-definition dft"""
