@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="polynomials per launch (default: 1, batch16: 1024)")
     ap.add_argument("--streams", type=int, default=2, help="independent transforms in flight (HIP streams)")
+    ap.add_argument("--tile-logc", type=int, default=-2, dest="tile_logc",
+                    help="log2 columns per tile of the timed plans (-2 = bench default: 2 when several streams, else library default)")
+    ap.add_argument("--twf", type=int, default=-1, help="largest full inter-pass twiddle matrix, log2 entries (-1 = library default)")
     ap.add_argument("--ranks", type=int, default=0, help="sharded: logical ranks (default: one per visible GPU)")
     ap.add_argument("--chunks", type=int, default=0, help="sharded: column chunks of the exchange (0 = default, up to 4)")
     ap.add_argument("--samples", type=int, default=5, help="timed regions of --steps steps each (median reported)")
@@ -281,8 +284,10 @@ def main():
     ys = [torch.empty_like(xs[0]) for _ in range(S)]
     # several transforms in flight -> narrower tiles (two workgroups per CU); one at a time -> default plan
     tile_lc = 2 if (S > 1 and log2n >= 20) else -1
-    plans = [L.Plan(P, G, log2n, batch, local_rank, tile_log2_columns=tile_lc) for _ in range(S)]
-    lat_plan = L.Plan(P, G, log2n, batch, local_rank) if tile_lc >= 0 else plans[0]
+    if args.tile_logc >= -1 and args.tile_logc != -2:
+        tile_lc = args.tile_logc
+    plans = [L.Plan(P, G, log2n, batch, local_rank, tile_log2_columns=tile_lc, twiddle_matrix_log2_max=args.twf) for _ in range(S)]
+    lat_plan = L.Plan(P, G, log2n, batch, local_rank, twiddle_matrix_log2_max=args.twf) if tile_lc >= 0 else plans[0]
     x, y, plan, stream = xs[0], ys[0], plans[0], main_stream.cuda_stream
     if wl == "mul22":
         b = torch.from_numpy(synth(n // 2, 0x5EED1000 + rank).view(np.int64)).cuda()

@@ -32,6 +32,12 @@
 #ifndef RONK_GL64_VARIANT
 #define RONK_GL64_VARIANT 7
 #endif
+// bit 3 (TIMING EXPERIMENTS ONLY, results undefined): drop the hazard wait states inside the asm blocks
+#if RONK_GL64_VARIANT & 8
+#define RONK_ASM_NOP1 ""
+#else
+#define RONK_ASM_NOP1 "s_nop 1\n\t"
+#endif
 
 namespace gl64 {
 
