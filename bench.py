@@ -434,15 +434,16 @@ def main():
     # median of SAMPLES regions as above.
     S_saved, S, plan0 = S, 1, plans[0]
     plans[0] = lat_plan
-    run(10)
-    dev_ms_samples = []
-    for _ in range(SAMPLES):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+    run(max(10, args.steps))
+    # SAMPLES back-to-back regions delimited by events on the launch stream, ONE synchronisation at the end: the device
+    # never idles between regions (short K would otherwise measure the clock ramp after every host sync)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(SAMPLES + 1)]
+    evs[0].record()
+    for i in range(SAMPLES):
         run(args.steps)
-        ev1.record()
-        torch.cuda.synchronize()
-        dev_ms_samples.append(ev0.elapsed_time(ev1))
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    dev_ms_samples = [evs[i].elapsed_time(evs[i + 1]) for i in range(SAMPLES)]
     S = S_saved
     plans[0] = plan0
     dev_ms = float(np.median(dev_ms_samples))
