@@ -182,11 +182,27 @@ RONK_HD void st_out(u64* p, u64 v) {
 // KIND != 0 also means NARROW addressing: every lane offset fits 32 bits IN BYTES (n*8 < 2^32), so global accesses
 // are the `global_load v, v_off, s[base:base+1]` form with offsets built from 32-bit adds.
 // LOGC >= 0 fixes the tile width (LDS addresses become immediates); -1 = run-time.
-template <int LOGC_, int KIND_>
+// LDSTW: the round-twiddle table omega_R^e (R entries, 8*R bytes) is staged in LDS behind the tile image at workgroup
+// start (the launcher requests 8*R more bytes) and read with ds_read_b64 instead of global loads.  Used where it fits
+// beside the image without costing a resident workgroup: the 2^11-row, 8-column tiles (136 + 16 KiB of the CU's 160).
+template <int LOGC_, int KIND_, bool LDSTW_ = false>
 struct TileCfg {
   static constexpr int LOGC = LOGC_;
   static constexpr int KIND = KIND_;
+  static constexpr bool LDSTW = LDSTW_;
 };
+// which specialised instantiations stage their round twiddles in LDS (launcher, emulator and kernel agree through this).
+// MEASURED AND SWITCHED OFF (round 2, 2^22, 2^11 x 8 tiles, the only shape where 16 KiB fit beside the image without
+// costing a resident workgroup): pass 1 / pass 2 33.8 / 24.4 us with the staged table against 31.2 / 22.7 us with the
+// L1/L2-resident table read through wave-uniform bases (51.2 -> 55.8 us per transform).  The fill, the extra barrier and
+// 30 more ds_read_b64 per lane on the LDS pipe cost more than the global gathers they replace (those cost ~1 us per
+// pass: ablation "twiddle values without table loads").  RONK_LDS_TWIDDLES=1 at compile time re-enables it.
+#ifndef RONK_LDS_TWIDDLES
+#define RONK_LDS_TWIDDLES 0
+#endif
+constexpr bool cfg_ldstw(int logr, int logc, int kind) {
+  return RONK_LDS_TWIDDLES && logr == 11 && logc == 3 && (kind == 1 || kind == 2);
+}
 
 inline bool tile_cfg_matches(const TileArgs& a, int logr, int logc, int kind) {
   const u64 C = (u64)1 << a.logc, R = (u64)1 << logr;
@@ -272,6 +288,15 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
 
   u64 x[16];
 
+  // LDS-staged round twiddles: table behind the image; filled now (its loads are in flight together with the tile's),
+  // visible after the barrier that follows the first register round
+  constexpr bool LDSTW = CFG::LDSTW && Q > 1;
+  const u32 IMG = (u32)(R + R / 16) << logc;               // elements of the tile image
+  if constexpr (LDSTW) {
+    const u32 Tn = (u32)(R / 16) << logc;
+    for (u32 e = tid; e < (u32)R; e += Tn) lds[IMG + e] = a.wr[e];
+  }
+
   // ---- round 1: j = j1*M + m, straight from HBM
   u32 joff[16];
   if (a.js_log < 31) {  // blocked rows (tiled scratch of a two-pass plan, multi-GPU receive buffer)
@@ -343,6 +368,8 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
     tb[0] = 0; tb[1] = m << 3;
 #pragma unroll
     for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
+    const char* const twl = reinterpret_cast<const char*>(lds + IMG);   // the staged table (LDSTW)
+    if constexpr (LDSTW) barrier();
     // LDS element index of (row, c) = (swz_row(row) << logc) + c.  Every access below is written as ONE per-lane base
     // plus a compile-time row constant (<< logc), so the address costs no VALU beyond the base (immediate offsets when
     // the tile width is a compile-time constant).  Q == 3: row k1*M + m, M a multiple of 16: swz = k1*(M + M/16) + m + m/16.
@@ -350,7 +377,9 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1) : ld_tabb(a.wr, tb[k1])));
+      if (k1 && !(ABL & 2))
+        x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1)
+                                           : LDSTW ? *reinterpret_cast<const u64*>(twl + tb[k1]) : ld_tabb(a.wr, tb[k1])));
       if (!(ABL & 8)) {
         if (Q == 3) {
           lds[park1 + ((u32)(k1 * (M + M / 16)) << logc)] = x[i];
@@ -389,7 +418,9 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
-        if (k2 && !(ABL & 2)) x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1) : ld_tabb(a.wr, tb[k2])));
+        if (k2 && !(ABL & 2))
+          x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1)
+                                             : LDSTW ? *reinterpret_cast<const u64*>(twl + tb[k2]) : ld_tabb(a.wr, tb[k2])));
         if (!(ABL & 8)) lds[park2 + ((u32)(272 * (k2 % RLAST) + RLAST * (k2 / RLAST)) << logc)] = x[i];
       }
       if (!(ABL & 8)) barrier();

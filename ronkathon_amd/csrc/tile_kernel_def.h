@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(1024) ntt_tile_kernel(const TileArgs a) {
   const u32 nb = gridDim.x, b = blockIdx.x;
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+  tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND, cfg_ldstw(LOGR, LOGC, KIND)>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
 }
 
 template <int LOGR, bool INV, int LOGC, int KIND>
@@ -37,6 +37,7 @@ static hipError_t launch_one(const TileArgs& a, u32 grid, u32 block, size_t lds,
       if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
   }
+  if (cfg_ldstw(LOGR, LOGC, KIND)) lds += (size_t)8 << LOGR;   // the staged round-twiddle table behind the image
   hipLaunchKernelGGL((ntt_tile_kernel<LOGR, INV, LOGC, KIND>), dim3(grid), dim3(block), lds, s, a);
   return hipGetLastError();
 }

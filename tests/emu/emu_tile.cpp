@@ -45,7 +45,7 @@ static bool dispatch_cfg(int logr, u32 tid) {
   const TileArgs& a = *g_fa.a;
 #define EMU_CFG_CASE(LR, LC, KD)                                                                 \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
-    tile_body<LR, INV, 0, TileCfg<LC, KD>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier);           \
+    tile_body<LR, INV, 0, TileCfg<LC, KD, cfg_ldstw(LR, LC, KD)>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
     g_cfg_used = KD;                                                                             \
     return true;                                                                                 \
   }
@@ -119,7 +119,7 @@ static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64*
     a.wr = pd.wr[p.wr_id].data();
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
-    lds.assign(p.lds_bytes / 8 + 1, 0);
+    lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);   // + room for the LDS-staged round twiddles
     for (u32 bid = 0; bid < p.grid; bid++) {
       g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
       run_block(p.block);
@@ -202,7 +202,7 @@ int main(int argc, char** argv) {
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
     if (in_valid && p.in_buf == BUF_IN) a.in_valid = in_valid;
     if (out_valid && p.out_buf == BUF_OUT) a.out_valid = out_valid;
-    lds.assign(p.lds_bytes / 8 + 1, 0);
+    lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);   // + room for the LDS-staged round twiddles
     g_cfg_used = 0;
     for (u32 bid = 0; bid < p.grid; bid++) {
       g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;

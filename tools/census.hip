@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(1024) census_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   // MODE 0: column pass (KIND 1), MODE 1: row pass (KIND 2); tile width fixed like the library's hot instantiations
   constexpr int LOGC = LOGR >= 11 ? 3 : 4;
-  tile_body<LOGR, INV, 0, TileCfg<LOGC, MODE == 0 ? 1 : 2>>(a, lds, threadIdx.x, blockIdx.x, [] { __syncthreads(); });
+  tile_body<LOGR, INV, 0, TileCfg<LOGC, MODE == 0 ? 1 : 2, cfg_ldstw(LOGR, LOGC, MODE == 0 ? 1 : 2)>>(a, lds, threadIdx.x, blockIdx.x, [] { __syncthreads(); });
 }
 template __global__ void census_kernel<11, false, 0>(TileArgs);
 template __global__ void census_kernel<11, false, 1>(TileArgs);

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(1024) abl_kernel(const TileArgs a) {
   const u32 nb = gridDim.x, b = blockIdx.x;
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tile_body<LOGR, INV, ABL, TileCfg<LOGC, KIND>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+  tile_body<LOGR, INV, ABL, TileCfg<LOGC, KIND, cfg_ldstw(LOGR, LOGC, KIND)>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
 }
 
 template <int K>
@@ -78,7 +78,8 @@ static float time_launch(std::function<void()> f, int iters) {
 template <int ABL, int LOGR, int LOGC, int KIND>
 static float run_abl_k(const PassDesc& ps, const TileArgs& a) {
   CK(hipFuncSetAttribute((const void*)abl_kernel<LOGR, false, ABL, LOGC, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  return time_launch([&] { hipLaunchKernelGGL((abl_kernel<LOGR, false, ABL, LOGC, KIND>), dim3(ps.grid), dim3(ps.block), ps.lds_bytes, 0, a); }, 50);
+  const size_t ldsb = ps.lds_bytes + (cfg_ldstw(LOGR, LOGC, KIND) ? ((size_t)8 << LOGR) : 0);
+  return time_launch([&] { hipLaunchKernelGGL((abl_kernel<LOGR, false, ABL, LOGC, KIND>), dim3(ps.grid), dim3(ps.block), ldsb, 0, a); }, 50);
 }
 static bool g_generic = false;   // ubench ... with RONK_NO_CFG_KERNELS set: generic bodies everywhere
 template <int ABL, int LOGR = 11>
