@@ -193,8 +193,8 @@ struct TileCfg {
 };
 // which specialised instantiations stage their round twiddles in LDS (launcher, emulator and kernel agree through this).
 // MEASURED AND SWITCHED OFF (round 2, 2^22, 2^11 x 8 tiles, the only shape where 16 KiB fit beside the image without
-// costing a resident workgroup): pass 1 / pass 2 33.8 / 24.4 us with the staged table against 31.2 / 22.7 us with the
-// L1/L2-resident table read through wave-uniform bases (51.2 -> 55.8 us per transform).  The fill, the extra barrier and
+// costing a resident workgroup): pass 1 / pass 2 33.8 / 24.4 us with the staged table against 31.1 / 22.9 us with the
+// L1/L2-resident table read through wave-uniform bases (same box).  The fill, the extra barrier and
 // 30 more ds_read_b64 per lane on the LDS pipe cost more than the global gathers they replace (those cost ~1 us per
 // pass: ablation "twiddle values without table loads").  RONK_LDS_TWIDDLES=1 at compile time re-enables it.
 #ifndef RONK_LDS_TWIDDLES
