@@ -185,11 +185,18 @@ RONK_HD void st_out(u64* p, u64 v) {
 // LDSTW: the round-twiddle table omega_R^e (R entries, 8*R bytes) is staged in LDS behind the tile image at workgroup
 // start (the launcher requests 8*R more bytes) and read with ds_read_b64 instead of global loads.  Used where it fits
 // beside the image without costing a resident workgroup: the 2^11-row, 8-column tiles (136 + 16 KiB of the CU's 160).
-template <int LOGC_, int KIND_, bool LDSTW_ = false>
+// HALF: the exchanges between rounds go through LDS in two 32-bit phases (low words, then high words) through an image
+// of 4-byte cells, so a tile needs half the LDS (68 instead of 136 KiB for 16384 coefficients) and twice as many
+// workgroups fit a CU: 8 resident waves per SIMD instead of 4 when the pass has enough tiles (batched plans, several
+// streams).  Costs two more barriers per exchange and 32-bit instead of 64-bit LDS instructions; same bank pattern
+// (ds_*_b32: 32-lane groups over 32 banks, ds_*_b64: 32-lane groups over 64 banks -- both need the 32 lanes' cell
+// indices distinct mod 32).
+template <int LOGC_, int KIND_, bool LDSTW_ = false, bool HALF_ = false>
 struct TileCfg {
   static constexpr int LOGC = LOGC_;
   static constexpr int KIND = KIND_;
   static constexpr bool LDSTW = LDSTW_;
+  static constexpr bool HALF = HALF_;
 };
 // which specialised instantiations stage their round twiddles in LDS (launcher, emulator and kernel agree through this).
 // MEASURED AND SWITCHED OFF (round 2, 2^22, 2^11 x 8 tiles, the only shape where 16 KiB fit beside the image without
@@ -291,6 +298,9 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
   // LDS-staged round twiddles: table behind the image; filled now (its loads are in flight together with the tile's),
   // visible after the barrier that follows the first register round
   constexpr bool LDSTW = CFG::LDSTW && Q > 1;
+  constexpr bool HALF = CFG::HALF && Q > 1;      // two-phase 32-bit exchanges (TileCfg); never with staged I/O or LDSTW
+  static_assert(!(HALF && LDSTW), "HALF and LDSTW exclude each other");
+  u32* const l32 = reinterpret_cast<u32*>(lds);  // the image as 4-byte cells (HALF)
   const u32 IMG = (u32)(R + R / 16) << logc;               // elements of the tile image
   if constexpr (LDSTW) {
     const u32 Tn = (u32)(R / 16) << logc;
@@ -374,6 +384,13 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
     // plus a compile-time row constant (<< logc), so the address costs no VALU beyond the base (immediate offsets when
     // the tile width is a compile-time constant).  Q == 3: row k1*M + m, M a multiple of 16: swz = k1*(M + M/16) + m + m/16.
     const u32 park1 = ((m + (m >> 4)) << logc) + c;
+    auto p1cell = [&](int i) -> u32 {   // LDS cell that register i of round 1 is parked in
+      const u32 k1 = brev(i, 4);
+      if (Q == 3) return park1 + ((u32)(k1 * (M + M / 16)) << logc);
+      const u32 blk = (k1 & (M - 1)) * (16 / RLAST) + k1 / M;
+      return (swz_row(blk * M + m) << logc) + c;
+    };
+    (void)lc;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
@@ -381,24 +398,40 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
         x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1)
                                            : LDSTW ? *reinterpret_cast<const u64*>(twl + tb[k1]) : ld_tabb(a.wr, tb[k1])));
       if (!(ABL & 8)) {
-        if (Q == 3) {
-          lds[park1 + ((u32)(k1 * (M + M / 16)) << logc)] = x[i];
-        } else {
-          const u32 blk = (k1 & (M - 1)) * (16 / RLAST) + k1 / M;
-          lc[swz_row(blk * M + m) << logc] = x[i];
-        }
+        const u32 cell = p1cell(i);
+        if (HALF) l32[cell] = (u32)x[i]; else lds[cell] = x[i];
       }
     }
     if (!(ABL & 8)) barrier();
 
+    // round-2 lane coordinates (Q == 3): thread (d1, d3) = (m / RLAST, m % RLAST); its results are parked at p2cell(i)
+    const u32 d1 = m >> LOGLAST, d3 = m & (RLAST - 1);
+    const u32 park2 = ((17 * d1 + d3) << logc) + c;
+    auto p2cell = [&](int i) -> u32 {
+      const u32 k2 = brev(i, 4);
+      return park2 + ((u32)(272 * (k2 % RLAST) + RLAST * (k2 / RLAST)) << logc);
+    };
     if (Q == 3) {
       // ---- round 2: thread (d1, d3) = (m / RLAST, m % RLAST), register digit d2
-      const u32 d1 = m >> LOGLAST, d3 = m & (RLAST - 1);
       // rows d1*16*RLAST + d3 + i*RLAST: swz = (17*RLAST*d1 + d3) + (i*RLAST + i*RLAST/16)     (d3 + (i*RLAST mod 16) < 16)
       const u32 rd2 = ((d1 * (17 * RLAST) + d3) << logc) + c;
+      if (HALF && !(ABL & 8)) {
+        // low words are in the image: read them, then (barrier) park the high words in the same cells and read those
+        u32 lo[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++)
-        if (!(ABL & 8)) x[i] = lds[rd2 + ((u32)(i * RLAST + (i * RLAST) / 16) << logc)];
+        for (int i = 0; i < 16; i++) lo[i] = l32[rd2 + ((u32)(i * RLAST + (i * RLAST) / 16) << logc)];
+        barrier();
+#pragma unroll
+        for (int i = 0; i < 16; i++) l32[p1cell(i)] = (u32)(x[i] >> 32);
+        barrier();
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          x[i] = ((u64)l32[rd2 + ((u32)(i * RLAST + (i * RLAST) / 16) << logc)] << 32) | lo[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          if (!(ABL & 8)) x[i] = lds[rd2 + ((u32)(i * RLAST + (i * RLAST) / 16) << logc)];
+      }
       // The results are NOT parked back at the rows just read.  The sub-transform with natural output index
       // kl = k1 + 16*k2 (k1 = d1) goes to group slot s = (kl mod M)*G + kl div M, G = 16/RLAST groups per lane, i.e. rows
       // s*RLAST .. s*RLAST + RLAST-1.  Lane m, which owns rows 16m .. 16m+15 in the last round, then holds the groups
@@ -414,23 +447,37 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
       const u32 tstep = 16 * d3;
       // slot row = 256*(k2 mod RLAST) + 16*d1 + RLAST*(k2 div RLAST) + d3 (M = 16*RLAST, G*RLAST = 16), and
       // RLAST*(k2 div RLAST) + d3 < 16: swz = (17*d1 + d3) + (272*(k2 mod RLAST) + RLAST*(k2 div RLAST))
-      const u32 park2 = ((17 * d1 + d3) << logc) + c;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
         if (k2 && !(ABL & 2))
           x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1)
                                              : LDSTW ? *reinterpret_cast<const u64*>(twl + tb[k2]) : ld_tabb(a.wr, tb[k2])));
-        if (!(ABL & 8)) lds[park2 + ((u32)(272 * (k2 % RLAST) + RLAST * (k2 / RLAST)) << logc)] = x[i];
+        if (!(ABL & 8)) {
+          const u32 cell = p2cell(i);
+          if (HALF) l32[cell] = (u32)x[i]; else lds[cell] = x[i];
+        }
       }
       if (!(ABL & 8)) barrier();
     }
 
     // ---- last round: thread m owns rows 16m .. 16m+15; row = v*RLAST + d_last
     const u32 rd3 = ((17 * m) << logc) + c;   // swz_row(16m + i) = 17m + i
+    if (HALF && !(ABL & 8)) {
+      u32 lo[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      if (!(ABL & 8)) x[i] = lds[rd3 + ((u32)i << logc)];
+      for (int i = 0; i < 16; i++) lo[i] = l32[rd3 + ((u32)i << logc)];
+      barrier();
+#pragma unroll
+      for (int i = 0; i < 16; i++) l32[Q == 3 ? p2cell(i) : p1cell(i)] = (u32)(x[i] >> 32);
+      barrier();
+#pragma unroll
+      for (int i = 0; i < 16; i++) x[i] = ((u64)l32[rd3 + ((u32)i << logc)] << 32) | lo[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (!(ABL & 8)) x[i] = lds[rd3 + ((u32)i << logc)];
+    }
   }
 
   // ---- last sub-DFTs + output, one group of GSZ registers at a time (sub-DFT -> inter-pass twiddle -> scale ->
@@ -465,15 +512,20 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
     }
     if (tf && !(ABL & 1)) {
       if (live) {  // dead columns of a ragged tile hold zeros anyway
-        u64 w[GSZ];
+        // HALF kernels are built for 64 VGPRs: at most 8 table entries in flight at a time
+        constexpr int WCH = (CFG::HALF && GSZ > 8) ? 8 : GSZ;
         const u32 tbase = tf_lane + kl * tf_sk;   // like the stores: per-lane base + wave-uniform constants
 #pragma unroll
-        for (int i = 0; i < GSZ; i++) {
-          const u32 ci = (Q == 1) ? (u32)brev(i, 4) : (u32)((R / RLAST) * brev(i, LOGLAST));
-          w[i] = ld_g<NARROW>(tf, tbase + ci * tf_sk);
-        }
+        for (int i0 = 0; i0 < GSZ; i0 += WCH) {
+          u64 w[WCH];
 #pragma unroll
-        for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], w[i]);
+          for (int i = 0; i < WCH; i++) {
+            const u32 ci = (Q == 1) ? (u32)brev(i0 + i, 4) : (u32)((R / RLAST) * brev(i0 + i, LOGLAST));
+            w[i] = ld_g<NARROW>(tf, tbase + ci * tf_sk);
+          }
+#pragma unroll
+          for (int i = 0; i < WCH; i++) xg[i0 + i] = gl64::mul(xg[i0 + i], w[i]);
+        }
       }
     } else if (a.tw_log && !(ABL & 1)) {
       // exponent (X*Y) mod 2^tw_log with tw_log <= 32 (the low 32 bits of a 32-bit product suffice); Y is affine in the

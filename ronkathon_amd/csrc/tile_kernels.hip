@@ -23,6 +23,13 @@ static hipError_t launch_dir(int logr, const TileArgs& a, u32 grid, u32 block, s
   }
 }
 
+// Two-phase 32-bit LDS exchanges (TileCfg::HALF) pay when a CU can then hold more workgroups than with the full image.
+// RONK_HALF_LDS = 0 never, 1 always (experiments); default: not yet enabled.
+static bool use_half(const TileArgs&, int, u32) {
+  static const int mode = [] { const char* e = getenv("RONK_HALF_LDS"); return e ? atoi(e) : 0; }();
+  return mode == 1;
+}
+
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds,
                        hipStream_t s) {
   static const bool no_cfg = getenv("RONK_NO_CFG_KERNELS") != nullptr;   // experiments: force the generic kernels
@@ -30,6 +37,10 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
     for (int kind : {1, 2, 3}) {
       if (!tile_cfg_matches(a, logr, (int)a.logc, kind)) continue;
       bool found = false;
+      if (use_half(a, logr, grid)) {
+        hipError_t e = launch_tile_cfg_half(logr, inverse, kind, a, grid, block, lds, s, &found);
+        if (found) return e;
+      }
       hipError_t e = launch_tile_cfg(logr, inverse, kind, a, grid, block, lds, s, &found);
       if (found) return e;
     }

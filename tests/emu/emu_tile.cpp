@@ -43,6 +43,17 @@ static int g_cfg_used = 0;
 template <bool INV>
 static bool dispatch_cfg(int logr, u32 tid) {
   const TileArgs& a = *g_fa.a;
+  static const bool half = getenv("RONK_HALF_LDS") && atoi(getenv("RONK_HALF_LDS")) == 1;   // TileCfg::HALF instantiations
+  if (half) {
+#define EMU_HALF_CASE(LR, LC, KD)                                                                \
+  if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
+    tile_body<LR, INV, 0, TileCfg<LC, KD, false, true>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
+    g_cfg_used = KD + 10;                                                                        \
+    return true;                                                                                 \
+  }
+    RONK_CFG_TABLE(EMU_HALF_CASE)
+#undef EMU_HALF_CASE
+  }
 #define EMU_CFG_CASE(LR, LC, KD)                                                                 \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
     tile_body<LR, INV, 0, TileCfg<LC, KD, cfg_ldstw(LR, LC, KD)>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
@@ -210,7 +221,8 @@ int main(int argc, char** argv) {
     }
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
-           g_cfg_used == 2 ? "cfg:row" : "generic");
+           g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
+           g_cfg_used == 12 ? "half:row" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
   for (u64 b = 0; b < batch; b++) {

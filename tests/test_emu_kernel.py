@@ -111,3 +111,15 @@ def test_gl64_field_arithmetic_edges():
         subprocess.check_call([cxx, "-O2", "-std=c++17", "-o", exe, src])
         out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "ALL OK" in out.stdout, (cxx, out.stdout[-800:])
+
+
+@pytest.mark.parametrize("args", [(22, 1, 0, 3), (22, 1, 1, 2), (16, 3, 0, 4, 18), (18, 1, 1, 4, 18), (20, 2, 0, 3), (19, 1, 1, 4)])
+def test_half_lds_exchange(emu, args):
+    """TileCfg::HALF (RONK_HALF_LDS=1: exchanges between rounds as two 32-bit phases through a half-size LDS image): the
+    specialised two- and three-round bodies compute the same plans; a missing barrier between the phases shows up here
+    because the fibers run one after the other"""
+    env = dict(os.environ, RONK_HALF_LDS="1")
+    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+    assert all("kernel=half:" in l for l in lines if l.startswith("pass")), out.stdout
