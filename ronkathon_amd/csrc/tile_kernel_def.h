@@ -29,8 +29,12 @@ __global__ void __launch_bounds__(1024) ntt_tile_kernel(const TileArgs a) {
 
 // TileCfg::HALF (two-phase 32-bit LDS exchanges, half the image): built for 8 resident waves per SIMD (<= 64 VGPRs), which
 // is the point of halving the image
+// waves per SIMD a HALF kernel is built for: 8 (64 VGPRs), except the two-round column pass with the full twiddle matrix
+// (16 table entries + 16 coefficients live at the end), which spills 70-80 bytes per lane at 64 and gets 6 (80 VGPRs)
+constexpr int half_wpe(int logr, int kind) { return (logr == 8 && kind == 3) ? 6 : 8; }
+
 template <int LOGR, bool INV, int LOGC, int KIND>
-__global__ void __launch_bounds__(1024, 8) ntt_tile_kernel_half(const TileArgs a) {
+__global__ void __launch_bounds__(1024, half_wpe(LOGR, KIND)) ntt_tile_kernel_half(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   tile_kernel_main<LOGR, INV, LOGC, KIND, true>(a, lds);
 }

@@ -23,11 +23,19 @@ static hipError_t launch_dir(int logr, const TileArgs& a, u32 grid, u32 block, s
   }
 }
 
-// Two-phase 32-bit LDS exchanges (TileCfg::HALF) pay when a CU can then hold more workgroups than with the full image.
-// RONK_HALF_LDS = 0 never, 1 always (experiments); default: not yet enabled.
-static bool use_half(const TileArgs&, int, u32) {
-  static const int mode = [] { const char* e = getenv("RONK_HALF_LDS"); return e ? atoi(e) : 0; }();
-  return mode == 1;
+// Two-phase 32-bit LDS exchanges (TileCfg::HALF, half the LDS image, kernels built for 6-8 waves per SIMD) pay when a
+// pass has far more tiles than the chip holds at once: the workgroups of a CU drift into different phases and the
+// additional resident ones fill the load / store phases of the others.  Measured (same box): 1024 x 2^16
+// 0.493 -> 0.469 ms, 512 x 2^17 0.561 -> 0.514 ms; row passes with >= 2^10 rows get slower (2^22 x 16 pass 2: 402 -> 484 us)
+// and a single transform (one tile per CU) only pays the extra barriers (51.4 -> 53.7 us), so:
+//   default  column passes (KIND 1, 3) of any size and row passes (KIND 2) up to 2^9 rows, when the grid has at least
+//            twice the threads the chip holds at four waves per SIMD (2 * 256 CUs * 1024)
+//   RONK_HALF_LDS = 0 never, 1 always, 2 row passes only (experiments)
+static bool use_half(const TileArgs&, int logr, u32 grid, u32 block, int kind) {
+  static const int mode = [] { const char* e = getenv("RONK_HALF_LDS"); return e ? atoi(e) : -1; }();
+  if (mode >= 0) return mode == 1 || (mode == 2 && kind == 2);
+  if ((unsigned long long)grid * block < 2ull * 256 * 1024) return false;
+  return kind != 2 || logr <= 9;
 }
 
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds,
@@ -37,7 +45,7 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
     for (int kind : {1, 2, 3}) {
       if (!tile_cfg_matches(a, logr, (int)a.logc, kind)) continue;
       bool found = false;
-      if (use_half(a, logr, grid)) {
+      if (use_half(a, logr, grid, block, kind)) {
         hipError_t e = launch_tile_cfg_half(logr, inverse, kind, a, grid, block, lds, s, &found);
         if (found) return e;
       }
