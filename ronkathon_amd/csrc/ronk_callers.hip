@@ -14,6 +14,8 @@
 struct WsSlot {
   void* p = nullptr;
   u32* ctl = nullptr;   // 64 bytes of control words, ZERO whenever the slot is not in use (fused scan kernels)
+  u64* lb = nullptr;    // two look-back arrays of LB_WORDS entries (scan_kernels.h, one-launch forms): the one a call uses
+  u32 lb_calls = 0;     // was set to LB_EMPTY by the call before it (at creation: both), parity = lb_calls & 1
   size_t bytes = 0;
   int device = -1;
   hipEvent_t done = nullptr;
@@ -57,8 +59,10 @@ struct WsLease {
       hipError_t e = hipMalloc(&w->p, need);
       if (e == hipSuccess) e = hipMalloc((void**)&w->ctl, 64);
       if (e == hipSuccess) e = hipMemset(w->ctl, 0, 64);
+      if (e == hipSuccess) e = hipMalloc((void**)&w->lb, (size_t)2 * LB_WORDS * 8);
+      if (e == hipSuccess) e = hipMemset(w->lb, 0xFF, (size_t)2 * LB_WORDS * 8);   // LB_EMPTY everywhere
       if (e == hipSuccess) e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
-      if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); if (w->ctl) (void)hipFree(w->ctl); delete w; return hip_fail(e, "workspace"); }
+      if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); if (w->ctl) (void)hipFree(w->ctl); if (w->lb) (void)hipFree(w->lb); delete w; return hip_fail(e, "workspace"); }
       w->bytes = need; w->device = dev;
       g_ws.push_back(w);
       slot = w;
@@ -68,7 +72,19 @@ struct WsLease {
   }
   u64* u() const { return (u64*)slot->p; }
   u32* ctl() const { return slot->ctl; }
+  // look-back arrays of a one-launch scan: *cur is all LB_EMPTY now, *next is cleared by the kernel for the call after
+  void lb_arrays(u64** cur, u64** next) {
+    const u32 par = slot->lb_calls++ & 1;
+    *cur = slot->lb + (size_t)par * LB_WORDS;
+    *next = slot->lb + (size_t)(par ^ 1) * LB_WORDS;
+  }
 };
+// the one-launch scans keep host state per call (which look-back array is clean): not for a capturing stream
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
 static void make_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
   u64 x = 1 % p;
   for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
@@ -79,10 +95,20 @@ static void make_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
   for (int s = 0; s < 20; s++) { t->Yp[s] = y; y = h_mulmod(y, y, p); }
   t->z = z % p;
   t->scale = scale;
+  static const u64 test_flags = [] { const char* e = getenv("RONK_LB_TEST_FLAGS"); return e ? (u64)atoi(e) : (u64)0; }();
+  t->test_flags = test_flags;
+  const u64 Y = t->Yp[0], Y16 = t->Yp[4], Y256 = t->Yp[8], z8 = t->zt[8], z128 = t->zt[128];
+  u64 a = 1 % p, b = 1 % p, cc = 1 % p, c8 = 1 % p, d8 = 1 % p;
+  for (int i = 0; i < 16; i++) {
+    t->YA[i] = a; t->YB[i] = b; t->YC[i] = cc; t->z8A[i] = c8; t->z8B[i] = d8;
+    a = h_mulmod(a, Y, p); b = h_mulmod(b, Y16, p); cc = h_mulmod(cc, Y256, p); c8 = h_mulmod(c8, z8, p); d8 = h_mulmod(d8, z128, p);
+  }
 }
 // fused paths (scan_kernels.h): evaluate in one launch up to 2^20 chunks; division in two launches up to 4096 chunks
 static const size_t FUSED_EVAL_MAX = (size_t)FCH << 20, FUSED_DIV_MAX = (size_t)FCH * 4096;
 static const bool g_no_fused_scans = getenv("RONK_NO_FUSED_SCANS") != nullptr;   // experiments / A-B
+static const bool g_no_onepass_scans = getenv("RONK_NO_ONEPASS_SCANS") != nullptr;
+static const bool g_onepass_div = getenv("RONK_ONEPASS_DIV") != nullptr;   // one-launch division: built, parity-tested, slower (scan_kernels.h)
 static void make_horner_tab(u64 p, u64 z, u64 scale, HornerTab* t) {
   u64 x = 1 % p;
   for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
@@ -122,6 +148,14 @@ extern "C" int ronk_poly_eval_dev(uint64_t p, const uint64_t* d_c, size_t d, uin
     make_horner_tab2(p, x % p, 1, &tab2);
     WsLease ws;
     RCHK(ws.acquire(nch * 8, s));
+    if (nch <= LB_MAX && !g_no_onepass_scans && !stream_is_capturing(s)) {   // one launch (scan_kernels.h)
+      u64 *cur, *next;
+      ws.lb_arrays(&cur, &next);
+      FIELD_DISPATCH(f, { hipLaunchKernelGGL((eval_onepass_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d,
+                                            tab2, cur, next, d_out); });
+      HIPCHK(hipGetLastError());
+      return RONK_OK;
+    }
     FIELD_DISPATCH(f, {
       hipLaunchKernelGGL((weighted_chunk_sum8_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d, tab2, ws.u());
       hipLaunchKernelGGL((partial_sum_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ws.u(), nch, d_out);
@@ -172,6 +206,14 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
     make_horner_tab2(p, z, b1inv, &tab2);
     WsLease ws;
     RCHK(ws.acquire(nch * 8, s));
+    if (g_onepass_div && nch <= LB_DIV_MAX && !g_no_onepass_scans && !stream_is_capturing(s)) {   // one launch (scan_kernels.h)
+      u64 *cur, *next;
+      ws.lb_arrays(&cur, &next);
+      FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_onepass_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d,
+                                            tab2, cur, next, d_quot, d_rem); });
+      HIPCHK(hipGetLastError());
+      return RONK_OK;
+    }
     FIELD_DISPATCH(f, {
       hipLaunchKernelGGL((chunk_sum8_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d, tab2, ws.u());
       hipLaunchKernelGGL((lindiv_fused_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d, tab2, ws.u(), d_quot,

@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the oracle, the reference's golden vectors
 and size-independent properties.  Bit-exact: all integer work.  Needs a real MI355X (-m gpu)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -500,6 +502,19 @@ def test_scan_paths_fused_and_three_kernel(R, orc):
         assert int(r[0]) == val, d
         for h in (dc, dq, dr):
             L.lib.ronk_dev_free(h)
+
+
+@pytest.mark.parametrize("env", [{}, {"RONK_ONEPASS_DIV": "1"}, {"RONK_ONEPASS_DIV": "1", "RONK_LB_TEST_FLAGS": "1"},
+                                 {"RONK_NO_ONEPASS_SCANS": "1"}, {"RONK_NO_FUSED_SCANS": "1"}])
+def test_scan_onepass_variants(R, env):
+    """the one-launch evaluate / linear division (look-back through an agent-coherent array), the same with every wait
+    forced to give up (the recompute-from-coefficients path that makes the waits bounded), and the two- and three-launch
+    forms: each in its own process, since the library reads its knobs once"""
+    import subprocess, sys
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "scan_subprocess_check.py")],
+                         capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0 and "scan check ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
 
 
 def test_determinism(R):
