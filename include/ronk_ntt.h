@@ -191,6 +191,19 @@ typedef struct ronk_curve { uint64_t p, nr, a, b; } ronk_curve;
 int ronk_curve_msm(const ronk_curve* curve, const uint64_t* points, size_t n_points, const uint64_t* scalars, size_t n,
                    uint64_t out[5]);
 
+/* kzg::commit on a production-size curve: sum_i scalars[i] * points[i] over BN254 (alt_bn128) G1,
+ * y^2 = x^3 + 3 over F_p, p = 21888242871839275222246405745257275088696311157297823662689037894645226208583, by the bucket
+ * method on the GPU (csrc/msm_kernels.h).  The reference's commit is the same sum as a fold of AffinePoint Mul / Add over
+ * its 17-element toy group (src/kzg/setup.rs:48-60, src/curve/mod.rs:157-211); its field traits are usize-wide
+ * (src/algebra/mod.rs:8-13), so a 254-bit curve is a new type on the Rust side.
+ * points: n x 8 words -- x then y, each 4 x 64-bit little-endian limbs, standard (non-Montgomery) form, < p; (0, 0) is the
+ * point at infinity.  scalars: n x 4 words, any 256-bit integers (e.g. residues mod the group order r).  out: 8 words, same
+ * encoding as a point.  RONK_ERR_NOT_ON_CURVE: a coordinate >= p or y^2 != x^3 + 3 (AffinePoint::new's assert,
+ * src/curve/mod.rs:79).  The _dev form takes device-resident points / scalars and a HOST result pointer: it enqueues
+ * on `stream`, waits for it, and finishes the last ~270 dependent doublings on the host. */
+int ronk_msm_bn254(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out[8]);
+int ronk_msm_bn254_dev(const uint64_t* d_points, const uint64_t* d_scalars, size_t n, uint64_t out[8], void* stream);
+
 /* ---- multi-GPU four-step building blocks (one process per GPU; the exchange between the two
  *      phases is an RCCL all-to-all issued by the host side, see ronkathon_amd/dist.py) ----
  * n = 2^log2n split as R x C with R = 2^(log2n - log2n/2) rows and C = 2^(log2n/2) columns;

@@ -71,3 +71,31 @@ def kzg_commit(curve, coeffs, g1_srs):
 def kzg_open(curve, scalar_field, coeffs, eval_point, g1_srs):
     """`kzg::open::<D>` (kzg/setup.rs:63-78): commit(poly.div([-z, 1]).coefficients, g1_srs)"""
     return kzg_commit(curve, kzg_open_quotient(scalar_field, coeffs, eval_point), g1_srs)
+
+
+# ---- kzg::commit on BN254 G1 (bucket-method MSM, csrc/msm_kernels.h)
+BN254_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BN254_G1 = (1, 2)
+
+
+def _limbs4(v):
+    return [(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def msm_bn254(points, scalars):
+    """sum_i scalars[i] * points[i]: `kzg::commit` (kzg/setup.rs:48-60) with a 254-bit group.  points: (x, y) integer
+    pairs or None for the point at infinity; scalars: non-negative integers < 2^256.  Returns (x, y) or None."""
+    assert len(points) == len(scalars)      # the reference zips and asserts srs.len() >= coeffs.len()
+    n = len(points)
+    pw = np.zeros((n, 8), dtype=np.uint64)
+    sw = np.zeros((n, 4), dtype=np.uint64)
+    for i, (pt, k) in enumerate(zip(points, scalars)):
+        if pt is not None:
+            pw[i, :4] = _limbs4(pt[0]); pw[i, 4:] = _limbs4(pt[1])
+        sw[i] = _limbs4(k)
+    out = np.zeros(8, dtype=np.uint64)
+    L.check(L.lib.ronk_msm_bn254(L.ptr(pw), L.ptr(sw), n, L.ptr(out)))
+    x = sum(int(out[i]) << (64 * i) for i in range(4))
+    y = sum(int(out[4 + i]) << (64 * i) for i in range(4))
+    return None if x == 0 and y == 0 else (x, y)

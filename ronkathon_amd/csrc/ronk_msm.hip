@@ -1,0 +1,120 @@
+// ronk_msm.hip -- C ABI of libronk_ntt.so, part 5: kzg::commit on a production-size curve -- the bucket-method MSM over
+// BN254 G1 (reference fold: src/kzg/setup.rs:48-60).  Kernels: msm_kernels.h; arithmetic: bn254.h.
+#include "runtime.h"
+#include "msm_kernels.h"
+
+namespace {
+
+// window size: buckets cost NB*W*c point additions in the reduction, entries cost n*W mixed additions
+u32 pick_window(size_t n) {
+  const char* e = getenv("RONK_MSM_C");    // read per call: tests and tuning runs sweep it inside one process
+  const int forced = e ? atoi(e) : 0;
+  if (forced >= 5 && forced <= 16) return (u32)forced;
+  int lg = 0;
+  while (((size_t)1 << lg) < n) lg++;
+  int c = lg - 5;
+  if (c < 6) c = 6;
+  if (c > 15) c = 15;
+  return (u32)c;
+}
+
+struct MsmWork {
+  MsmShape sh;
+  DevBuf pts, counts, offsets, cursor, entries, buckets, st0, st1, status;
+  size_t planes = 0;   // W * c rows of the bit-plane reduction
+  int alloc(size_t n) {
+    sh.n = (u32)n;
+    sh.c = pick_window(n);
+    sh.W = (257 + sh.c - 1) / sh.c;
+    sh.NB = 1u << (sh.c - 1);
+    const size_t keys = (size_t)sh.W * sh.NB;
+    planes = (size_t)sh.W * sh.c;
+    RCHK(pts.alloc(n * sizeof(Affine)));
+    RCHK(counts.alloc(keys * 4));
+    RCHK(offsets.alloc((keys + 1) * 4));
+    RCHK(cursor.alloc(keys * 4));
+    RCHK(entries.alloc(n * sh.W * 4));
+    RCHK(buckets.alloc(keys * sizeof(Xyzz)));
+    RCHK(st0.alloc(planes * (sh.NB / 16) * sizeof(Xyzz)));
+    RCHK(st1.alloc(planes * ((sh.NB / 16 + 7) / 8) * sizeof(Xyzz)));
+    RCHK(status.alloc(8));
+    return RONK_OK;
+  }
+};
+
+// host tail: rows[w*c + k] = Q_k of window w  ->  sum_w 2^(c w) sum_k 2^k Q_k, affine standard form
+void msm_host_tail(const MsmShape& sh, const Xyzz* rows, u64 out[8]) {
+  Xyzz total = bn254::xyzz_inf();
+  for (int w = (int)sh.W - 1; w >= 0; w--) {
+    for (u32 i = 0; i < sh.c; i++) total = bn254::xyzz_dbl(total);
+    Xyzz win = bn254::xyzz_inf();
+    for (int k = (int)sh.c - 1; k >= 0; k--) {
+      win = bn254::xyzz_dbl(win);
+      win = bn254::xyzz_add(win, rows[(size_t)w * sh.c + k]);
+    }
+    total = bn254::xyzz_add(total, win);
+  }
+  bn254::xyzz_store_affine(total, out);
+}
+
+int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hipStream_t s) {
+  if (n == 0) { for (int i = 0; i < 8; i++) out[i] = 0; return RONK_OK; }
+  if (n >= ((size_t)1 << 31)) return RONK_ERR_UNSUPPORTED;
+  MsmWork wk;
+  RCHK(wk.alloc(n));
+  const MsmShape sh = wk.sh;
+  const u32 keys = sh.W * sh.NB;
+  const u32 gn = (u32)((n + 255) / 256);
+  HIPCHK(hipMemsetAsync(wk.status.p, 0, 8, s));
+  HIPCHK(hipMemsetAsync(wk.counts.p, 0, (size_t)keys * 4, s));
+  hipLaunchKernelGGL(msm_prepare_kernel, dim3(gn), dim3(256), 0, s, d_points, sh.n, (Affine*)wk.pts.p, (int*)wk.status.p);
+  hipLaunchKernelGGL((msm_digits_kernel<false>), dim3(gn), dim3(256), 0, s, d_scalars, sh, (u32*)wk.counts.p, (u32*)nullptr,
+                     (u32*)nullptr);
+  hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)wk.counts.p, keys, (u32*)wk.offsets.p,
+                     (u32*)wk.cursor.p);
+  hipLaunchKernelGGL((msm_digits_kernel<true>), dim3(gn), dim3(256), 0, s, d_scalars, sh, (u32*)nullptr, (u32*)wk.cursor.p,
+                     (u32*)wk.entries.p);
+  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((keys + 255) / 256), dim3(256), 0, s, (const Affine*)wk.pts.p,
+                     (const u32*)wk.offsets.p, (const u32*)wk.entries.p, keys, (Xyzz*)wk.buckets.p);
+  const u32 rows = (u32)wk.planes;
+  u32 cnt = sh.NB / 16;
+  hipLaunchKernelGGL(msm_bitplane_kernel, dim3((rows * cnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)wk.buckets.p, sh,
+                     (Xyzz*)wk.st0.p);
+  Xyzz* cur = (Xyzz*)wk.st0.p;
+  Xyzz* nxt = (Xyzz*)wk.st1.p;
+  while (cnt > 1) {
+    const u32 ocnt = (cnt + 7) / 8;
+    hipLaunchKernelGGL(msm_sum8_kernel, dim3((rows * ocnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)cur, rows, cnt, nxt);
+    Xyzz* t = cur; cur = nxt; nxt = t;
+    cnt = ocnt;
+  }
+  HIPCHK(hipGetLastError());
+  std::vector<Xyzz> h(rows);
+  int st[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h.data(), cur, (size_t)rows * sizeof(Xyzz), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(st, wk.status.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (st[0] & 1) return RONK_ERR_NOT_ON_CURVE;
+  msm_host_tail(sh, h.data(), out);
+  return RONK_OK;
+}
+
+}  // namespace
+
+// sum_i scalars[i] * points[i] over BN254 G1.  points: n x 8 words (x, y as 4 x 64-bit little-endian limbs, standard
+// form, < p; (0, 0) = the point at infinity); scalars: n x 4 words, any 256-bit integers; out: 8 words, same encoding.
+extern "C" int ronk_msm_bn254_dev(const uint64_t* d_points, const uint64_t* d_scalars, size_t n, uint64_t* out, void* stream) {
+  if (!out || (n && (!d_points || !d_scalars))) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  return msm_run(d_points, d_scalars, n, out, (hipStream_t)stream);
+}
+extern "C" int ronk_msm_bn254(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out) {
+  if (!out || (n && (!points || !scalars))) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  if (n == 0) { for (int i = 0; i < 8; i++) out[i] = 0; return RONK_OK; }
+  DevBuf dp, ds;
+  RCHK(dp.alloc(n * 64)); RCHK(ds.alloc(n * 32));
+  HIPCHK(hipMemcpy(dp.p, points, n * 64, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  return msm_run(dp.u(), ds.u(), n, out, 0);
+}

@@ -1,0 +1,61 @@
+// bn254_host.cpp -- TEST INFRASTRUCTURE: csrc/bn254.h compiled for the host behind a C interface, so that
+// tests/test_bn254_host.py can check the field and group arithmetic (the same source the kernels and the MSM's host tail
+// use) against oracle/bn254.py on the CPU-only container.  Never linked into the product library.
+#include "../../ronkathon_amd/csrc/bn254.h"
+
+using namespace bn254;
+
+extern "C" {
+// standard form in / out (4 x u64 little endian)
+void h_fp_mul(const u64* a, const u64* b, u64* out) {
+  fp_store(out, fp_from_mont(fp_mul(fp_to_mont(fp_load(a)), fp_to_mont(fp_load(b)))));
+}
+void h_fp_add(const u64* a, const u64* b, u64* out) { fp_store(out, fp_add(fp_load(a), fp_load(b))); }
+void h_fp_sub(const u64* a, const u64* b, u64* out) { fp_store(out, fp_sub(fp_load(a), fp_load(b))); }
+void h_fp_inv(const u64* a, u64* out) { fp_store(out, fp_from_mont(fp_inv(fp_to_mont(fp_load(a))))); }
+int h_fp_geq_p(const u64* a) { return fp_geq_p(fp_load(a)) ? 1 : 0; }
+
+static Affine load_affine(const u64* p) {
+  Affine a;
+  a.x = fp_load(p); a.y = fp_load(p + 4);
+  if (!(fp_is_zero(a.x) && fp_is_zero(a.y))) { a.x = fp_to_mont(a.x); a.y = fp_to_mont(a.y); }
+  return a;
+}
+int h_on_curve(const u64* p) { return affine_on_curve(load_affine(p)) ? 1 : 0; }
+// out = (p + q) through madd (q affine), then the general add and dbl paths: mode 0 madd, 1 add of two XYZZ with non-unit
+// ZZ (both scaled first), 2 dbl of p (q ignored)
+void h_point_op(const u64* p, const u64* q, int neg_q, int mode, u64* out) {
+  const Affine ap = load_affine(p), aq = load_affine(q);
+  Xyzz acc = xyzz_inf();
+  xyzz_madd(acc, ap, false);
+  if (mode == 0) {
+    xyzz_madd(acc, aq, neg_q != 0);
+  } else if (mode == 1) {
+    // rescale both operands to non-trivial ZZ: (X l^2, Y l^3, ZZ l^2, ZZZ l^3) with l = 5 and 7
+    Xyzz b = xyzz_inf();
+    xyzz_madd(b, aq, neg_q != 0);
+    Fp five = fp_zero(); five.l[0] = 5; five = fp_to_mont(five);
+    Fp seven = fp_zero(); seven.l[0] = 7; seven = fp_to_mont(seven);
+    auto scale = [](Xyzz& v, const Fp& l) {
+      if (xyzz_is_inf(v)) return;
+      const Fp l2 = fp_sqr(l), l3 = fp_mul(l2, l);
+      v.X = fp_mul(v.X, l2); v.Y = fp_mul(v.Y, l3); v.ZZ = fp_mul(v.ZZ, l2); v.ZZZ = fp_mul(v.ZZZ, l3);
+    };
+    scale(acc, five); scale(b, seven);
+    acc = xyzz_add(acc, b);
+  } else {
+    acc = xyzz_dbl(acc);
+  }
+  xyzz_store_affine(acc, out);
+}
+// k * p by double-and-add on XYZZ (k: 4 x u64)
+void h_scalar_mul(const u64* p, const u64* k, u64* out) {
+  const Affine ap = load_affine(p);
+  Xyzz acc = xyzz_inf();
+  for (int i = 255; i >= 0; i--) {
+    acc = xyzz_dbl(acc);
+    if ((k[i >> 6] >> (i & 63)) & 1) xyzz_madd(acc, ap, false);
+  }
+  xyzz_store_affine(acc, out);
+}
+}

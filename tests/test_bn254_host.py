@@ -1,0 +1,79 @@
+"""csrc/bn254.h (the arithmetic under the BN254 MSM kernels and the MSM's host tail) compiled for the host and checked
+against oracle/bn254.py: Montgomery multiplication, add / sub / inverse, the XYZZ mixed addition, general addition and
+doubling including their special cases (P + P, P - P, infinity operands).  CPU only."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "build", "libbn254_host.so")
+
+
+@pytest.fixture(scope="module")
+def H():
+    src = os.path.join(ROOT, "tests", "emu", "bn254_host.cpp")
+    deps = [src, os.path.join(ROOT, "ronkathon_amd", "csrc", "bn254.h"), os.path.join(ROOT, "ronkathon_amd", "csrc", "bn254_consts.h")]
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, src])
+    return C.CDLL(SO)
+
+
+def w4(v):
+    return (C.c_uint64 * 4)(*[(v >> (64 * i)) & (2**64 - 1) for i in range(4)])
+
+
+def w8(pt):
+    x, y = (0, 0) if pt is None else pt
+    return (C.c_uint64 * 8)(*[(x >> (64 * i)) & (2**64 - 1) for i in range(4)], *[(y >> (64 * i)) & (2**64 - 1) for i in range(4)])
+
+
+def rd(a, off=0):
+    return sum(int(a[off + i]) << (64 * i) for i in range(4))
+
+
+def rdpt(a):
+    x, y = rd(a), rd(a, 4)
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def test_field_ops(H):
+    from oracle import bn254 as o
+    rng = random.Random(254)
+    edge = [0, 1, 2, o.P - 1, o.P - 2, (1 << 253) - 1, (1 << 253), 0xFFFFFFFF, 1 << 32, (1 << 224) - 1]
+    vals = edge + [rng.randrange(o.P) for _ in range(200)]
+    out = (C.c_uint64 * 4)()
+    for i, a in enumerate(vals):
+        b = vals[(7 * i + 3) % len(vals)]
+        H.h_fp_mul(w4(a), w4(b), out); assert rd(out) == a * b % o.P, (a, b)
+        H.h_fp_add(w4(a), w4(b), out); assert rd(out) == (a + b) % o.P
+        H.h_fp_sub(w4(a), w4(b), out); assert rd(out) == (a - b) % o.P
+        if a:
+            H.h_fp_inv(w4(a), out); assert rd(out) == pow(a, -1, o.P)
+    for v, want in ((o.P, 1), (o.P - 1, 0), (o.P + 1, 1), (2**256 - 1, 1), (0, 0), (1 << 253, 0)):
+        assert H.h_fp_geq_p(w4(v)) == want
+
+
+def test_group_law(H):
+    from oracle import bn254 as o
+    rng = random.Random(7)
+    pts = [o.mul(rng.randrange(1, o.R), o.G) for _ in range(12)] + [o.G, o.TWO_G, None]
+    out = (C.c_uint64 * 8)()
+    for p in pts:
+        assert H.h_on_curve(w8(p)) == (0 if p is None else 1)
+        for q in pts:
+            for neg in (0, 1):
+                qq = o.neg(q) if neg else q
+                for mode in (0, 1):
+                    H.h_point_op(w8(p), w8(q), neg, mode, out)
+                    assert rdpt(out) == o.add(p, qq), (p, q, neg, mode)
+        H.h_point_op(w8(p), w8(p), 0, 2, out)
+        assert rdpt(out) == o.add(p, p)
+    bad = (o.G[0], o.G[1] + 1)
+    assert H.h_on_curve(w8(bad)) == 0
+    for k in (0, 1, 2, o.R - 1, o.R, 2**256 - 1, rng.randrange(2**256)):
+        H.h_scalar_mul(w8(pts[0]), w4(k), out)
+        assert rdpt(out) == o.mul(k, pts[0]), k

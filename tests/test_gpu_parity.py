@@ -1028,3 +1028,85 @@ def test_large_plans_spot_and_roundtrip(R, orc, k):
         assert int(y[i]) == orc.poly_eval(GP, x, orc.pow_(GP, w, i)), (k, i)
     assert np.array_equal(plan.inverse(y), x)
     plan.close()
+
+
+# ---------------------------------------------------------------- row N4: bucket-method MSM over BN254 G1 (kzg::commit)
+def _bn254_words(points, scalars):
+    n = len(points)
+    pw = np.zeros((n, 8), dtype=np.uint64); sw = np.zeros((n, 4), dtype=np.uint64)
+    m64 = (1 << 64) - 1
+    for i, (pt, k) in enumerate(zip(points, scalars)):
+        if pt is not None:
+            pw[i] = [(pt[0] >> (64 * j)) & m64 for j in range(4)] + [(pt[1] >> (64 * j)) & m64 for j in range(4)]
+        sw[i] = [(int(k) >> (64 * j)) & m64 for j in range(4)]
+    return pw, sw
+
+
+def test_msm_bn254_small_vs_oracle(R):
+    """kzg::commit's fold (src/kzg/setup.rs:48-60) on BN254: random points and scalars against the oracle's affine fold,
+    with the cases the group law distinguishes: zero scalars, scalars >= r and the full 256 bits, the point at infinity, the
+    same point twice in one bucket (doubling inside the mixed addition), P and -P in one bucket (sum = infinity)"""
+    import random
+    from oracle import bn254 as o
+    from ronkathon_amd import callers
+    rng = random.Random(20)
+    base = [o.mul(rng.randrange(1, o.R), o.G) for _ in range(40)]
+    assert callers.msm_bn254([], []) is None
+    assert callers.msm_bn254([o.G], [0]) is None
+    assert callers.msm_bn254([o.G], [1]) == o.G
+    assert callers.msm_bn254([o.G], [o.R]) is None
+    assert callers.msm_bn254([o.G, o.G], [5, 5]) == o.mul(10, o.G)                 # equal points, equal digits: P + P
+    assert callers.msm_bn254([o.G, o.neg(o.G)], [77, 77]) is None                   # P + (-P)
+    assert callers.msm_bn254([None, o.G, None], [9, 2, 3]) == o.TWO_G               # infinity operands
+    for n in (1, 2, 3, 17, 64, 200):
+        pts = [base[rng.randrange(len(base))] if rng.random() < 0.8 else None for _ in range(n)]
+        ks = [rng.choice([0, 1, 2, o.R - 1, o.R, 2**256 - 1, rng.randrange(2**256), rng.randrange(o.R), rng.randrange(1 << 20)])
+              for _ in range(n)]
+        assert callers.msm_bn254(pts, ks) == o.msm(pts, ks), n
+    # every window size the planner can pick
+    pts = [base[i % len(base)] for i in range(300)]
+    ks = [rng.randrange(2**256) for _ in range(300)]
+    want = o.msm(pts, ks)
+    try:
+        for c in range(5, 17):
+            os.environ["RONK_MSM_C"] = str(c)
+            assert callers.msm_bn254(pts, ks) == want, c
+    finally:
+        os.environ.pop("RONK_MSM_C", None)
+
+
+def test_msm_bn254_rejects_bad_points(R):
+    from oracle import bn254 as o
+    from ronkathon_amd import _lib as L
+    for bad in ((o.G[0], o.G[1] + 1), (o.P, 2), (1, o.P + 2), (0, 1)):
+        pw, sw = _bn254_words([o.G, bad, o.TWO_G], [1, 2, 3])
+        out = np.zeros(8, dtype=np.uint64)
+        assert L.lib.ronk_msm_bn254(L.ptr(pw), L.ptr(sw), 3, L.ptr(out)) == -11      # RONK_ERR_NOT_ON_CURVE
+
+
+@pytest.mark.parametrize("logn", [12, 16, 20])
+def test_msm_bn254_large_structured(R, logn):
+    """full-size MSM through the device-pointer entry point: the points are known multiples a_i * G (built by the oracle's
+    repeated addition, tiled), so sum k_i P_i = (sum k_i a_i mod r) * G -- one oracle scalar multiplication checks 2^20
+    terms bit for bit"""
+    import torch
+    from oracle import bn254 as o
+    from ronkathon_amd import _lib as L
+    n = 1 << logn
+    m = min(n, 1 << 12)
+    mult = o.multiples(m)                                   # (j+1) * G
+    rng = np.random.default_rng(logn)
+    sw = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    sw[::7, 3] = 0; sw[::11, 2:] = 0; sw[5] = 0                      # short scalars, a zero
+    pw1, _ = _bn254_words(mult, [0] * m)
+    pw = np.tile(pw1, (n // m, 1))
+    acc = 0
+    a = np.tile(np.arange(1, m + 1, dtype=object), n // m)
+    ks = [sum(int(sw[i, j]) << (64 * j) for j in range(4)) for i in range(n)]
+    acc = sum(k * int(ai) for k, ai in zip(ks, a)) % o.R
+    want = o.mul(acc, o.G)
+    dp = torch.from_numpy(pw.view(np.int64)).cuda(); ds = torch.from_numpy(sw.view(np.int64)).cuda()
+    out = np.zeros(8, dtype=np.uint64)
+    L.check(L.lib.ronk_msm_bn254_dev(dp.data_ptr(), ds.data_ptr(), n, L.ptr(out), 0))
+    got = (sum(int(out[i]) << (64 * i) for i in range(4)), sum(int(out[4 + i]) << (64 * i) for i in range(4)))
+    assert got == want

@@ -224,3 +224,18 @@ def test_self_consistency_large():
     fa = orc.fft(GP, GG, orc.poly_from(a, 256)); fb = orc.fft(GP, GG, orc.poly_from(b, 256))
     c = orc.ifft(GP, GG, orc.vec_mul(GP, fa, fb))
     assert np.array_equal(c[:256], orc.poly_mul(GP, a, b))
+
+
+def test_bn254_oracle_pins():
+    """oracle/bn254.py against public constants and first principles (the reference has no 254-bit curve: 'derived' pins)"""
+    from oracle import bn254 as o
+    assert o.P == 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    assert o.R == 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    assert o.on_curve(o.G) and o.add(o.G, o.G) == o.TWO_G and o.mul(2, o.G) == o.TWO_G
+    assert o.mul(o.R, o.G) is None and o.mul(o.R - 1, o.G) == o.neg(o.G) and o.mul(o.R + 5, o.G) == o.mul(5, o.G)
+    assert o.add(o.G, o.neg(o.G)) is None and o.add(None, o.G) == o.G
+    pts = o.multiples(20)
+    assert all(o.on_curve(p) for p in pts) and pts[6] == o.mul(7, o.G)
+    ks = [3, 0, 2**255 + 12345, o.R - 1, 1] + list(range(5, 20))
+    want = o.mul(sum(k * (i + 1) for i, k in enumerate(ks)) % o.R, o.G)
+    assert o.msm(pts, ks) == want
