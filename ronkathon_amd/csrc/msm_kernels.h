@@ -8,7 +8,8 @@
 //   count     histogram of (window, |digit|) over all scalars                        } counting sort of the
 //   scan      exclusive prefix sum of the histogram                                  } n*W (point, sign)
 //   scatter   point indices (sign in bit 31) into their bucket's run                 } entries by bucket
-//   accumulate  one lane per bucket: XYZZ sum of its run (mixed additions, 8M + 2S each): the dominant kernel
+//   accumulate  one lane per TASK (<= CH entries of one bucket's run): XYZZ sum by mixed additions (8M + 2S each), the
+//             dominant kernel; collect / heavy fold the tasks of a bucket
 //   reduce    sum_b (b+1) B_b per window as bit planes: Q_k = sum of the buckets whose weight has bit k set (plain sums, no
 //             serial running-sum chain: a lane adds at most 16 points, then three to five 8-to-1 stages), the rest
 //             (sum_k 2^k Q_k, then Horner over the windows: ~270 dependent doublings) runs on the host, where one
@@ -69,41 +70,77 @@ __global__ void __launch_bounds__(256) msm_prepare_kernel(const u64* __restrict_
   out[i] = p;
 }
 
-// pass 1: histogram; pass 2 (SCATTER): entries into the runs
+// pass 1: histogram; pass 2 (SCATTER): entries into the runs.
+// Atomics on one address are served one after the other (~14 ns each): when the scalars share a digit -- the top window
+// of scalars shorter than 256 bits, or equal scalars -- half a million increments of ONE counter took 7 ms.  So a wave
+// first looks at how many of its lanes hold the key of their neighbour; if many do, lanes with equal keys elect a leader
+// that adds their count with one atomic (one pass per distinct key in the wave), else every lane issues its own.
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const u64* __restrict__ scalars, MsmShape sh, u32* __restrict__ counts,
                                                           u32* __restrict__ cursor, u32* __restrict__ entries) {
   const u32 i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= sh.n) return;
-  u64 k[4];
+  const bool live = i < sh.n;
+  const u32 lane = threadIdx.x & 63;
+  u64 k[4] = {0, 0, 0, 0};
+  if (live) {
 #pragma unroll
-  for (int j = 0; j < 4; j++) k[j] = scalars[(size_t)i * 4 + j];
+    for (int j = 0; j < 4; j++) k[j] = scalars[(size_t)i * 4 + j];
+  }
   u32 carry = 0;
+  u32* const ctr = SCATTER ? cursor : counts;
   for (u32 w = 0; w < sh.W; w++) {
     const int d = msm_digit(k, w, sh.c, &carry);
-    if (d == 0) continue;
+    const bool has = live && d != 0;
     const u32 mag = (u32)(d < 0 ? -d : d);
-    const u32 key = w * sh.NB + (mag - 1);
-    if (SCATTER) {
-      const u32 pos = atomicAdd(&cursor[key], 1u);
-      entries[pos] = i | (d < 0 ? 0x80000000u : 0u);
-    } else {
-      atomicAdd(&counts[key], 1u);
+    const u32 key = has ? w * sh.NB + (mag - 1) : 0xFFFFFFFFu;
+    const u32 ent = i | (d < 0 ? 0x80000000u : 0u);
+    const u32 up = __shfl_up(key, 1);
+    const bool same = has && lane > 0 && up == key;
+    if (__popcll(__ballot(same)) >= 16) {
+      bool todo = has;
+      while (__ballot(todo)) {
+        const unsigned long long pend = __ballot(todo);   // the key of the first lane that still has something to do
+        const int first = __ffsll((long long)pend) - 1;
+        const u32 kf = __shfl(key, first);
+        const bool mine = todo && key == kf;
+        const unsigned long long grp = __ballot(mine);
+        if (mine) {
+          const u32 cnt = (u32)__popcll(grp), rank = (u32)__popcll(grp & ((1ull << lane) - 1));
+          u32 basepos = 0;
+          if (rank == 0) basepos = atomicAdd(&ctr[kf], cnt);
+          basepos = __shfl(basepos, __ffsll((long long)grp) - 1);
+          if (SCATTER) entries[basepos + rank] = ent;
+          todo = false;
+        }
+      }
+    } else if (has) {
+      const u32 pos = atomicAdd(&ctr[key], 1u);
+      if (SCATTER) entries[pos] = ent;
     }
   }
 }
 
-// exclusive prefix sum of `m` counts by ONE workgroup of 1024 (m <= ~10^6): offsets[0..m], offsets[m] = total; also
-// copies the offsets into `cursor` for the scatter pass
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const u32* __restrict__ counts, u32 m, u32* __restrict__ offsets,
-                                                         u32* __restrict__ cursor) {
+// exclusive prefix sum of `m` counts (m up to a few 10^5), three launches: per-block totals (SCAN_BLK entries per workgroup),
+// one workgroup scanning the <= 1024 totals, then every workgroup scanning its own block from its base.  offsets[m] = total;
+// `cursor` (may be null) receives a copy of the offsets for the scatter pass.
+constexpr u32 SCAN_BLK = 1024;   // entries per workgroup of 256: 4 per lane
+__global__ void __launch_bounds__(256) msm_scan_totals_kernel(const u32* __restrict__ counts, u32 m, u32* __restrict__ totals) {
+  __shared__ u32 red[256];
+  const u32 tid = threadIdx.x, base = blockIdx.x * SCAN_BLK + tid * 4;
+  u32 s = 0;
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) s += base + j < m ? counts[base + j] : 0;
+  red[tid] = s;
+  __syncthreads();
+  for (u32 k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+  if (tid == 0) totals[blockIdx.x] = red[0];
+}
+// in-place exclusive scan of nb <= 1024 block totals; totals[nb] = grand total
+__global__ void __launch_bounds__(1024) msm_scan_mid_kernel(u32* __restrict__ totals, u32 nb) {
   __shared__ u32 part[1024];
   const u32 tid = threadIdx.x;
-  const u32 per = (m + 1023) / 1024;
-  const u32 lo = tid * per, hi = lo + per < m ? lo + per : m;
-  u32 s = 0;
-  for (u32 i = lo; i < hi; i++) s += counts[i];
-  part[tid] = s;
+  const u32 v0 = tid < nb ? totals[tid] : 0;
+  part[tid] = v0;
   __syncthreads();
   for (u32 off = 1; off < 1024; off <<= 1) {
     const u32 v = tid >= off ? part[tid - off] : 0;
@@ -111,25 +148,95 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const u32* __restrict__ 
     part[tid] += v;
     __syncthreads();
   }
-  u32 run = tid ? part[tid - 1] : 0;
-  for (u32 i = lo; i < hi; i++) { offsets[i] = run; cursor[i] = run; run += counts[i]; }
-  if (tid == 1023) offsets[m] = part[1023];
+  if (tid < nb) totals[tid] = part[tid] - v0;
+  if (tid == 1023) totals[nb] = part[1023];
+}
+__global__ void __launch_bounds__(256) msm_scan_apply_kernel(const u32* __restrict__ counts, u32 m, const u32* __restrict__ totals,
+                                                              u32 nb, u32* __restrict__ offsets, u32* __restrict__ cursor) {
+  __shared__ u32 part[256];
+  const u32 tid = threadIdx.x, base = blockIdx.x * SCAN_BLK + tid * 4;
+  u32 c[4], s = 0;
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) { c[j] = base + j < m ? counts[base + j] : 0; s += c[j]; }
+  part[tid] = s;
+  __syncthreads();
+  for (u32 off = 1; off < 256; off <<= 1) {
+    const u32 v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  u32 run = totals[blockIdx.x] + part[tid] - s;
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) {
+    if (base + j < m) { offsets[base + j] = run; if (cursor) cursor[base + j] = run; }
+    run += c[j];
+  }
+  if (blockIdx.x == 0 && tid == 0) offsets[m] = totals[nb];
 }
 
-// one lane per bucket: sum of its run
+// Buckets are summed in TASKS of at most CH entries, so that one heavy bucket (every scalar shares its top digit, or all
+// scalars are equal: n entries in one run) cannot serialise the launch: ntasks[key] = ceil(count/CH) goes through the
+// same scan as the counts; one lane per task adds its slice of the run; msm_collect_kernel then folds the tasks of a
+// bucket (normally one: a copy), leaving buckets with more than 8 tasks to msm_heavy_kernel (one workgroup per bucket:
+// strided partial sums, then a tree in LDS).
+__global__ void __launch_bounds__(256) msm_ntasks_kernel(const u32* __restrict__ counts, u32 keys, u32 ch, u32* __restrict__ ntasks) {
+  const u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k < keys) ntasks[k] = (counts[k] + ch - 1) / ch;
+}
+
+// task t -> (key, slice): largest key with toff[key] <= t
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine* __restrict__ pts, const u32* __restrict__ offsets,
-                                                              const u32* __restrict__ entries, u32 nbuckets,
-                                                              Xyzz* __restrict__ buckets) {
-  const u32 b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= nbuckets) return;
-  const u32 lo = offsets[b], hi = offsets[b + 1];
+                                                              const u32* __restrict__ entries, const u32* __restrict__ toff,
+                                                              u32 keys, u32 ch, Xyzz* __restrict__ partial) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= toff[keys]) return;
+  u32 lo = 0, hi = keys;            // invariant: toff[lo] <= t < toff[hi]
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (toff[mid] <= t) lo = mid; else hi = mid;
+  }
+  const u32 key = lo, j = t - toff[key];
+  const u32 b0 = offsets[key] + j * ch, bend = offsets[key + 1];
+  const u32 e1 = b0 + ch < bend ? b0 + ch : bend;
   Xyzz acc = bn254::xyzz_inf();
-  for (u32 e = lo; e < hi; e++) {
+  for (u32 e = b0; e < e1; e++) {
     const u32 ent = entries[e];
     const Affine p = pts[ent & 0x7FFFFFFFu];
     bn254::xyzz_madd(acc, p, (ent >> 31) != 0);
   }
-  buckets[b] = acc;
+  partial[t] = acc;
+}
+
+__global__ void __launch_bounds__(256) msm_collect_kernel(const Xyzz* __restrict__ partial, const u32* __restrict__ toff, u32 keys,
+                                                           Xyzz* __restrict__ buckets, u32* __restrict__ heavy, u32* __restrict__ nheavy) {
+  const u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= keys) return;
+  const u32 t0 = toff[k], T = toff[k + 1] - t0;
+  if (T > 8) { heavy[atomicAdd(nheavy, 1u)] = k; return; }
+  Xyzz acc = bn254::xyzz_inf();
+  for (u32 i = 0; i < T; i++) acc = i ? bn254::xyzz_add(acc, partial[t0 + i]) : partial[t0];
+  buckets[k] = acc;
+}
+
+__global__ void __launch_bounds__(256) msm_heavy_kernel(const Xyzz* __restrict__ partial, const u32* __restrict__ toff,
+                                                         const u32* __restrict__ heavy, const u32* __restrict__ nheavy,
+                                                         Xyzz* __restrict__ buckets) {
+  __shared__ Xyzz red[256];
+  const u32 tid = threadIdx.x;
+  for (u32 h = blockIdx.x; h < *nheavy; h += gridDim.x) {
+    const u32 k = heavy[h], t0 = toff[k], T = toff[k + 1] - t0;
+    Xyzz acc = bn254::xyzz_inf();
+    for (u32 i = tid; i < T; i += 256) acc = bn254::xyzz_add(acc, partial[t0 + i]);
+    red[tid] = acc;
+    __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] = bn254::xyzz_add(red[tid], red[tid + s]);
+      __syncthreads();
+    }
+    if (tid == 0) buckets[k] = red[0];
+    __syncthreads();
+  }
 }
 
 // bit planes, first stage: out[(w*K + k)*G + g] = sum of buckets b in [16g, 16g+16) of window w whose weight (b+1) has

@@ -18,10 +18,27 @@ u32 pick_window(size_t n) {
   return (u32)c;
 }
 
+// grow-only device buffer (the MSM workspace is cached per device: thirteen hipMalloc / hipFree pairs cost more than a
+// 2^16-point MSM)
+struct GrowBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int alloc(size_t bytes) {
+    if (bytes <= cap) return RONK_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (MSM workspace)");
+    cap = bytes;
+    return RONK_OK;
+  }
+};
 struct MsmWork {
   MsmShape sh;
-  DevBuf pts, counts, offsets, cursor, entries, buckets, st0, st1, status;
+  GrowBuf pts, counts, offsets, cursor, entries, buckets, st0, st1, status, ntasks, toff, partial, heavy, totals;
+  u32 ch = 0, max_tasks = 0;
   size_t planes = 0;   // W * c rows of the bit-plane reduction
+  std::mutex mu;       // one MSM at a time per device workspace
   int alloc(size_t n) {
     sh.n = (u32)n;
     sh.c = pick_window(n);
@@ -38,6 +55,15 @@ struct MsmWork {
     RCHK(st0.alloc(planes * (sh.NB / 16) * sizeof(Xyzz)));
     RCHK(st1.alloc(planes * ((sh.NB / 16 + 7) / 8) * sizeof(Xyzz)));
     RCHK(status.alloc(8));
+    // tasks of at most ch entries: ~2x the mean run, at least 16; every non-empty bucket has one, plus one per ch entries
+    size_t mean = n / sh.NB;
+    ch = (u32)(2 * mean < 16 ? 16 : 2 * mean);
+    max_tasks = (u32)(keys + (n * sh.W) / ch + 1);
+    RCHK(ntasks.alloc(keys * 4));
+    RCHK(toff.alloc((keys + 1) * 4));
+    RCHK(partial.alloc((size_t)max_tasks * sizeof(Xyzz)));
+    RCHK(heavy.alloc(keys * 4));
+    RCHK(totals.alloc((1024 + 1) * 4));
     return RONK_OK;
   }
 };
@@ -57,10 +83,24 @@ void msm_host_tail(const MsmShape& sh, const Xyzz* rows, u64 out[8]) {
   bn254::xyzz_store_affine(total, out);
 }
 
+// offsets[0..m] = exclusive prefix sums of counts[0..m) (+ a copy in cursor, may be null)
+void msm_scan(MsmWork& wk, const u32* counts, u32 m, u32* offsets, u32* cursor, hipStream_t s) {
+  const u32 nb = (m + SCAN_BLK - 1) / SCAN_BLK;   // <= 1024 for every window size (17 * 2^15 keys = 544 blocks)
+  u32* totals = (u32*)wk.totals.p;
+  hipLaunchKernelGGL(msm_scan_totals_kernel, dim3(nb), dim3(256), 0, s, counts, m, totals);
+  hipLaunchKernelGGL(msm_scan_mid_kernel, dim3(1), dim3(1024), 0, s, totals, nb);
+  hipLaunchKernelGGL(msm_scan_apply_kernel, dim3(nb), dim3(256), 0, s, counts, m, (const u32*)totals, nb, offsets, cursor);
+}
+
 int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hipStream_t s) {
   if (n == 0) { for (int i = 0; i < 8; i++) out[i] = 0; return RONK_OK; }
   if (n >= ((size_t)1 << 31)) return RONK_ERR_UNSUPPORTED;
-  MsmWork wk;
+  static MsmWork g_work[64];
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return RONK_ERR_INVALID;
+  MsmWork& wk = g_work[dev];
+  std::lock_guard<std::mutex> lk(wk.mu);
   RCHK(wk.alloc(n));
   const MsmShape sh = wk.sh;
   const u32 keys = sh.W * sh.NB;
@@ -70,12 +110,19 @@ int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hip
   hipLaunchKernelGGL(msm_prepare_kernel, dim3(gn), dim3(256), 0, s, d_points, sh.n, (Affine*)wk.pts.p, (int*)wk.status.p);
   hipLaunchKernelGGL((msm_digits_kernel<false>), dim3(gn), dim3(256), 0, s, d_scalars, sh, (u32*)wk.counts.p, (u32*)nullptr,
                      (u32*)nullptr);
-  hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)wk.counts.p, keys, (u32*)wk.offsets.p,
-                     (u32*)wk.cursor.p);
+  msm_scan(wk, (const u32*)wk.counts.p, keys, (u32*)wk.offsets.p, (u32*)wk.cursor.p, s);
   hipLaunchKernelGGL((msm_digits_kernel<true>), dim3(gn), dim3(256), 0, s, d_scalars, sh, (u32*)nullptr, (u32*)wk.cursor.p,
                      (u32*)wk.entries.p);
-  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((keys + 255) / 256), dim3(256), 0, s, (const Affine*)wk.pts.p,
-                     (const u32*)wk.offsets.p, (const u32*)wk.entries.p, keys, (Xyzz*)wk.buckets.p);
+  hipLaunchKernelGGL(msm_ntasks_kernel, dim3((keys + 255) / 256), dim3(256), 0, s, (const u32*)wk.counts.p, keys, wk.ch,
+                     (u32*)wk.ntasks.p);
+  msm_scan(wk, (const u32*)wk.ntasks.p, keys, (u32*)wk.toff.p, nullptr, s);
+  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((wk.max_tasks + 255) / 256), dim3(256), 0, s, (const Affine*)wk.pts.p,
+                     (const u32*)wk.offsets.p, (const u32*)wk.entries.p, (const u32*)wk.toff.p, keys, wk.ch,
+                     (Xyzz*)wk.partial.p);
+  hipLaunchKernelGGL(msm_collect_kernel, dim3((keys + 255) / 256), dim3(256), 0, s, (const Xyzz*)wk.partial.p,
+                     (const u32*)wk.toff.p, keys, (Xyzz*)wk.buckets.p, (u32*)wk.heavy.p, (u32*)wk.status.p + 1);
+  hipLaunchKernelGGL(msm_heavy_kernel, dim3(256), dim3(256), 0, s, (const Xyzz*)wk.partial.p, (const u32*)wk.toff.p,
+                     (const u32*)wk.heavy.p, (const u32*)wk.status.p + 1, (Xyzz*)wk.buckets.p);
   const u32 rows = (u32)wk.planes;
   u32 cnt = sh.NB / 16;
   hipLaunchKernelGGL(msm_bitplane_kernel, dim3((rows * cnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)wk.buckets.p, sh,

@@ -1075,6 +1075,30 @@ def test_msm_bn254_small_vs_oracle(R):
         os.environ.pop("RONK_MSM_C", None)
 
 
+def test_msm_bn254_heavy_buckets(R):
+    """every scalar equal (ONE bucket per window holds all n entries), scalars that share their top digit, a single
+    point repeated: the runs are cut in tasks and folded by the collect / heavy kernels"""
+    import random
+    from oracle import bn254 as o
+    from ronkathon_amd import callers
+    rng = random.Random(5)
+    n = 3000
+    pts = o.multiples(n)
+    tri = n * (n + 1) // 2
+    assert callers.msm_bn254(pts, [1] * n) == o.mul(tri % o.R, o.G)
+    k = rng.randrange(o.R)
+    assert callers.msm_bn254(pts, [k] * n) == o.mul(k * tri % o.R, o.G)
+    ks = [(1 << 252) + rng.randrange(1 << 40) for _ in range(n)]                    # same top digits, different low ones
+    assert callers.msm_bn254(pts, ks) == o.mul(sum(kk * (i + 1) for i, kk in enumerate(ks)) % o.R, o.G)
+    assert callers.msm_bn254([o.TWO_G] * n, ks) == o.mul(2 * sum(ks) % o.R, o.G)    # one point, n times
+    try:
+        for c in (5, 9, 16):
+            os.environ["RONK_MSM_C"] = str(c)
+            assert callers.msm_bn254(pts, [k] * n) == o.mul(k * tri % o.R, o.G), c
+    finally:
+        os.environ.pop("RONK_MSM_C", None)
+
+
 def test_msm_bn254_rejects_bad_points(R):
     from oracle import bn254 as o
     from ronkathon_amd import _lib as L
