@@ -111,40 +111,73 @@ RONK_HD Fp fp_sub(const Fp& a, const Fp& b) {
 RONK_HD Fp fp_neg(const Fp& a) { return fp_is_zero(a) ? a : fp_sub(fp_zero(), a); }
 RONK_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
-// Montgomery product a*b/R mod p, CIOS on 32-bit limbs: every inner step is t + a_j*b_i + carry <= 2^64 - 1
+// ---- Montgomery product a*b/R mod p.
+// Product scanning (FIPS): column i of the 16-limb sum a*b + m*p is accumulated in ONE 96-bit register triple
+// (lo:64, hi:32), then its low limb is dropped.  On the device every product is
+//     v_mad_u64_u32  lo, carry, x, y, lo        (32 x 32 + 64 -> 64, carry-out to an SGPR pair)
+//     v_addc_co_u32  hi, _, 0, hi, carry
+// i.e. two VALU instructions per limb product and no register moves: the row-wise (CIOS) form, whose inner step is
+// t + a*b + c with two 32-bit addends, compiles to mad + 64-bit add + THREE v_mov for the zero-extended operand pairs
+// (5 534 v_mov of 11 375 VALU instructions in the first accumulate kernel).  Products are issued in pairs so that the
+// two wait states gfx950 wants between a VALU writing an SGPR and a VALU reading it are real work (mad, mad, s_nop 0, addc, addc).
+// The compiler never uses the mad's carry-out, hence the inline asm; the host build (tests, the MSM's host tail) runs the
+// same algorithm on unsigned __int128.
+struct Acc96 { u64 lo; u32 hi; };
+RONK_HD void acc_mad(Acc96& t, u32 x, u32 y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 c;
+  asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, %1, %2"
+      : "+v"(t.lo), "+v"(t.hi), "=&s"(c)
+      : "v"(x), "v"(y)
+      : "vcc");
+#else
+  const unsigned __int128 s = (((unsigned __int128)t.hi << 64) | t.lo) + (unsigned __int128)((u64)x * y);
+  t.lo = (u64)s; t.hi = (u32)(s >> 64);
+#endif
+}
+// t += x1*y1 + x2*y2  (y2 may sit in an SGPR: the modulus limbs are constants)
+RONK_HD void acc_mad2(Acc96& t, u32 x1, u32 y1, u32 x2, u32 y2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 c1, c2;
+  asm("v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, %1, %3"
+      : "+v"(t.lo), "+v"(t.hi), "=&s"(c1), "=&s"(c2)
+      : "v"(x1), "v"(y1), "v"(x2), "s"(y2)
+      : "vcc");
+#else
+  acc_mad(t, x1, y1);
+  acc_mad(t, x2, y2);
+#endif
+}
+RONK_HD void acc_shift(Acc96& t) { t.lo = (t.lo >> 32) | ((u64)t.hi << 32); t.hi = 0; }
+
 RONK_HD Fp fp_mul(const Fp& a, const Fp& b) {
-  u32 t[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) t[i] = 0;
+  u32 m[8];
+  Fp r;
+  Acc96 t;
+  t.lo = 0; t.hi = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    u64 c = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const u64 uv = (u64)a.l[j] * b.l[i] + t[j] + c;
-      t[j] = (u32)uv;
-      c = uv >> 32;
-    }
-    u64 uv = (u64)t[8] + c;
-    t[8] = (u32)uv;
-    t[9] = (u32)(uv >> 32);
-    const u32 m = t[0] * BN254_N0INV;
-    uv = (u64)m * P_limb(0) + t[0];
-    c = uv >> 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      uv = (u64)m * P_limb(j) + t[j] + c;
-      t[j - 1] = (u32)uv;
-      c = uv >> 32;
-    }
-    uv = (u64)t[8] + c;
-    t[7] = (u32)uv;
-    t[8] = t[9] + (u32)(uv >> 32);
+    for (int j = 0; j < i; j++) acc_mad2(t, a.l[j], b.l[i - j], m[j], P_limb(i - j));
+    acc_mad(t, a.l[i], b.l[0]);
+    m[i] = (u32)t.lo * BN254_N0INV;
+    acc_mad(t, m[i], P_limb(0));          // the low limb becomes zero
+    acc_shift(t);
   }
-  Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = t[i];
-  return fp_cond_sub_p(r, t[8]);
+  for (int i = 8; i < 16; i++) {
+#pragma unroll
+    for (int j = i - 7; j < 8; j++) acc_mad2(t, a.l[j], b.l[i - j], m[j], P_limb(i - j));
+    r.l[i - 8] = (u32)t.lo;
+    acc_shift(t);
+  }
+  return fp_cond_sub_p(r, (u32)t.lo);
 }
 RONK_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 

@@ -30,6 +30,8 @@ extern "C" {
   pub fn ronk_lagrange_eval(p: u64, c: *const u64, nodes: *const u64, n: usize, x: u64, out: *mut u64) -> c_int;
   /// `Message::decode` (src/codes/reed_solomon.rs:54-106)
   pub fn ronk_rs_decode(p: u64, xs: *const u64, ys: *const u64, k: usize, out: *mut u64) -> c_int;
+  /// `kzg::commit` (src/kzg/setup.rs:48-60) over BN254 G1: points n x [x: 4 limbs, y: 4 limbs], scalars n x 4 limbs
+  pub fn ronk_msm_bn254(points: *const u64, scalars: *const u64, n: usize, out: *mut u64) -> c_int;
 }
 
 /// 0 -> (), anything else -> the reference's panic

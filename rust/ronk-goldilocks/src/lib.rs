@@ -6,6 +6,7 @@
 //!   `Polynomial<B, F, D>`, `src/kzg`, `src/codes` -- compiles against it unchanged.
 //! * [`polynomial::Accelerated`] / [`polynomial::AcceleratedLagrange`] -- `fft` / `ifft` / `dft` / `Mul` / `Div` / `Rem` /
 //!   `evaluate` on the GPU through the C ABI (include/ronk_ntt.h), bit-exact with the reference's CPU results.
+//! * [`bn254::commit`] -- `kzg::commit` (src/kzg/setup.rs:48-60) over BN254 G1 through the GPU's bucket-method MSM.
 //! * `in_tree/` -- how the same bodies become specialisations when vendored inside ronkathon, so call sites do not change.
 //!
 //! The nightly features mirror ronkathon's own (src/lib.rs:15-24); `generic_const_exprs` is needed for `D + D2 - 1`.
@@ -14,6 +15,7 @@
 #![feature(const_trait_impl)]
 #![feature(effects)]
 
+pub mod bn254;
 pub mod ffi;
 pub mod field;
 pub mod polynomial;
