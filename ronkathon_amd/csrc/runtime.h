@@ -127,8 +127,9 @@ struct CompiledPlan {
   // in_poly_stride (multi-pass plans, 0 = n): element stride between the polynomials of a batched input
   // x0_add: added to the X offset of passes whose inter-pass twiddle depends on the column (column chunks of the
   // sharded four-step: chunk j starts j*Cwc columns further right, ronk_dist.hip)
+  // sb0 / sbn: launch the pass for polynomials [sb0, sb0 + sbn) of the batch only (sbn = 0: all of them)
   int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0) const {
+             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u32 sb0 = 0, u32 sbn = 0) const {
     const PassDesc& ps = pd.passes[idx];
     TileArgs a = ps.args;
     const u64* bufs_in[3] = {in, out, tmp};
@@ -146,12 +147,40 @@ struct CompiledPlan {
     a.wr = d_wr[ps.wr_id];
     if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
     if (ps.twf_id >= 0) a.tw_full = d_twf[ps.twf_id];
-    hipError_t e = launch_tile(ps.logr, pd.inverse, a, ps.grid, ps.block, ps.lds_bytes, s);
+    u32 grid = ps.grid;
+    if (sbn) {   // a slice of the batch axis b1: shift the three base pointers, shrink the grid
+      a.in += (i64)sb0 * a.in_sb1;
+      if (a.in2) a.in2 += (i64)sb0 * a.in_sb1;
+      a.out += (i64)sb0 * a.out_sb1;
+      grid = ps.grid / a.nb1 * sbn;
+      a.nb1 = sbn;
+    }
+    hipError_t e = launch_tile(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s);
     if (e != hipSuccess) return hip_fail(e, "launch_tile");
     return RONK_OK;
   }
+  // Large batches of multi-pass plans run in SLICES of the batch axis, all passes of a slice before the next slice: the
+  // scratch a slice writes in one pass is read back by the next pass while it is still in the 256 MB Infinity Cache,
+  // instead of streaming the whole batch (512 MiB for 1024 x 2^16) through HBM between the passes.
+  // RONK_SUB_BATCH_MIB: slice size in MiB of coefficients (0 = off).
   int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
           u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0) const {
+    static const long slice_mib = [] { const char* e = getenv("RONK_SUB_BATCH_MIB"); return e ? atol(e) : 0L; }();
+    const u64 n = (u64)1 << pd.log2n;
+    if (slice_mib > 0 && pd.passes.size() >= 2 && pd.batch > 1) {
+      u64 per = ((u64)slice_mib << 20) / (n * 8);
+      if (per < 1) per = 1;
+      bool ok = per < pd.batch;
+      for (auto& ps : pd.passes) ok = ok && ps.args.nb1 == pd.batch;
+      if (ok) {
+        for (u64 b0 = 0; b0 < pd.batch; b0 += per) {
+          const u32 cnt = (u32)(pd.batch - b0 < per ? pd.batch - b0 : per);
+          for (size_t i = 0; i < pd.passes.size(); i++)
+            RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, (u32)b0, cnt));
+        }
+        return RONK_OK;
+      }
+    }
     for (size_t i = 0; i < pd.passes.size(); i++)
       RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add));
     return RONK_OK;
