@@ -5,9 +5,8 @@
 // field elements mod r), split in W signed digits of c bits, digit in [-2^(c-1), 2^(c-1)]:
 //
 //   prepare   points -> Montgomery form, on-curve check (AffinePoint::new's assert, src/curve/mod.rs:79)
-//   count     histogram of (window, |digit|) over all scalars                        } counting sort of the
-//   scan      exclusive prefix sum of the histogram                                  } n*W (point, sign)
-//   scatter   point indices (sign in bit 31) into their bucket's run                 } entries by bucket
+//   carries / hist / scan / place   counting sort of the n*W (point, sign) entries by (window, bucket) with the counters of
+//             a window in LDS (no global atomics)
 //   accumulate  one lane per TASK (<= CH entries of one bucket's run): XYZZ sum by mixed additions (8M + 2S each), the
 //             dominant kernel; collect / heavy fold the tasks of a bucket
 //   reduce    sum_b (b+1) B_b per window as bit planes: Q_k = sum of the buckets whose weight has bit k set (plain sums, no
@@ -70,66 +69,88 @@ __global__ void __launch_bounds__(256) msm_prepare_kernel(const u64* __restrict_
   out[i] = p;
 }
 
-// pass 1: histogram; pass 2 (SCATTER): entries into the runs.
-// Atomics on one address are served one after the other (~14 ns each): when the scalars share a digit -- the top window
-// of scalars shorter than 256 bits, or equal scalars -- half a million increments of ONE counter took 7 ms.  So a wave
-// first looks at how many of its lanes hold the key of their neighbour; if many do, lanes with equal keys elect a leader
-// that adds their count with one atomic (one pass per distinct key in the wave), else every lane issues its own.
-template <bool SCATTER>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const u64* __restrict__ scalars, MsmShape sh, u32* __restrict__ counts,
-                                                          u32* __restrict__ cursor, u32* __restrict__ entries) {
+// ---- counting sort of the n*W (point, sign) entries by (window, bucket), without global atomics ----------------------------
+// (First version: one global atomicAdd per entry in a count pass and a returning one in a scatter pass: 0.64 + 1.56 ms
+// of a 7.7 ms MSM at 2^20 points, and 7 ms each when the scalars share a digit -- same-address atomics are served one
+// after the other.)  Now a workgroup owns (window w, chunk of the scalars) and keeps that window's 2^(c-1) counters in
+// LDS:
+//   carries   per scalar, the W carry bits of the signed-digit recoding (bit w = carry INTO window w), so that any window's
+//             digit can be computed on its own
+//   hist      LDS histogram of the chunk's digits for window w -> hist[key][chunk]        (key-major: a scan over the flat
+//   scan      array yields, for every key, the start of each chunk's share of its run, and offsets[key] = pos[key][0])
+//   place     LDS cursors initialised from pos[key][chunk]; ds_add_rtn hands out the slots; entries[slot] = point | sign
+constexpr u32 MSM_SORT_WG = 1024;
+
+__global__ void __launch_bounds__(256) msm_carries_kernel(const u64* __restrict__ scalars, MsmShape sh, u64* __restrict__ carries) {
   const u32 i = blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < sh.n;
-  const u32 lane = threadIdx.x & 63;
-  u64 k[4] = {0, 0, 0, 0};
-  if (live) {
+  if (i >= sh.n) return;
+  u64 k[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) k[j] = scalars[(size_t)i * 4 + j];
+  u32 carry = 0;
+  u64 mask = 0;   // W <= 52 windows (c >= 5)
+  for (u32 w = 0; w < sh.W; w++) {
+    mask |= (u64)carry << w;
+    (void)msm_digit(k, w, sh.c, &carry);
+  }
+  carries[i] = mask;
+}
+
+// PLACE = false: hist[(w*NB + b)*chunks + chunk] = number of entries; PLACE = true: entries placed from pos[...]
+template <bool PLACE>
+__global__ void __launch_bounds__(MSM_SORT_WG) msm_sort_kernel(const u64* __restrict__ scalars, const u64* __restrict__ carries,
+                                                                MsmShape sh, u32 chunk_size, u32 chunks, u32* __restrict__ hist,
+                                                                const u32* __restrict__ pos, u32* __restrict__ entries) {
+  extern __shared__ u32 lds_cnt[];   // NB counters / cursors
+  const u32 tid = threadIdx.x, chunk = blockIdx.x, w = blockIdx.y;
+  const size_t kbase = (size_t)w * sh.NB;
+  for (u32 b = tid; b < sh.NB; b += MSM_SORT_WG) lds_cnt[b] = PLACE ? pos[(kbase + b) * chunks + chunk] : 0;
+  __syncthreads();
+  const u32 i0 = chunk * chunk_size, i1 = i0 + chunk_size < sh.n ? i0 + chunk_size : sh.n;
+  for (u32 i = i0 + tid; i < i1; i += MSM_SORT_WG) {
+    // only the words the window touches are needed, but the four loads are one 32-byte segment anyway
+    u64 k[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) k[j] = scalars[(size_t)i * 4 + j];
-  }
-  u32 carry = 0;
-  u32* const ctr = SCATTER ? cursor : counts;
-  for (u32 w = 0; w < sh.W; w++) {
+    u32 carry = (u32)(carries[i] >> w) & 1;
     const int d = msm_digit(k, w, sh.c, &carry);
-    const bool has = live && d != 0;
-    const u32 mag = (u32)(d < 0 ? -d : d);
-    const u32 key = has ? w * sh.NB + (mag - 1) : 0xFFFFFFFFu;
-    const u32 ent = i | (d < 0 ? 0x80000000u : 0u);
-    const u32 up = __shfl_up(key, 1);
-    const bool same = has && lane > 0 && up == key;
-    if (__popcll(__ballot(same)) >= 16) {
-      bool todo = has;
-      while (__ballot(todo)) {
-        const unsigned long long pend = __ballot(todo);   // the key of the first lane that still has something to do
-        const int first = __ffsll((long long)pend) - 1;
-        const u32 kf = __shfl(key, first);
-        const bool mine = todo && key == kf;
-        const unsigned long long grp = __ballot(mine);
-        if (mine) {
-          const u32 cnt = (u32)__popcll(grp), rank = (u32)__popcll(grp & ((1ull << lane) - 1));
-          u32 basepos = 0;
-          if (rank == 0) basepos = atomicAdd(&ctr[kf], cnt);
-          basepos = __shfl(basepos, __ffsll((long long)grp) - 1);
-          if (SCATTER) entries[basepos + rank] = ent;
-          todo = false;
-        }
-      }
-    } else if (has) {
-      const u32 pos = atomicAdd(&ctr[key], 1u);
-      if (SCATTER) entries[pos] = ent;
+    if (d == 0) continue;
+    const u32 b = (u32)(d < 0 ? -d : d) - 1;
+    if (PLACE) {
+      const u32 slot = atomicAdd(&lds_cnt[b], 1u);
+      entries[slot] = i | (d < 0 ? 0x80000000u : 0u);
+    } else {
+      atomicAdd(&lds_cnt[b], 1u);
     }
+  }
+  if (!PLACE) {
+    __syncthreads();
+    for (u32 b = tid; b < sh.NB; b += MSM_SORT_WG) hist[(kbase + b) * chunks + chunk] = lds_cnt[b];
   }
 }
 
-// exclusive prefix sum of `m` counts (m up to a few 10^5), three launches: per-block totals (SCAN_BLK entries per workgroup),
-// one workgroup scanning the <= 1024 totals, then every workgroup scanning its own block from its base.  offsets[m] = total;
-// `cursor` (may be null) receives a copy of the offsets for the scatter pass.
-constexpr u32 SCAN_BLK = 1024;   // entries per workgroup of 256: 4 per lane
-__global__ void __launch_bounds__(256) msm_scan_totals_kernel(const u32* __restrict__ counts, u32 m, u32* __restrict__ totals) {
+// offsets[key] = pos[key*chunks] (start of the key's run), offsets[keys] = total; counts / ntasks from neighbours
+__global__ void __launch_bounds__(256) msm_offsets_kernel(const u32* __restrict__ pos, u32 keys, u32 chunks, u32 ch,
+                                                           u32* __restrict__ offsets, u32* __restrict__ ntasks) {
+  const u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k > keys) return;
+  const u32 o = pos[(size_t)k * chunks];          // k == keys: pos[keys*chunks] = total
+  offsets[k] = o;
+  if (k < keys) {
+    const u32 cnt = pos[(size_t)(k + 1) * chunks] - o;
+    ntasks[k] = (cnt + ch - 1) / ch;
+  }
+}
+
+// exclusive prefix sum of `m` counts, three launches: per-block totals (256 lanes x `per` consecutive entries per
+// workgroup; the host picks `per` so that there are at most 1024 blocks), one workgroup scanning the block totals, then
+// every workgroup scanning its own block from its base.  offsets[m] = total.
+__global__ void __launch_bounds__(256) msm_scan_totals_kernel(const u32* __restrict__ counts, u32 m, u32 per, u32* __restrict__ totals) {
   __shared__ u32 red[256];
-  const u32 tid = threadIdx.x, base = blockIdx.x * SCAN_BLK + tid * 4;
+  const u32 tid = threadIdx.x;
+  const size_t base = ((size_t)blockIdx.x * 256 + tid) * per;
   u32 s = 0;
-#pragma unroll
-  for (u32 j = 0; j < 4; j++) s += base + j < m ? counts[base + j] : 0;
+  for (u32 j = 0; j < per; j++) s += base + j < m ? counts[base + j] : 0;
   red[tid] = s;
   __syncthreads();
   for (u32 k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
@@ -151,13 +172,13 @@ __global__ void __launch_bounds__(1024) msm_scan_mid_kernel(u32* __restrict__ to
   if (tid < nb) totals[tid] = part[tid] - v0;
   if (tid == 1023) totals[nb] = part[1023];
 }
-__global__ void __launch_bounds__(256) msm_scan_apply_kernel(const u32* __restrict__ counts, u32 m, const u32* __restrict__ totals,
-                                                              u32 nb, u32* __restrict__ offsets, u32* __restrict__ cursor) {
+__global__ void __launch_bounds__(256) msm_scan_apply_kernel(const u32* __restrict__ counts, u32 m, u32 per,
+                                                              const u32* __restrict__ totals, u32 nb, u32* __restrict__ offsets) {
   __shared__ u32 part[256];
-  const u32 tid = threadIdx.x, base = blockIdx.x * SCAN_BLK + tid * 4;
-  u32 c[4], s = 0;
-#pragma unroll
-  for (u32 j = 0; j < 4; j++) { c[j] = base + j < m ? counts[base + j] : 0; s += c[j]; }
+  const u32 tid = threadIdx.x;
+  const size_t base = ((size_t)blockIdx.x * 256 + tid) * per;
+  u32 s = 0;
+  for (u32 j = 0; j < per; j++) s += base + j < m ? counts[base + j] : 0;
   part[tid] = s;
   __syncthreads();
   for (u32 off = 1; off < 256; off <<= 1) {
@@ -167,10 +188,8 @@ __global__ void __launch_bounds__(256) msm_scan_apply_kernel(const u32* __restri
     __syncthreads();
   }
   u32 run = totals[blockIdx.x] + part[tid] - s;
-#pragma unroll
-  for (u32 j = 0; j < 4; j++) {
-    if (base + j < m) { offsets[base + j] = run; if (cursor) cursor[base + j] = run; }
-    run += c[j];
+  for (u32 j = 0; j < per; j++) {
+    if (base + j < m) { const u32 c = counts[base + j]; offsets[base + j] = run; run += c; }
   }
   if (blockIdx.x == 0 && tid == 0) offsets[m] = totals[nb];
 }
@@ -178,13 +197,8 @@ __global__ void __launch_bounds__(256) msm_scan_apply_kernel(const u32* __restri
 // Buckets are summed in TASKS of at most CH entries, so that one heavy bucket (every scalar shares its top digit, or all
 // scalars are equal: n entries in one run) cannot serialise the launch: ntasks[key] = ceil(count/CH) goes through the
 // same scan as the counts; one lane per task adds its slice of the run; msm_collect_kernel then folds the tasks of a
-// bucket (normally one: a copy), leaving buckets with more than 8 tasks to msm_heavy_kernel (one workgroup per bucket:
+// bucket (normally one: a copy), leaving buckets with more than 24 tasks to msm_heavy_kernel (one workgroup per bucket:
 // strided partial sums, then a tree in LDS).
-__global__ void __launch_bounds__(256) msm_ntasks_kernel(const u32* __restrict__ counts, u32 keys, u32 ch, u32* __restrict__ ntasks) {
-  const u32 k = blockIdx.x * 256 + threadIdx.x;
-  if (k < keys) ntasks[k] = (counts[k] + ch - 1) / ch;
-}
-
 // task t -> (key, slice): largest key with toff[key] <= t
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine* __restrict__ pts, const u32* __restrict__ offsets,
                                                               const u32* __restrict__ entries, const u32* __restrict__ toff,
@@ -213,7 +227,7 @@ __global__ void __launch_bounds__(256) msm_collect_kernel(const Xyzz* __restrict
   const u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= keys) return;
   const u32 t0 = toff[k], T = toff[k + 1] - t0;
-  if (T > 8) { heavy[atomicAdd(nheavy, 1u)] = k; return; }
+  if (T > 24) { heavy[atomicAdd(nheavy, 1u)] = k; return; }
   Xyzz acc = bn254::xyzz_inf();
   for (u32 i = 0; i < T; i++) acc = i ? bn254::xyzz_add(acc, partial[t0 + i]) : partial[t0];
   buckets[k] = acc;

@@ -35,8 +35,8 @@ struct GrowBuf {
 };
 struct MsmWork {
   MsmShape sh;
-  GrowBuf pts, counts, offsets, cursor, entries, buckets, st0, st1, status, ntasks, toff, partial, heavy, totals;
-  u32 ch = 0, max_tasks = 0;
+  GrowBuf pts, carries, hist, pos, offsets, entries, buckets, st0, st1, status, ntasks, toff, partial, heavy, totals;
+  u32 ch = 0, max_tasks = 0, chunk_size = 0, chunks = 0;
   size_t planes = 0;   // W * c rows of the bit-plane reduction
   std::mutex mu;       // one MSM at a time per device workspace
   int alloc(size_t n) {
@@ -47,17 +47,26 @@ struct MsmWork {
     const size_t keys = (size_t)sh.W * sh.NB;
     planes = (size_t)sh.W * sh.c;
     RCHK(pts.alloc(n * sizeof(Affine)));
-    RCHK(counts.alloc(keys * 4));
+    // chunks of the scalars for the LDS counting sort: 32768 scalars per workgroup, at most 64 chunks
+    chunk_size = 32768;
+    while ((n + chunk_size - 1) / chunk_size > 64) chunk_size *= 2;
+    chunks = (u32)((n + chunk_size - 1) / chunk_size);
+    RCHK(carries.alloc(n * 8));
+    RCHK(hist.alloc((keys * chunks + 1) * 4));
+    RCHK(pos.alloc((keys * chunks + 1) * 4));
     RCHK(offsets.alloc((keys + 1) * 4));
-    RCHK(cursor.alloc(keys * 4));
     RCHK(entries.alloc(n * sh.W * 4));
     RCHK(buckets.alloc(keys * sizeof(Xyzz)));
     RCHK(st0.alloc(planes * (sh.NB / 16) * sizeof(Xyzz)));
     RCHK(st1.alloc(planes * ((sh.NB / 16 + 7) / 8) * sizeof(Xyzz)));
     RCHK(status.alloc(8));
-    // tasks of at most ch entries: ~2x the mean run, at least 16; every non-empty bucket has one, plus one per ch entries
+    // tasks of at most ch entries: a QUARTER of the mean run, at least 16.  With one task per bucket (ch = 2x the mean) a
+    // 2^20-point MSM had 4.5 waves per SIMD for 4 resident ones -- one round plus a half-empty one, each wave as slow as its
+    // fullest bucket: 3.65 ms; with ~5 tasks per bucket 23 waves per SIMD keep every slot busy: 1.9 ms, +0.2 ms to fold
+    // the tasks (sweep ch = 8 .. 128: 4.58 / 4.51 (16) / 4.76 (32) / 5.36 (64) / 5.79 ms per MSM)
     size_t mean = n / sh.NB;
-    ch = (u32)(2 * mean < 16 ? 16 : 2 * mean);
+    ch = (u32)(mean / 4 < 16 ? 16 : mean / 4);
+    if (const char* e = getenv("RONK_MSM_CH")) { const int v = atoi(e); if (v >= 1 && v <= 65536) ch = (u32)v; }   // tuning runs
     max_tasks = (u32)(keys + (n * sh.W) / ch + 1);
     RCHK(ntasks.alloc(keys * 4));
     RCHK(toff.alloc((keys + 1) * 4));
@@ -83,13 +92,15 @@ void msm_host_tail(const MsmShape& sh, const Xyzz* rows, u64 out[8]) {
   bn254::xyzz_store_affine(total, out);
 }
 
-// offsets[0..m] = exclusive prefix sums of counts[0..m) (+ a copy in cursor, may be null)
-void msm_scan(MsmWork& wk, const u32* counts, u32 m, u32* offsets, u32* cursor, hipStream_t s) {
-  const u32 nb = (m + SCAN_BLK - 1) / SCAN_BLK;   // <= 1024 for every window size (17 * 2^15 keys = 544 blocks)
+// offsets[0..m] = exclusive prefix sums of counts[0..m)
+void msm_scan(MsmWork& wk, const u32* counts, size_t m, u32* offsets, hipStream_t s) {
+  u32 per = 4;
+  while ((m + (size_t)256 * per - 1) / ((size_t)256 * per) > 1024) per *= 2;
+  const u32 nb = (u32)((m + (size_t)256 * per - 1) / ((size_t)256 * per));
   u32* totals = (u32*)wk.totals.p;
-  hipLaunchKernelGGL(msm_scan_totals_kernel, dim3(nb), dim3(256), 0, s, counts, m, totals);
+  hipLaunchKernelGGL(msm_scan_totals_kernel, dim3(nb), dim3(256), 0, s, counts, (u32)m, per, totals);
   hipLaunchKernelGGL(msm_scan_mid_kernel, dim3(1), dim3(1024), 0, s, totals, nb);
-  hipLaunchKernelGGL(msm_scan_apply_kernel, dim3(nb), dim3(256), 0, s, counts, m, (const u32*)totals, nb, offsets, cursor);
+  hipLaunchKernelGGL(msm_scan_apply_kernel, dim3(nb), dim3(256), 0, s, counts, (u32)m, per, (const u32*)totals, nb, offsets);
 }
 
 int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hipStream_t s) {
@@ -106,16 +117,27 @@ int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hip
   const u32 keys = sh.W * sh.NB;
   const u32 gn = (u32)((n + 255) / 256);
   HIPCHK(hipMemsetAsync(wk.status.p, 0, 8, s));
-  HIPCHK(hipMemsetAsync(wk.counts.p, 0, (size_t)keys * 4, s));
   hipLaunchKernelGGL(msm_prepare_kernel, dim3(gn), dim3(256), 0, s, d_points, sh.n, (Affine*)wk.pts.p, (int*)wk.status.p);
-  hipLaunchKernelGGL((msm_digits_kernel<false>), dim3(gn), dim3(256), 0, s, d_scalars, sh, (u32*)wk.counts.p, (u32*)nullptr,
-                     (u32*)nullptr);
-  msm_scan(wk, (const u32*)wk.counts.p, keys, (u32*)wk.offsets.p, (u32*)wk.cursor.p, s);
-  hipLaunchKernelGGL((msm_digits_kernel<true>), dim3(gn), dim3(256), 0, s, d_scalars, sh, (u32*)nullptr, (u32*)wk.cursor.p,
-                     (u32*)wk.entries.p);
-  hipLaunchKernelGGL(msm_ntasks_kernel, dim3((keys + 255) / 256), dim3(256), 0, s, (const u32*)wk.counts.p, keys, wk.ch,
-                     (u32*)wk.ntasks.p);
-  msm_scan(wk, (const u32*)wk.ntasks.p, keys, (u32*)wk.toff.p, nullptr, s);
+  // counting sort of the entries by (window, bucket)
+  {
+    static bool attr_done[64] = {};
+    const size_t lds = (size_t)sh.NB * 4;
+    if (lds > 48 * 1024 && !attr_done[dev]) {
+      HIPCHK(hipFuncSetAttribute((const void*)msm_sort_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)msm_sort_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done[dev] = true;
+    }
+    const size_t m = (size_t)keys * wk.chunks;
+    hipLaunchKernelGGL(msm_carries_kernel, dim3(gn), dim3(256), 0, s, d_scalars, sh, (u64*)wk.carries.p);
+    hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(wk.chunks, sh.W), dim3(MSM_SORT_WG), lds, s, d_scalars,
+                       (const u64*)wk.carries.p, sh, wk.chunk_size, wk.chunks, (u32*)wk.hist.p, (const u32*)nullptr, (u32*)nullptr);
+    msm_scan(wk, (const u32*)wk.hist.p, m, (u32*)wk.pos.p, s);
+    hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(wk.chunks, sh.W), dim3(MSM_SORT_WG), lds, s, d_scalars,
+                       (const u64*)wk.carries.p, sh, wk.chunk_size, wk.chunks, (u32*)nullptr, (const u32*)wk.pos.p, (u32*)wk.entries.p);
+    hipLaunchKernelGGL(msm_offsets_kernel, dim3((keys + 256) / 256), dim3(256), 0, s, (const u32*)wk.pos.p, keys, wk.chunks, wk.ch,
+                       (u32*)wk.offsets.p, (u32*)wk.ntasks.p);
+  }
+  msm_scan(wk, (const u32*)wk.ntasks.p, keys, (u32*)wk.toff.p, s);
   hipLaunchKernelGGL(msm_accumulate_kernel, dim3((wk.max_tasks + 255) / 256), dim3(256), 0, s, (const Affine*)wk.pts.p,
                      (const u32*)wk.offsets.p, (const u32*)wk.entries.p, (const u32*)wk.toff.p, keys, wk.ch,
                      (Xyzz*)wk.partial.p);
