@@ -34,7 +34,7 @@ WORKLOADS = {
     "mul22":       (22, 1,    48.0,          "op/s",  None),   # config 3: 3 transforms of size 2^22, pad/pointwise/truncate fused
     "roundtrip16": (16, 1,    32.0,          "op/s",  None),   # config 2: forward + inverse
     "open22":      (22, 1,    16.0,          "op/s",  "chunk_sum8_kernel + lindiv_fused_kernel (csrc/scan_kernels.h)"),
-    "eval22":      (22, 1,    8.0,           "op/s",  "weighted_chunk_sum8_kernel + partial_sum_kernel (csrc/scan_kernels.h)"),
+    "eval22":      (22, 1,    8.0,           "op/s",  "eval_onepass_kernel (csrc/scan_kernels.h)"),
     "rs16":        (16, 1024, 12.0 * 1024,   "op/s",  None),   # reads n/2, writes n coefficients per codeword
     "vecmul24":    (24, 1,    24.0,          "op/s",  "vec_binary2_kernel<GlOps, VEC_MUL>"),
     "vecadd24":    (24, 1,    24.0,          "op/s",  "vec_binary2_kernel<GlOps, VEC_ADD>"),
@@ -55,7 +55,8 @@ def synth(n, seed):
 
 KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", "ronkathon_amd/csrc/plan.h",
                   "ronkathon_amd/csrc/tile_kernels.hip", "ronkathon_amd/csrc/tile_kernels_cfg.hip",
-                  "ronkathon_amd/csrc/tile_kernel_def.h", "ronkathon_amd/csrc/tile_cfg_table.h")
+                  "ronkathon_amd/csrc/tile_kernel_def.h", "ronkathon_amd/csrc/tile_cfg_table.h",
+                  "ronkathon_amd/csrc/tile_kernels_half.hip")
 VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
 
 

@@ -10,6 +10,7 @@ timeout 200 python bench.py > $OUT/bench_default.json 2>> $OUT/err
 timeout 100 python bench.py --no-cpu --streams 1 > $OUT/bench_ntt22_1stream.json 2>> $OUT/err
 for wl in batch16 mul22 roundtrip16 rs16; do timeout 300 python bench.py --workload $wl > $OUT/bench_$wl.json 2>> $OUT/err; done
 for wl in open22 eval22 vecmul24 vecadd24; do timeout 100 python bench.py --no-cpu --workload $wl > $OUT/bench_$wl.json 2>> $OUT/err; done
+for lg in 16 18 20; do timeout 300 python bench.py --workload msm20 --log2n $lg --steps 5 --samples 3 > $OUT/bench_msm$lg.json 2>> $OUT/err; done
 timeout 100 python bench.py --no-cpu --workload fourstep --log2n 26 --steps 20 --warmup 3 > $OUT/bench_fourstep_1gpu.json 2>> $OUT/err
 timeout 100 python bench.py --no-cpu --workload sharded --ranks 8 --log2n 26 --steps 20 --warmup 3 > $OUT/bench_sharded_8ranks_1gpu.json 2>> $OUT/err
 timeout 400 bash tools/profile.sh ntt22 ${TAG}_1stream --streams 1 > $OUT/prof_1stream.txt 2>&1
