@@ -1,0 +1,140 @@
+// ntt_small.h -- the LATENCY form of a tile pass: 4 coefficients per work-item, radix-4 rounds in place in LDS.
+//
+// ntt_tile.h gives a work-item 16 coefficients (fewest LDS exchanges and table twiddles per coefficient: the right trade
+// when the chip is full).  A single 2^16 transform (BASELINE config 2) is only 64 waves of that kind on 1024 SIMDs, and its
+// time is one wave's dependent instruction stream: ~2 000 VALU instructions per pass at ~9.5 cycles each when a wave has
+// its SIMD to itself (tools/clock_probe.hip) = 8 us per launch, 35 us per forward + inverse.  Here the same pass is
+// R*C/4 work-items doing log4(R) rounds of one radix-4 butterfly each (omega_4 = 2^48: a shift), i.e. a quarter of the
+// instructions per lane and four times the waves; more barriers and one table twiddle per coefficient and round do not
+// matter when nothing else competes for the VALU.  Selected by the planner (plan.h) for two-pass plans whose whole batch
+// is at most 2^17 coefficients.
+//
+// Same TileArgs contract as tile_body (strides, blocked rows, inter-pass twiddle by two-level table or full matrix, scale,
+// second operand and implicit padding / truncation of the fused polynomial multiply; no staged I/O), same results: X[k] = sum_j x[j] omega^{jk}, natural order in and out
+// (reference src/polynomial/mod.rs:273-323, :430-484).
+//
+// One column of R = 2^LOGR points, in place, decimation in frequency: round s works on blocks of L = R/4^s points,
+//   a_i = y[B + j + i*L/4]   ->   y[B + j + r*L/4] = (sum_i a_i omega_4^{ir}) * omega_L^{jr},   r = 0..3
+// (a last radix-2 round when LOGR is odd); afterwards position p = d_0*R/4 + d_1*R/16 + ... holds X[d_0 + 4 d_1 + ...].
+// Round 0 reads its inputs from HBM, the last round writes to HBM; LDS image: [R + R/4][C] (one dummy row per 4 rows keeps
+// the short strides of the last rounds off the same banks).
+#pragma once
+#include "ntt_tile.h"
+
+namespace ronk {
+
+RONK_HD u32 small_row(u32 p) { return p + (p >> 2); }
+
+// omega_4^{+-1} * x: omega_4 = omega_64^16 = 2^(39*16 mod 192) = 2^48; the inverse is 2^144 = -2^48
+template <bool INV>
+RONK_HD u64 mul_w4_of_diff(u64 a, u64 b) {   // (a - b) * omega_4^{+-1}
+  return INV ? gl64::mul_2exp<48>(gl64::sub(b, a)) : gl64::mul_2exp<48>(gl64::sub(a, b));
+}
+
+template <int LOGR, bool INV, class Barrier>
+RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
+  constexpr u32 R = 1u << LOGR;
+  constexpr int S4 = LOGR / 2;              // radix-4 rounds
+  constexpr bool ODD = (LOGR & 1) != 0;     // + one radix-2 round
+  static_assert(LOGR >= 4 && LOGR <= 10, "small pass size");
+  const u32 logc = a.logc, C = 1u << logc;
+  const u32 c = tid & (C - 1), u = tid >> logc;   // u in [0, R/4)
+  const u32 t = bid % a.tiles, bb = bid / a.tiles, b1 = bb % a.nb1, b2 = bb / a.nb1;
+  const u32 col = (t << logc) + c;
+  const bool live = col < a.ncols;
+  const u64* in = a.in + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st + (i64)c * a.in_sc;
+  u64* out = a.out + (i64)b1 * a.out_sb1 + (i64)b2 * a.out_sb2 + (i64)t * a.out_st + (i64)c * a.out_sc;
+  auto in_row = [&](u32 j) -> i64 {
+    return a.js_log < 31 ? (i64)(j >> a.js_log) * a.in_sj_hi + (i64)(j & ((1u << a.js_log) - 1)) * a.in_sj : (i64)j * a.in_sj;
+  };
+  auto cell = [&](u32 p) -> u32 { return (small_row(p) << logc) + c; };
+
+  u64 x[4];
+  // ---- radix-4 rounds
+#pragma unroll
+  for (int s = 0; s < S4; s++) {
+    const u32 L = R >> (2 * s), q = L / 4;
+    const u32 Bk = u / q, j = u % q;
+    const u32 p0 = Bk * L + j;
+    if (s == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const i64 off = in_row(p0 + i * q);
+        // lin = offset inside the polynomial (everything but the b1 term): >= in_valid reads as ZERO (From<[F;N]> padding)
+        const u64 lin = (u64)((i64)b2 * a.in_sb2 + (i64)t * a.in_st + (i64)c * a.in_sc + off);
+        const bool ok = live && (a.in_valid == ~(u64)0 || lin < a.in_valid);
+        x[i] = ok ? in[off] : 0;
+        if (a.in2 && ok) x[i] = gl64::mul(x[i], (a.in2 + (in - a.in))[off]);   // fused pointwise product
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = lds[cell(p0 + i * q)];
+    }
+    const u64 t0 = gl64::add(x[0], x[2]), t1 = gl64::sub(x[0], x[2]);
+    const u64 t2 = gl64::add(x[1], x[3]), t3 = mul_w4_of_diff<INV>(x[1], x[3]);
+    x[0] = gl64::add(t0, t2); x[1] = gl64::add(t1, t3); x[2] = gl64::sub(t0, t2); x[3] = gl64::sub(t1, t3);
+    // twiddles omega_L^{j r} = omega_R^{j r R/L}; none in the last radix-4 round of an even size (L == 4, j == 0)
+    if (q > 1 || ODD) {
+      const u32 step = j * (R / L);
+#pragma unroll
+      for (int r = 1; r < 4; r++)
+        if (j) x[r] = gl64::mul(x[r], ld_tab(a.wr, (step * r) & (R - 1)));
+    }
+    if (s == S4 - 1 && !ODD) break;   // results stay in registers: output below
+    // in place: the four positions belong to this work-item alone in this round, so no barrier between its reads and writes
+#pragma unroll
+    for (int i = 0; i < 4; i++) lds[cell(p0 + i * q)] = x[i];
+    barrier();
+  }
+  // natural output index of position p: reverse the base-4 digits (and the last binary digit when LOGR is odd)
+  auto natural = [&](u32 p) -> u32 {
+    u32 k = 0;
+    if (ODD) {
+      k = (p & 1) << (2 * S4);
+      p >>= 1;
+#pragma unroll
+      for (int s = S4 - 1; s >= 0; s--) { k |= (p & 3) << (2 * s); p >>= 2; }
+    } else {
+#pragma unroll
+      for (int s = S4 - 1; s >= 0; s--) { k |= (p & 3) << (2 * s); p >>= 2; }
+    }
+    return k;
+  };
+  u32 pos[4];
+  if (ODD) {
+    // last round: radix 2 on positions 2v, 2v+1; each work-item does two butterflies (v = 2u, 2u + 1)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const u32 v = 2 * u + h;
+      const u64 e0 = lds[cell(2 * v)], e1 = lds[cell(2 * v + 1)];
+      x[2 * h] = gl64::add(e0, e1);
+      x[2 * h + 1] = gl64::sub(e0, e1);
+      pos[2 * h] = 2 * v; pos[2 * h + 1] = 2 * v + 1;
+    }
+  } else {
+    const u32 p0 = u * 4;   // last radix-4 round: L = 4, q = 1, block u
+#pragma unroll
+    for (int i = 0; i < 4; i++) pos[i] = p0 + i;
+  }
+  // ---- output: inter-pass twiddle / scale, natural order
+  if (!live) return;
+  const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
+  const u32 lmask = (1u << a.tw_lo_bits) - 1;
+  const u32 twX = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const u32 k = natural(pos[i]);
+    u64 v = x[i];
+    if (a.tw_full) {
+      v = gl64::mul(v, a.tw_full[(size_t)k * a.tf_sk + (size_t)col * a.tf_sc + (size_t)b2 * a.tf_sb2]);
+    } else if (a.tw_log) {
+      const u32 e = (twX * ((u32)a.yk * k + (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0)) & nmask;
+      v = gl64::mul(v, gl64::mul(ld_tab(a.tw_lo, e & lmask), ld_tab(a.tw_hi, e >> a.tw_lo_bits)));
+    }
+    if (a.scale != 1) v = gl64::mul(v, a.scale);
+    const u64 lin = (u64)((i64)b2 * a.out_sb2 + (i64)t * a.out_st + (i64)c * a.out_sc + (i64)k * a.out_sk);
+    if (a.out_valid == ~(u64)0 || lin < a.out_valid) out[(i64)k * a.out_sk] = v;
+  }
+}
+
+}  // namespace ronk

@@ -36,6 +36,7 @@ struct PassDesc {
   int twf_id;         // index into PlanDesc::twf (full twiddle matrix), or -1
   u32 grid, block;
   size_t lds_bytes;
+  bool small = false;   // run ntt_small.h's latency form (4 coefficients per work-item) instead of the tile kernel
 };
 
 struct TwTable {
@@ -140,6 +141,18 @@ struct PlanBuilder {
     d.passes.push_back(p);
     return d.passes.back();
   }
+  // switch a pass to the latency form (ntt_small.h): 256 work-items x 4 coefficients = R x C with C = 1024/R columns
+  static void make_small(PassDesc& p) {
+    int lc = 10 - p.logr;
+    if (lc < 0) lc = 0;
+    while (lc > 0 && ((u64)1 << lc) > p.args.ncols) lc--;
+    const u64 C = (u64)1 << lc, R = (u64)1 << p.logr;
+    p.args.logc = (u32)lc;
+    p.args.tiles = (u32)((p.args.ncols + C - 1) / C);
+    p.block = (u32)(R * C / 4);
+    p.lds_bytes = (R + R / 4) * C * 8;
+    p.small = true;
+  }
   int twf_max_log = 0;  // build the full twiddle matrix of a pass when it has at most 2^twf_max_log entries
 
   // Full matrix of the pass's output twiddle, T[k*tf_sk + col*tf_sc + b2*tf_sb2] = omega_N^{X*Y}, strides chosen
@@ -221,12 +234,19 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     // different phases -- beat 16384 (2^20 x 64: 0.961 -> 0.826 ms, 2^22 x 16: 1.04 -> 0.925); with one tile per CU
     // (a single 2^22 transform) the large tile stays better, and for 2^8 / 2^9-row passes C = 16 stays best.
     const bool many_tiles = auto_tiles && (double)batch * (double)n / 16384.0 >= 1024.0;
+    // Latency regime (ntt_small.h): the whole batch is at most 2^18 coefficients -- with 16 coefficients per work-item that
+    // is at most 256 waves on 1024 SIMDs and the time is one wave's instruction stream.  Measured (forward + inverse, same
+    // box): 2^13 34.9 -> 23.3 us, 2^16 35.1 -> 25.9, 2^17 43.8 -> 32.0, 2^18 56.6 -> 38.2, 4 x 2^16 forward 18.1 -> 13.3;
+    // 16 x 2^16 (2^20 coefficients) is slower that way, 19.4 -> 22.7.  RONK_SMALL = 0 / 1 forces it.
+    bool small = auto_tiles && batch * n <= ((u64)1 << 18) && ka <= 10 && kb <= 10;
+    if (const char* e = getenv("RONK_SMALL")) small = atoi(e) != 0 && ka <= 10 && kb <= 10;
     int lc1 = max_logc, lc2 = max_logc;
     if (many_tiles && ka >= 10 && ka <= 11 && lc1 > 13 - ka) lc1 = 13 - ka;
     if (many_tiles && kb >= 10 && kb <= 11 && lc2 > 13 - kb) lc2 = 13 - kb;
     u32 logcp;
     {
       PassDesc& p = b.add_pass(ka, B, lc1);  // [A][B]: columns b, rows a
+      if (small) PlanBuilder::make_small(p);
       logcp = p.args.logc;
       const i64 Cp = (i64)1 << logcp;
       p.args.in_sj = (i64)B; p.args.in_sc = 1;
@@ -240,6 +260,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     }
     {
       PassDesc& p = b.add_pass(kb, A, lc2);  // rows ka are the columns of this pass
+      if (small) PlanBuilder::make_small(p);
       const i64 Cp = (i64)1 << logcp, C2 = (i64)1 << p.args.logc;
       // j = b: (b >> logcp) selects the pass-1 tile, (b & (Cp-1)) the column inside it
       p.args.in_sj = 1; p.args.js_log = logcp; p.args.in_sj_hi = (i64)A * Cp;

@@ -155,7 +155,8 @@ struct CompiledPlan {
       grid = ps.grid / a.nb1 * sbn;
       a.nb1 = sbn;
     }
-    hipError_t e = launch_tile(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s);
+    hipError_t e = ps.small ? launch_small(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s)
+                            : launch_tile(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s);
     if (e != hipSuccess) return hip_fail(e, "launch_tile");
     return RONK_OK;
   }

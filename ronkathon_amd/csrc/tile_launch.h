@@ -7,4 +7,7 @@
 namespace ronk {
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
                        hipStream_t stream);
+// the latency form of a pass (ntt_small.h: 4 coefficients per work-item), 2^4 .. 2^10 rows
+hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
+                        hipStream_t stream);
 }

@@ -17,6 +17,7 @@
 
 #include "../../oracle/ronk_oracle.h"
 #include "../../ronkathon_amd/csrc/plan.h"
+#include "../../ronkathon_amd/csrc/ntt_small.h"
 #include "../../ronkathon_amd/csrc/tile_cfg_table.h"
 
 using namespace ronk;
@@ -28,7 +29,7 @@ static std::vector<char> g_done;
 static int g_cur;
 
 struct FiberArgs {
-  const TileArgs* a; u64* lds; u32 bid; int logr; bool inv;
+  const TileArgs* a; u64* lds; u32 bid; int logr; bool inv; bool small;
 };
 static FiberArgs g_fa;
 
@@ -66,7 +67,18 @@ static bool dispatch_cfg(int logr, u32 tid) {
 }
 
 template <bool INV>
+static void dispatch_small(int logr, u32 tid) {
+  switch (logr) {
+#define EMU_SMALL_CASE(LR) case LR: small_body<LR, INV>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); break;
+    EMU_SMALL_CASE(4) EMU_SMALL_CASE(5) EMU_SMALL_CASE(6) EMU_SMALL_CASE(7) EMU_SMALL_CASE(8) EMU_SMALL_CASE(9) EMU_SMALL_CASE(10)
+#undef EMU_SMALL_CASE
+    default: abort();
+  }
+}
+
+template <bool INV>
 static void dispatch(int logr, u32 tid) {
+  if (g_fa.small) { dispatch_small<INV>(logr, tid); return; }
   if (!getenv("RONK_NO_CFG_KERNELS") && dispatch_cfg<INV>(logr, tid)) return;
   switch (logr) {
     case 4: run_body<4, INV>(tid); break;
@@ -132,7 +144,7 @@ static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64*
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
     lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);   // + room for the LDS-staged round twiddles
     for (u32 bid = 0; bid < p.grid; bid++) {
-      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
+      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv; g_fa.small = p.small;
       run_block(p.block);
     }
   }
@@ -216,13 +228,13 @@ int main(int argc, char** argv) {
     lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);   // + room for the LDS-staged round twiddles
     g_cfg_used = 0;
     for (u32 bid = 0; bid < p.grid; bid++) {
-      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv;
+      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv; g_fa.small = p.small;
       run_block(p.block);
     }
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
            g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
-           g_cfg_used == 12 ? "half:row" : "generic");
+           g_cfg_used == 12 ? "half:row" : p.small ? "small" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
   for (u64 b = 0; b < batch; b++) {

@@ -15,7 +15,7 @@ EXE = os.path.join(ROOT, "build", "emu_tile")
 def emu():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "emu", "emu_tile.cpp")]
-    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "plan.h", "gl64.h", "tile_cfg_table.h")]
+    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "ntt_small.h", "plan.h", "gl64.h", "tile_cfg_table.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
         subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
@@ -123,3 +123,20 @@ def test_half_lds_exchange(emu, args):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
     assert all("kernel=half:" in l for l in lines if l.startswith("pass")), out.stdout
+
+
+@pytest.mark.parametrize("args", [(13, 2, 0), (13, 1, 1), (14, 3, 1), (15, 1, 0), (16, 1, 0), (16, 4, 1), (17, 2, 0), (18, 1, 1)])
+def test_small_latency_kernel(emu, args):
+    """ntt_small.h (4 coefficients per work-item, radix-4 rounds in place; a radix-2 round for odd pass sizes): the plans
+    the planner builds for at most 2^18 coefficients in all (auto_tiles = 1), forward and inverse, batched"""
+    k, batch, inv = args
+    out = subprocess.run([emu, str(k), str(batch), str(inv), "4", "18", "25", "0", "0", "1"], capture_output=True, text=True, timeout=600)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+    assert all("kernel=small" in l for l in lines if l.startswith("pass")), out.stdout
+
+
+def test_small_kernel_fused_multiply_arguments(emu):
+    """implicit zero padding on load (in_valid) and truncation on store (out_valid) through the small kernel"""
+    for args in ((13, 1, 0, 4, 18, 25, 3000, 0, 1), (13, 1, 1, 4, 18, 25, 0, 5000, 1), (16, 2, 0, 4, 18, 25, 40000, 0, 1)):
+        run(emu, *args)
