@@ -234,11 +234,12 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     // different phases -- beat 16384 (2^20 x 64: 0.961 -> 0.826 ms, 2^22 x 16: 1.04 -> 0.925); with one tile per CU
     // (a single 2^22 transform) the large tile stays better, and for 2^8 / 2^9-row passes C = 16 stays best.
     const bool many_tiles = auto_tiles && (double)batch * (double)n / 16384.0 >= 1024.0;
-    // Latency regime (ntt_small.h): the whole batch is at most 2^18 coefficients -- with 16 coefficients per work-item that
-    // is at most 256 waves on 1024 SIMDs and the time is one wave's instruction stream.  Measured (forward + inverse, same
+    // Latency regime (ntt_small.h): the whole batch is at most 2^19 coefficients -- with 16 coefficients per work-item that
+    // is at most 512 waves on 1024 SIMDs and the time is one wave's instruction stream.  Measured (forward + inverse, same
     // box): 2^13 34.9 -> 23.3 us, 2^16 35.1 -> 25.9, 2^17 43.8 -> 32.0, 2^18 56.6 -> 38.2, 4 x 2^16 forward 18.1 -> 13.3;
-    // 16 x 2^16 (2^20 coefficients) is slower that way, 19.4 -> 22.7.  RONK_SMALL = 0 / 1 forces it.
-    bool small = auto_tiles && batch * n <= ((u64)1 << 18) && ka <= 10 && kb <= 10;
+    // one forward 2^19 37.3 -> 26.7, 64 x 2^13 19.1 -> 13.7; at 2^20 coefficients it is a draw or worse (single 47.2 -> 49.3,
+    // 16 x 2^16 19.4 -> 22.7).  RONK_SMALL = 0 / 1 forces it.
+    bool small = auto_tiles && batch * n <= ((u64)1 << 19) && ka <= 10 && kb <= 10;
     if (const char* e = getenv("RONK_SMALL")) small = atoi(e) != 0 && ka <= 10 && kb <= 10;
     int lc1 = max_logc, lc2 = max_logc;
     if (many_tiles && ka >= 10 && ka <= 11 && lc1 > 13 - ka) lc1 = 13 - ka;

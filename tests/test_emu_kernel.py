@@ -125,10 +125,10 @@ def test_half_lds_exchange(emu, args):
     assert all("kernel=half:" in l for l in lines if l.startswith("pass")), out.stdout
 
 
-@pytest.mark.parametrize("args", [(13, 2, 0), (13, 1, 1), (14, 3, 1), (15, 1, 0), (16, 1, 0), (16, 4, 1), (17, 2, 0), (18, 1, 1)])
+@pytest.mark.parametrize("args", [(13, 2, 0), (13, 1, 1), (14, 3, 1), (15, 1, 0), (16, 1, 0), (16, 4, 1), (17, 2, 0), (18, 1, 1), (19, 1, 0)])
 def test_small_latency_kernel(emu, args):
     """ntt_small.h (4 coefficients per work-item, radix-4 rounds in place; a radix-2 round for odd pass sizes): the plans
-    the planner builds for at most 2^18 coefficients in all (auto_tiles = 1), forward and inverse, batched"""
+    the planner builds for at most 2^19 coefficients in all (auto_tiles = 1), forward and inverse, batched"""
     k, batch, inv = args
     out = subprocess.run([emu, str(k), str(batch), str(inv), "4", "18", "25", "0", "0", "1"], capture_output=True, text=True, timeout=600)
     lines = out.stdout.strip().splitlines()
