@@ -85,7 +85,7 @@ static bool stream_is_capturing(hipStream_t s) {
   if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
   return st != hipStreamCaptureStatusNone;
 }
-static void make_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
+static void build_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
   u64 x = 1 % p;
   for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
   t->z256 = x;
@@ -103,6 +103,16 @@ static void make_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
     t->YA[i] = a; t->YB[i] = b; t->YC[i] = cc; t->z8A[i] = c8; t->z8B[i] = d8;
     a = h_mulmod(a, Y, p); b = h_mulmod(b, Y16, p); cc = h_mulmod(cc, Y256, p); c8 = h_mulmod(c8, z8, p); d8 = h_mulmod(d8, z128, p);
   }
+}
+// ~330 modular products on the host (~6 us): more than the launch itself, and callers open or evaluate many polynomials at
+// ONE point (kzg batch openings), so the last table is kept
+static void make_horner_tab2(u64 p, u64 z, u64 scale, HornerTab2* t) {
+  static std::mutex mu;
+  static HornerTab2 last;
+  static u64 lp = 0, lz = 0, lscale = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (lp != p || lz != z || lscale != scale) { build_horner_tab2(p, z, scale, &last); lp = p; lz = z; lscale = scale; }
+  *t = last;
 }
 // fused paths (scan_kernels.h): evaluate in one launch up to 2^20 chunks; division in two launches up to 4096 chunks
 static const size_t FUSED_EVAL_MAX = (size_t)FCH << 20, FUSED_DIV_MAX = (size_t)FCH * 4096;
