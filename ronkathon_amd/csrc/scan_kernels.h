@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) lindiv_fused_kernel(Ops ops, const u64* _
       const u32 cnt = (nchunks - first + 255) / 256;
       const u64 Y256 = tab.Yp[8];
       for (u32 q = cnt; q-- > 0;) cpart = ops.add(ops.mul(cpart, Y256), H[first + 256 * q]);
-      cpart = ops.mul(cpart, ypow(ops, tab, (u32)tid));
+      cpart = ops.mul(cpart, ops.mul(tab.YA[tid & 15], tab.YB[tid >> 4]));   // Y^tid from two 16-entry tables (was: 8 predicated products)
     }
   }
   const u64 cin = block_sum_256(ops, cpart, sc);            // (its barriers also publish buf)
