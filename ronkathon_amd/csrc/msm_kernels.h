@@ -10,7 +10,7 @@
 //   accumulate  one lane per TASK (<= CH entries of one bucket's run): XYZZ sum by mixed additions (8M + 2S each), the
 //             dominant kernel; collect / heavy fold the tasks of a bucket
 //   reduce    sum_b (b+1) B_b per window as bit planes: Q_k = sum of the buckets whose weight has bit k set (plain sums, no
-//             serial running-sum chain: a lane adds at most 16 points, then three to five 8-to-1 stages), the rest
+//             serial running-sum chain: a lane adds at most 4 points, then 4-to-1 stages), the rest
 //             (sum_k 2^k Q_k, then Horner over the windows: ~270 dependent doublings) runs on the host, where one
 //             doubling takes 0.5 us instead of 14 us on a single lane.
 // Everything here is VALU-bound 32-bit limb arithmetic (bn254.h); no MFMA (carry chains), HBM traffic is the gather of
@@ -197,8 +197,7 @@ __global__ void __launch_bounds__(256) msm_scan_apply_kernel(const u32* __restri
 // Buckets are summed in TASKS of at most CH entries, so that one heavy bucket (every scalar shares its top digit, or all
 // scalars are equal: n entries in one run) cannot serialise the launch: ntasks[key] = ceil(count/CH) goes through the
 // same scan as the counts; one lane per task adds its slice of the run; msm_collect_kernel then folds the tasks of a
-// bucket (normally one: a copy), leaving buckets with more than 24 tasks to msm_heavy_kernel (one workgroup per bucket:
-// strided partial sums, then a tree in LDS).
+// bucket (normally one: a copy), leaving buckets with more than 24 tasks to msm_heavy_kernel (below).
 // task t -> (key, slice): largest key with toff[key] <= t
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine* __restrict__ pts, const u32* __restrict__ offsets,
                                                               const u32* __restrict__ entries, const u32* __restrict__ toff,
@@ -233,50 +232,82 @@ __global__ void __launch_bounds__(256) msm_collect_kernel(const Xyzz* __restrict
   buckets[k] = acc;
 }
 
-__global__ void __launch_bounds__(256) msm_heavy_kernel(const Xyzz* __restrict__ partial, const u32* __restrict__ toff,
+// Heavy buckets (more than 24 tasks; with uniform 254-bit scalars the top window of most window sizes has a handful of
+// buckets holding n/4 entries each = thousands of tasks): MSM_HY workgroups per bucket each fold one slice of its task
+// sums (strided per lane, then a tree in LDS) and leave the result in the slice's first entry; a second launch folds the
+// MSM_HY slice sums.  (One workgroup per bucket was 64 dependent additions per lane + the tree: ~2 ms for a 16 000-task
+// bucket.)
+constexpr u32 MSM_HY = 64;
+__device__ __forceinline__ Xyzz msm_block_sum(Xyzz acc, Xyzz* red) {
+  const u32 tid = threadIdx.x;
+  red[tid] = acc;
+  __syncthreads();
+  for (u32 s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = bn254::xyzz_add(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  const Xyzz r = red[0];
+  __syncthreads();
+  return r;
+}
+// STAGE 0: slice y of every heavy bucket -> partial[t0 + y*len]; STAGE 1: the MSM_HY slice sums -> buckets[k]
+template <int STAGE>
+__global__ void __launch_bounds__(256) msm_heavy_kernel(Xyzz* __restrict__ partial, const u32* __restrict__ toff,
                                                          const u32* __restrict__ heavy, const u32* __restrict__ nheavy,
                                                          Xyzz* __restrict__ buckets) {
   __shared__ Xyzz red[256];
   const u32 tid = threadIdx.x;
   for (u32 h = blockIdx.x; h < *nheavy; h += gridDim.x) {
     const u32 k = heavy[h], t0 = toff[k], T = toff[k + 1] - t0;
+    const u32 len = (T + MSM_HY - 1) / MSM_HY;
     Xyzz acc = bn254::xyzz_inf();
-    for (u32 i = tid; i < T; i += 256) acc = bn254::xyzz_add(acc, partial[t0 + i]);
-    red[tid] = acc;
-    __syncthreads();
-    for (u32 s = 128; s > 0; s >>= 1) {
-      if (tid < s) red[tid] = bn254::xyzz_add(red[tid], red[tid + s]);
-      __syncthreads();
+    const bool sliced = T > 1024;            // below that one workgroup folds the bucket directly (one tree instead of two)
+    if (STAGE == 0) {
+      if (!sliced) continue;
+      const u32 y = blockIdx.y, lo = y * len, hi = lo + len < T ? lo + len : T;
+      for (u32 i = lo + tid; i < hi; i += 256) acc = bn254::xyzz_add(acc, partial[t0 + i]);
+      const Xyzz r = msm_block_sum(acc, red);      // (its barriers order every lane's reads before the write below)
+      if (tid == 0 && lo < T) partial[t0 + lo] = r;
+    } else {
+      if (sliced) {
+        if (tid < MSM_HY && tid * len < T) acc = partial[t0 + tid * len];
+      } else {
+        for (u32 i = tid; i < T; i += 256) acc = bn254::xyzz_add(acc, partial[t0 + i]);
+      }
+      const Xyzz r = msm_block_sum(acc, red);
+      if (tid == 0) buckets[k] = r;
     }
-    if (tid == 0) buckets[k] = red[0];
-    __syncthreads();
   }
 }
 
-// bit planes, first stage: out[(w*K + k)*G + g] = sum of buckets b in [16g, 16g+16) of window w whose weight (b+1) has
-// bit k set; K = c bit planes (weights go up to NB = 2^(c-1), so bits 0 .. c-1), G = NB/16 groups
+// bit planes, first stage: out[(w*K + k)*G + g] = sum of the buckets b in [FB*g, FB*g + FB) of window w whose weight (b+1)
+// has bit k set; K = c bit planes (weights go up to NB = 2^(c-1), so bits 0 .. c-1), G = NB/FB groups.
+// The reduction is bound by its DEPTH (dependent point additions, ~17 us each on a lane with a quiet SIMD), not by its
+// work: fan-in 16 here and 8 per later stage was 44 dependent additions (0.58 + 0.33 ms at 2^20 points), fan-in 4 / 4 is 22.
+template <u32 FB>
 __global__ void __launch_bounds__(256) msm_bitplane_kernel(const Xyzz* __restrict__ buckets, MsmShape sh, Xyzz* __restrict__ out) {
-  const u32 G = sh.NB / 16, K = sh.c;
+  const u32 G = sh.NB / FB, K = sh.c;
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t >= sh.W * K * G) return;
   const u32 g = t % G, k = (t / G) % K, w = t / (G * K);
   Xyzz acc = bn254::xyzz_inf();
-  for (u32 j = 0; j < 16; j++) {
-    const u32 b = 16 * g + j;
+  for (u32 j = 0; j < FB; j++) {
+    const u32 b = FB * g + j;
     if (((b + 1) >> k) & 1) acc = bn254::xyzz_add(acc, buckets[(size_t)w * sh.NB + b]);
   }
   out[t] = acc;
 }
 
-// 8-to-1 stage over rows: in[row][cnt] -> out[row][ceil(cnt/8)]
-__global__ void __launch_bounds__(256) msm_sum8_kernel(const Xyzz* __restrict__ in, u32 rows, u32 cnt, Xyzz* __restrict__ out) {
-  const u32 ocnt = (cnt + 7) / 8;
+// FS-to-1 stage over rows: in[row][cnt] -> out[row][ceil(cnt/FS)]
+template <u32 FS>
+__global__ void __launch_bounds__(256) msm_sum_kernel(const Xyzz* __restrict__ in, u32 rows, u32 cnt, Xyzz* __restrict__ out) {
+  const u32 ocnt = (cnt + FS - 1) / FS;
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t >= rows * ocnt) return;
   const u32 row = t / ocnt, o = t % ocnt;
   Xyzz acc = bn254::xyzz_inf();
-  for (u32 j = 0; j < 8; j++) {
-    const u32 i = 8 * o + j;
+  for (u32 j = 0; j < FS; j++) {
+    const u32 i = FS * o + j;
     if (i < cnt) acc = bn254::xyzz_add(acc, in[(size_t)row * cnt + i]);
   }
   out[t] = acc;

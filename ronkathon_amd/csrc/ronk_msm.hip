@@ -5,6 +5,15 @@
 
 namespace {
 
+#ifndef RONK_MSM_FB
+#define RONK_MSM_FB 4
+#endif
+#ifndef RONK_MSM_FS
+#define RONK_MSM_FS 4
+#endif
+constexpr u32 MSM_FB = RONK_MSM_FB;   // buckets per lane in the bit-plane stage (NB >= 16 is a multiple)
+constexpr u32 MSM_FS = RONK_MSM_FS;   // fan-in of the later stages
+
 // window size: buckets cost NB*W*c point additions in the reduction, entries cost n*W mixed additions
 u32 pick_window(size_t n) {
   const char* e = getenv("RONK_MSM_C");    // read per call: tests and tuning runs sweep it inside one process
@@ -12,8 +21,10 @@ u32 pick_window(size_t n) {
   if (forced >= 5 && forced <= 16) return (u32)forced;
   int lg = 0;
   while (((size_t)1 << lg) < n) lg++;
-  int c = lg - 5;
-  if (c < 6) c = 6;
+  // measured (tools/experiments/msm_window_sweep.sh, ms per MSM): 2^14: c=10 1.04 (c=9 1.07, c=8 1.22); 2^16: c=10 1.30
+  // (c=11 1.58, c=9 1.57); 2^18: c=13 1.85 (c=12 2.32, c=14 2.36); 2^20: c=13 4.29, c=15 4.41 (c=14 4.77); 2^22: c=15 12.4
+  int c = lg <= 17 ? 10 : lg - 5;
+  if (lg < 10) c = lg < 6 ? 6 : lg;          // tiny inputs: about one entry per bucket
   if (c > 15) c = 15;
   return (u32)c;
 }
@@ -57,8 +68,8 @@ struct MsmWork {
     RCHK(offsets.alloc((keys + 1) * 4));
     RCHK(entries.alloc(n * sh.W * 4));
     RCHK(buckets.alloc(keys * sizeof(Xyzz)));
-    RCHK(st0.alloc(planes * (sh.NB / 16) * sizeof(Xyzz)));
-    RCHK(st1.alloc(planes * ((sh.NB / 16 + 7) / 8) * sizeof(Xyzz)));
+    RCHK(st0.alloc(planes * (sh.NB / MSM_FB) * sizeof(Xyzz)));
+    RCHK(st1.alloc(planes * ((sh.NB / MSM_FB + MSM_FS - 1) / MSM_FS) * sizeof(Xyzz)));
     RCHK(status.alloc(8));
     // tasks of at most ch entries: a QUARTER of the mean run, at least 16.  With one task per bucket (ch = 2x the mean) a
     // 2^20-point MSM had 4.5 waves per SIMD for 4 resident ones -- one round plus a half-empty one, each wave as slow as its
@@ -143,17 +154,19 @@ int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hip
                      (Xyzz*)wk.partial.p);
   hipLaunchKernelGGL(msm_collect_kernel, dim3((keys + 255) / 256), dim3(256), 0, s, (const Xyzz*)wk.partial.p,
                      (const u32*)wk.toff.p, keys, (Xyzz*)wk.buckets.p, (u32*)wk.heavy.p, (u32*)wk.status.p + 1);
-  hipLaunchKernelGGL(msm_heavy_kernel, dim3(256), dim3(256), 0, s, (const Xyzz*)wk.partial.p, (const u32*)wk.toff.p,
+  hipLaunchKernelGGL((msm_heavy_kernel<0>), dim3(64, MSM_HY), dim3(256), 0, s, (Xyzz*)wk.partial.p, (const u32*)wk.toff.p,
+                     (const u32*)wk.heavy.p, (const u32*)wk.status.p + 1, (Xyzz*)wk.buckets.p);
+  hipLaunchKernelGGL((msm_heavy_kernel<1>), dim3(64), dim3(256), 0, s, (Xyzz*)wk.partial.p, (const u32*)wk.toff.p,
                      (const u32*)wk.heavy.p, (const u32*)wk.status.p + 1, (Xyzz*)wk.buckets.p);
   const u32 rows = (u32)wk.planes;
-  u32 cnt = sh.NB / 16;
-  hipLaunchKernelGGL(msm_bitplane_kernel, dim3((rows * cnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)wk.buckets.p, sh,
+  u32 cnt = sh.NB / MSM_FB;
+  hipLaunchKernelGGL((msm_bitplane_kernel<MSM_FB>), dim3((rows * cnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)wk.buckets.p, sh,
                      (Xyzz*)wk.st0.p);
   Xyzz* cur = (Xyzz*)wk.st0.p;
   Xyzz* nxt = (Xyzz*)wk.st1.p;
   while (cnt > 1) {
-    const u32 ocnt = (cnt + 7) / 8;
-    hipLaunchKernelGGL(msm_sum8_kernel, dim3((rows * ocnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)cur, rows, cnt, nxt);
+    const u32 ocnt = (cnt + MSM_FS - 1) / MSM_FS;
+    hipLaunchKernelGGL((msm_sum_kernel<MSM_FS>), dim3((rows * ocnt + 255) / 256), dim3(256), 0, s, (const Xyzz*)cur, rows, cnt, nxt);
     Xyzz* t = cur; cur = nxt; nxt = t;
     cnt = ocnt;
   }
