@@ -123,6 +123,10 @@ int msm_run(const u64* d_points, const u64* d_scalars, size_t n, u64 out[8], hip
   if (dev < 0 || dev >= 64) return RONK_ERR_INVALID;
   MsmWork& wk = g_work[dev];
   std::lock_guard<std::mutex> lk(wk.mu);
+  {   // entry slots and task ids are 32-bit: n * W must fit (n < 2^27 for every window size the planner picks)
+    const u32 c = pick_window(n), W = (257 + c - 1) / c;
+    if ((u64)n * W >= ((u64)1 << 32)) return RONK_ERR_UNSUPPORTED;
+  }
   RCHK(wk.alloc(n));
   const MsmShape sh = wk.sh;
   const u32 keys = sh.W * sh.NB;
