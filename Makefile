@@ -29,10 +29,13 @@ sanitize:
 	g++ $(SAN) -std=c++17 -fsanitize=address,undefined -o build/san/test_gl64_host tests/emu/test_gl64_host.cpp
 	gcc -O1 -c -o build/san/orc.o oracle/ronk_oracle.c
 	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_tile tests/emu/emu_tile.cpp build/san/orc.o
+	g++ $(SAN) -std=c++17 -fsanitize=address,undefined -o build/san/bn254_san tests/emu/bn254_san.cpp
 	./build/san/oracle_san
+	./build/san/bn254_san
 	./build/san/test_gl64_host
 	./build/san/emu_tile 12 3 0 4 | tail -1
 	./build/san/emu_tile 16 2 1 4 18 | tail -1
+	./build/san/emu_tile 15 2 0 4 18 25 0 0 1 | tail -1
 	./build/san/emu_tile 20 1 0 3 | tail -1
 	./build/san/emu_tile dist 16 4 0 0 2 | tail -1
 .PHONY: sanitize
