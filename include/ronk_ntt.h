@@ -156,7 +156,10 @@ int ronk_poly_eval(uint64_t p, const uint64_t* c, size_t d, uint64_t x, uint64_t
 int ronk_poly_eval_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t x, uint64_t* d_out, void* stream);
 /* Polynomial::<Lagrange<F>>::evaluate (polynomial/mod.rs:382-415): barycentric evaluation at x from the
  * values c[j] at nodes[j].  As in the reference, x equal to a node yields ZERO (its fold multiplies by
- * l(x) = 0); coincident nodes -> RONK_ERR_ZERO_INVERSE.  n <= 2^16 (O(n^2) weights, like the reference). */
+ * l(x) = 0); coincident nodes -> RONK_ERR_ZERO_INVERSE.  n <= 2^16 (O(n^2) weights, like the reference). 
+ * More than 2^16 nodes: only node tables of the form Lagrange::new builds (nodes[i] = omega^i, omega of order n; any n | p-1)
+ * -- then prod_{m != j}(x_j - x_m) = n / x_j and prod_i (x - x_i) = x^n - 1 give the same value in O(n); other tables of
+ * that size are RONK_ERR_UNSUPPORTED (the _dev form sets bit 2 of *d_status, which it then requires). */
 int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, size_t n, uint64_t x, uint64_t* out);
 /* quotient_and_remainder (polynomial/mod.rs:170-225) behind impl Div / Rem (arithmetic.rs:121-146);
  * quot and rem both have d coefficients.  Used by kzg::open (src/kzg/setup.rs:63-78). */

@@ -196,6 +196,69 @@ __global__ void __launch_bounds__(1024) poly_divrem_kernel(Ops ops, u64* __restr
   }
 }
 
+// ---- the same evaluate for the node tables Lagrange::new builds (polynomial/mod.rs:358-365: nodes[i] = omega^i, omega of
+// order n), in O(n): prod_{m != j} (x_j - x_m) = n * x_j^(n-1) = n / x_j and prod_i (x - x_i) = x^n - 1, so
+//   L(x) = (x^n - 1) / n * sum_j c_j x_j / (x - x_j)
+// -- the same field element as the general formula above (at a node both give l(x) * (...) = 0, like the reference's
+// fold).  lagrange_check_kernel verifies the structure the identity needs: nodes[0] == 1, nodes[j] == nodes[j-1] * nodes[1],
+// nodes[1]^n == 1 and nodes[1]^(n/q) != 1 for every prime q | n (order exactly n, hence n distinct nodes); otherwise bit 2 of
+// *status is set and the result is meaningless (the entry point reports RONK_ERR_UNSUPPORTED).
+struct LagPrimes { u64 q[16]; int count; };
+template <class Ops>
+__global__ void __launch_bounds__(256) lagrange_check_kernel(Ops ops, const u64* __restrict__ nodes, size_t n, LagPrimes pr,
+                                                              int* status) {
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  bool ok = true;
+  if (j == 0) {
+    ok = nodes[0] == ops.one() % ops.order();
+    if (n > 1) {
+      const u64 w = nodes[1];
+      ok = ok && ops.pow(w, (u64)n) == 1;
+      for (int i = 0; i < pr.count; i++) ok = ok && ops.pow(w, (u64)n / pr.q[i]) != 1;
+    }
+  } else {
+    ok = nodes[j] == ops.mul(nodes[j - 1], nodes[1]);
+  }
+  if (!ok) atomicOr(status, 4);
+}
+template <class Ops>
+__global__ void __launch_bounds__(256) lagrange_fast_terms_kernel(Ops ops, const u64* __restrict__ c, const u64* __restrict__ nodes,
+                                                                   size_t n, u64 x, u64* __restrict__ part_sum) {
+  __shared__ u64 rs[256];
+  u64 acc = 0;
+  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+    const u64 xj = nodes[j], fac = ops.sub(x, xj);
+    // fac == 0 (x is a node): pow gives 0, the term vanishes, and the factor x^n - 1 makes the whole value 0 anyway
+    acc = ops.add(acc, ops.mul(ops.mul(c[j], xj), ops.pow(fac, ops.order() - 2)));
+  }
+  rs[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) rs[threadIdx.x] = ops.add(rs[threadIdx.x], rs[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part_sum[blockIdx.x] = rs[0];
+}
+template <class Ops>
+__global__ void __launch_bounds__(256) lagrange_fast_finish_kernel(Ops ops, const u64* __restrict__ part_sum, size_t nparts,
+                                                                    size_t n, u64 x, u64* out) {
+  __shared__ u64 rs[256];
+  u64 s = 0;
+  for (size_t i = threadIdx.x; i < nparts; i += 256) s = ops.add(s, part_sum[i]);
+  rs[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) rs[threadIdx.x] = ops.add(rs[threadIdx.x], rs[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const u64 l = ops.sub(ops.pow(x, (u64)n), 1 % ops.order());                 // x^n - 1
+    const u64 ninv = ops.pow((u64)n % ops.order(), ops.order() - 2);
+    *out = ops.mul(ops.mul(l, ninv), rs[0]);
+  }
+}
+
 // ---- Polynomial::<Lagrange>::evaluate (polynomial/mod.rs:382-415), barycentric form --------------------
 //   w_j = prod_{m != j} 1/(x_j - x_m),  l(x) = prod_i (x - x_i),  L(x) = l(x) * sum_j c_j w_j / (x - x_j)
 // One work-item per node j: den_j = (x - x_j) * prod_{m != j} (x_j - x_m) with the nodes staged through LDS,

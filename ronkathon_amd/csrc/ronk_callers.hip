@@ -249,11 +249,31 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
 extern "C" int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uint64_t* d_nodes, size_t n, uint64_t x,
                                       uint64_t* d_out, int* d_status, void* stream) {
   if (!d_c || !d_nodes || !d_out || n == 0) return RONK_ERR_INVALID;
-  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;  // O(n^2) weights, as in the reference
   RCHK(need_device());
   FieldCtx f;
   RCHK(make_field(p, &f));
   hipStream_t s = (hipStream_t)stream;
+  static const size_t fast_min = [] { const char* e = getenv("RONK_LAGRANGE_FAST_MIN"); return e ? (size_t)atol(e) : ((size_t)1 << 16) + 1; }();
+  if (n >= fast_min) {
+    // O(n) form for nodes = consecutive powers of an order-n element (what Lagrange::new builds); *d_status bit 2 = the
+    // nodes are something else (the general O(n^2) formula is limited to n <= 2^16)
+    if (!d_status || n > ((size_t)1 << 32)) return RONK_ERR_UNSUPPORTED;
+    LagPrimes pr;
+    pr.count = 0;
+    { size_t m = n; for (size_t q = 2; q * q <= m; q++) if (m % q == 0) { pr.q[pr.count++] = q; while (m % q == 0) m /= q; }
+      if (m > 1) pr.q[pr.count++] = m; }
+    const u32 gb = grid_for(n);
+    WsLease ws;
+    RCHK(ws.acquire((size_t)gb * 8 + 64, s));
+    FIELD_DISPATCH(f, {
+      hipLaunchKernelGGL((lagrange_check_kernel<decltype(ops)>), dim3((u32)((n + 255) / 256)), dim3(256), 0, s, ops, d_nodes, n, pr, d_status);
+      hipLaunchKernelGGL((lagrange_fast_terms_kernel<decltype(ops)>), dim3(gb), dim3(256), 0, s, ops, d_c, d_nodes, n, x % p, ws.u());
+      hipLaunchKernelGGL((lagrange_fast_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ws.u(), (size_t)gb, n, x % p, d_out);
+    });
+    HIPCHK(hipGetLastError());
+    return RONK_OK;
+  }
+  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;  // O(n^2) weights, as in the reference
   const u32 blocks = (u32)((n + 255) / 256);
   WsLease ws;
   RCHK(ws.acquire((size_t)blocks * 16 + 64, s));
@@ -269,7 +289,6 @@ extern "C" int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uin
 }
 extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t* nodes, size_t n, uint64_t x, uint64_t* out) {
   if (!c || !nodes || !out || n == 0) return RONK_ERR_INVALID;
-  if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
   RCHK(need_device());
   DevBuf dc, dn, dres, dflag;
   RCHK(dc.alloc(n * 8)); RCHK(dn.alloc(n * 8)); RCHK(dres.alloc(8)); RCHK(dflag.alloc(4));
@@ -279,7 +298,8 @@ extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t*
   RCHK(ronk_lagrange_eval_dev(p, dc.u(), dn.u(), n, x, dres.u(), (int*)dflag.p, 0));
   int hflag = 0;
   HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
-  if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: F::ONE.div(ZERO) -> unwrap on None
+  if (hflag & 4) return RONK_ERR_UNSUPPORTED;   // more than 2^16 nodes that are not the powers of an order-n element
+  if (hflag) return RONK_ERR_ZERO_INVERSE;      // coincident nodes: F::ONE.div(ZERO) -> unwrap on None
   HIPCHK(hipMemcpy(out, dres.p, 8, hipMemcpyDeviceToHost));
   return RONK_OK;
 }

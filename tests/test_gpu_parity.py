@@ -1134,3 +1134,32 @@ def test_msm_bn254_large_structured(R, logn):
     L.check(L.lib.ronk_msm_bn254_dev(dp.data_ptr(), ds.data_ptr(), n, L.ptr(out), 0))
     got = (sum(int(out[i]) << (64 * i) for i in range(4)), sum(int(out[4 + i]) << (64 * i) for i in range(4)))
     assert got == want
+
+
+def test_lagrange_evaluate_fast_path_small_sizes(R):
+    """the O(n) form (nodes = powers of an order-n element) forced on for sizes the oracle covers, in its own process"""
+    import subprocess, sys
+    e = dict(os.environ, RONK_LAGRANGE_FAST_MIN="1")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "lagrange_fast_check.py")],
+                         capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0 and "lagrange fast check ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
+
+
+def test_lagrange_evaluate_large(R, orc):
+    """more than 2^16 nodes: `poly.dft().evaluate(x) == poly.evaluate(x)` (the reference's own check, src/polynomial/tests.rs:13-44)
+    at 2^18 and 3 * 2^16 nodes, 0 at a node, and RONK_ERR_UNSUPPORTED for a table that is not omega^i"""
+    from ronkathon_amd import _lib as L
+    for n in (1 << 18, 3 << 16):
+        c = splitmix_field(n % 1000, n)
+        y = np.empty(n, dtype=np.uint64); nodes = np.empty(n, dtype=np.uint64)
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(c), L.ptr(y), n))
+        L.check(L.lib.ronk_lagrange_nodes(GP, GG, L.ptr(nodes), n))
+        import ctypes as C
+        for x in (7, 0x123456789ABCDEF % GP):      # (2 has order 192: it IS a node when 192 | n, where the reference yields 0)
+            assert L.out_scalar(L.lib.ronk_lagrange_eval, GP, L.ptr(y), L.ptr(nodes), n, x) == orc.poly_eval(GP, c, x), (n, x)
+        if n % 192 == 0:
+            assert L.out_scalar(L.lib.ronk_lagrange_eval, GP, L.ptr(y), L.ptr(nodes), n, 2) == 0
+        assert L.out_scalar(L.lib.ronk_lagrange_eval, GP, L.ptr(y), L.ptr(nodes), n, int(nodes[12345])) == 0
+        bad = nodes.copy(); bad[777] = bad[778]
+        out = C.c_uint64(0)
+        assert L.lib.ronk_lagrange_eval(GP, L.ptr(y), L.ptr(bad), n, 2, C.byref(out)) == -9
