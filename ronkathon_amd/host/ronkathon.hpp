@@ -236,4 +236,26 @@ AffinePoint open(const std::array<S, D>& coeffs, S eval_point, const std::vector
 }
 }  // namespace kzg
 
+// ---- the same commit over a production-size group: BN254 (alt_bn128) G1, y^2 = x^3 + 3 -------------------------------
+// ronkathon's field traits are usize-wide (src/algebra/mod.rs:8-13), so the 254-bit types are plain data here: four 64-bit
+// little-endian limbs per coordinate / scalar, standard form, (0, 0) = the point at infinity (what ronk_msm_bn254 takes).
+namespace bn254 {
+using Limbs = std::array<uint64_t, 4>;
+struct G1Affine {
+  Limbs x{0, 0, 0, 0}, y{0, 0, 0, 0};
+  static G1Affine Infinity() { return G1Affine{}; }
+  static G1Affine Generator() { G1Affine g; g.x = {1, 0, 0, 0}; g.y = {2, 0, 0, 0}; return g; }
+  friend bool operator==(const G1Affine& a, const G1Affine& b) { return a.x == b.x && a.y == b.y; }
+};
+static_assert(sizeof(G1Affine) == 64, "G1Affine is passed to the C ABI as 8 words");
+// kzg::commit (src/kzg/setup.rs:48-60): SUM g1_srs[i] * coeffs[i]; asserts like the reference that the SRS is long enough
+inline G1Affine commit(const std::vector<Limbs>& coeffs, const std::vector<G1Affine>& g1_srs) {
+  if (g1_srs.size() < coeffs.size()) throw Panic(RONK_ERR_INDEX);
+  G1Affine out;
+  check(ronk_msm_bn254(reinterpret_cast<const uint64_t*>(g1_srs.data()), reinterpret_cast<const uint64_t*>(coeffs.data()),
+                       coeffs.size(), reinterpret_cast<uint64_t*>(&out)));
+  return out;
+}
+}  // namespace bn254
+
 }  // namespace ronkathon

@@ -85,6 +85,22 @@ int main() {
   CHECK(kzg::commit(std::vector<S>{S::new_(7), S::new_(16), S::new_(1), S::new_(11), S::new_(1)}, srs) == AffinePoint::new_(32, 0, 59, 0));
   CHECK(kzg::commit(std::vector<S>{S::new_(3), S::new_(2), S::new_(1)}, srs) == AffinePoint::new_(32, 0, 59, 0));
   CHECK((kzg::open<S, 4>(arr<S, 4>({11, 11, 11, 1}), S::new_(4), srs) == AffinePoint::new_(26, 0, 45, 0)));
+  // kzg::commit over BN254 G1 (bucket-method MSM): 5*G + 7*G == 3*(4*G) == 12*G, computed three ways; G - G == infinity
+  {
+    using namespace bn254;
+    const G1Affine g = G1Affine::Generator();
+    const G1Affine g4 = commit({Limbs{4, 0, 0, 0}}, {g});
+    const G1Affine a = commit({Limbs{5, 0, 0, 0}, Limbs{7, 0, 0, 0}}, {g, g});
+    const G1Affine b = commit({Limbs{3, 0, 0, 0}}, {g4});
+    const G1Affine c = commit({Limbs{12, 0, 0, 0}}, {g});
+    CHECK(a == b && b == c && !(a == G1Affine::Infinity()));
+    // r - 1 (the group order minus one) times G is -G: adding G gives infinity
+    const Limbs rm1{0x43e1f593f0000000ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    CHECK(commit({rm1, Limbs{1, 0, 0, 0}}, {g, g}) == G1Affine::Infinity());
+    // 2G: the EIP-196 test vector
+    const G1Affine two = commit({Limbs{2, 0, 0, 0}}, {g});
+    CHECK(two.x == (Limbs{0xd3c208c16d87cfd3ull, 0xd97816a916871ca8ull, 0x9b85045b68181585ull, 0x030644e72e131a02ull}));
+  }
   printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }
