@@ -292,13 +292,14 @@ def main():
                             "frac": nn * 96.0 / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "note": "algorithmic bytes = 96 per point (64-byte point + 32-byte scalar); the work is VALU-bound "
                                     "254-bit modular arithmetic, not memory-bound: see valu",
-                            "valu": {"bucket_additions": int(nn) * 18, "valu_per_addition": 3500,
-                                     "issue_bound_ms": nn * 18 * 3500 / 64.0 / 1024.0 * 1.95e-6,
-                                     "frac_of_valu_peak": (nn * 18 * 3500 / 64.0 / 1024.0 * 1.95e-6) / (dt * 1e3),
-                                     "note": "mixed additions of the accumulate kernel alone (n x ~18 windows at 2^20 points; "
-                                             "8M + 2S at ~290 VALU per Montgomery product + additions, static count of the kernel) at "
-                                             "the measured 1.95 ns per wave-instruction per SIMD (profiles/r02_clock_probe.txt); the "
-                                             "sort, the bucket reduction and the host tail are on top"}}}
+                            "valu": {"bucket_additions": int(nn) * 18, "valu_per_addition": 4080,
+                                     "issue_bound_ms": nn * 18 * 4080 / 64.0 / 1024.0 * 1.95e-6,
+                                     "frac_of_valu_peak": (nn * 18 * 4080 / 64.0 / 1024.0 * 1.95e-6) / (dt * 1e3),
+                                     "note": "mixed additions of the accumulate kernel alone (n x ~18 windows at 2^20 points): "
+                                             "SQ_INSTS_VALU = 1.204e9 wave-instructions per launch = 4 080 lane-instructions per "
+                                             "addition incl. divergence (profiles/r02_rocprof_msm20_pmc.txt; static count of the "
+                                             "8M + 2S path: ~3 500), at the measured 1.95 ns per wave-instruction per SIMD "
+                                             "(profiles/r02_clock_probe.txt); the sort, the bucket reduction and the host tail are on top"}}}
         if cpu:
             res["cpu_baseline"] = cpu
         print(json.dumps(res))
