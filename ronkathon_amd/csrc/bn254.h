@@ -4,7 +4,9 @@
 //
 //   p = 36x^4 + 36x^3 + 24x^2 + 6x + 1,  x = 4965661367192848881  (254 bits),   E: y^2 = x^3 + 3,   G = (1, 2)
 //
-// Field elements: 8 x 32-bit limbs, little endian, MONTGOMERY form (R = 2^256) inside kernels; the C ABI speaks the
+// Field elements: 8 x 32-bit limbs, little endian, MONTGOMERY form (R = 2^256), WEAKLY REDUCED -- any representative in
+// [0, 2p) -- inside kernels (4p < R, so a Montgomery product of two such values is again below 2p without the final
+// conditional subtraction, and sums of two fit 256 bits; zero tests accept 0 and p; the conversion back canonicalises); the C ABI speaks the
 // standard form as 4 x 64-bit little-endian limbs (the same bytes).  gfx950 has no 64x64 multiplier: a limb product is one
 // v_mad_u64_u32 (32 x 32 + 64 -> 64), which is exactly the CIOS inner step t + a*b + carry.
 // Points: affine (x, y) on input ((0, 0) = the point at infinity, which is not on the curve), buckets and partial sums
@@ -33,22 +35,25 @@ struct Fp { u32 l[8]; };
 
 // constants live in functions (constexpr arrays in device code without relocatable globals)
 RONK_HD u32 P_limb(int i) { constexpr u32 c[8] = BN254_P_LIMBS; return c[i]; }
+RONK_HD u32 P2_limb(int i) { constexpr u32 c[8] = BN254_2P_LIMBS; return c[i]; }
 RONK_HD Fp fp_const_one() { constexpr u32 c[8] = BN254_R_LIMBS; Fp r; for (int i = 0; i < 8; i++) r.l[i] = c[i]; return r; }
 RONK_HD Fp fp_const_r2() { constexpr u32 c[8] = BN254_R2_LIMBS; Fp r; for (int i = 0; i < 8; i++) r.l[i] = c[i]; return r; }
 RONK_HD Fp fp_const_b() { constexpr u32 c[8] = BN254_B_MONT_LIMBS; Fp r; for (int i = 0; i < 8; i++) r.l[i] = c[i]; return r; }
 RONK_HD Fp fp_zero() { Fp r; for (int i = 0; i < 8; i++) r.l[i] = 0; return r; }
 
-RONK_HD bool fp_is_zero(const Fp& a) {
+// the integer zero (the encoding of the point at infinity's coordinates)
+RONK_HD bool fp_is_zero_exact(const Fp& a) {
   u32 o = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) o |= a.l[i];
   return o == 0;
 }
-RONK_HD bool fp_eq(const Fp& a, const Fp& b) {
-  u32 o = 0;
+// a == 0 (mod p) for a weakly reduced a: the integers 0 and p
+RONK_HD bool fp_is_zero(const Fp& a) {
+  u32 o = 0, q = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
-  return o == 0;
+  for (int i = 0; i < 8; i++) { o |= a.l[i]; q |= a.l[i] ^ P_limb(i); }
+  return o == 0 || q == 0;
 }
 // a >= p (as integers)
 RONK_HD bool fp_geq_p(const Fp& a) {
@@ -60,23 +65,24 @@ RONK_HD bool fp_geq_p(const Fp& a) {
   }
   return ge;
 }
-// r = a - p if a >= p (a < 2p)
-RONK_HD Fp fp_cond_sub_p(const Fp& a, u32 top = 0) {
+// r = a - M if a >= M, M = p (TWO == false) or 2p
+template <bool TWO>
+RONK_HD Fp fp_cond_sub(const Fp& a) {
   Fp d;
   u64 borrow = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const u64 t = (u64)a.l[i] - P_limb(i) - borrow;
+    const u64 t = (u64)a.l[i] - (TWO ? P2_limb(i) : P_limb(i)) - borrow;
     d.l[i] = (u32)t;
     borrow = (t >> 32) & 1;
   }
-  // a - p is the answer when there was no borrow, or when the ninth limb `top` absorbs it
-  const bool use = top != 0 || borrow == 0;
   Fp r;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = use ? d.l[i] : a.l[i];
+  for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
   return r;
 }
+// weakly reduced -> canonical
+RONK_HD Fp fp_canon(const Fp& a) { return fp_cond_sub<false>(fp_cond_sub<false>(a)); }
 RONK_HD Fp fp_add(const Fp& a, const Fp& b) {
   Fp s;
   u64 c = 0;
@@ -86,7 +92,7 @@ RONK_HD Fp fp_add(const Fp& a, const Fp& b) {
     s.l[i] = (u32)t;
     c = t >> 32;
   }
-  return fp_cond_sub_p(s, (u32)c);   // p < 2^254: the sum of two residues fits 255 bits, c == 0 always
+  return fp_cond_sub<true>(s);   // a + b < 4p < 2^256: no carry out; back below 2p
 }
 RONK_HD Fp fp_sub(const Fp& a, const Fp& b) {
   Fp d;
@@ -97,18 +103,19 @@ RONK_HD Fp fp_sub(const Fp& a, const Fp& b) {
     d.l[i] = (u32)t;
     borrow = (t >> 32) & 1;
   }
-  // + p on borrow
+  // + 2p on borrow: the difference of two values below 2p lies in (-2p, 2p)
   const u32 m = (u32)0 - (u32)borrow;
   u64 c = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const u64 t = (u64)d.l[i] + (P_limb(i) & m) + c;
+    const u64 t = (u64)d.l[i] + (P2_limb(i) & m) + c;
     d.l[i] = (u32)t;
     c = t >> 32;
   }
   return d;
 }
-RONK_HD Fp fp_neg(const Fp& a) { return fp_is_zero(a) ? a : fp_sub(fp_zero(), a); }
+RONK_HD bool fp_eq(const Fp& a, const Fp& b) { return fp_is_zero(fp_sub(a, b)); }
+RONK_HD Fp fp_neg(const Fp& a) { return fp_is_zero_exact(a) ? a : fp_sub(fp_zero(), a); }   // 0 - a + 2p in (0, 2p); the integer 0 stays 0
 RONK_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
 // ---- Montgomery product a*b/R mod p.
@@ -177,15 +184,15 @@ RONK_HD Fp fp_mul(const Fp& a, const Fp& b) {
     r.l[i - 8] = (u32)t.lo;
     acc_shift(t);
   }
-  return fp_cond_sub_p(r, (u32)t.lo);
+  return r;   // < 2p for inputs < 2p (4p < R): no final subtraction; the 17th limb (u32)t.lo is 0
 }
 RONK_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 
 RONK_HD Fp fp_to_mont(const Fp& a) { return fp_mul(a, fp_const_r2()); }
-RONK_HD Fp fp_from_mont(const Fp& a) {
+RONK_HD Fp fp_from_mont(const Fp& a) {   // -> standard form, canonical
   Fp one = fp_zero();
   one.l[0] = 1;
-  return fp_mul(a, one);
+  return fp_canon(fp_mul(a, one));
 }
 // a^(p-2) (a != 0), Montgomery in and out
 RONK_HD Fp fp_inv(const Fp& a) {
@@ -215,7 +222,7 @@ RONK_HD void fp_store(u64* w, const Fp& a) {
 struct Affine { Fp x, y; };            // Montgomery form; (0, 0) = infinity
 struct Xyzz { Fp X, Y, ZZ, ZZZ; };     // ZZ == 0 <=> infinity
 
-RONK_HD bool affine_is_inf(const Affine& p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
+RONK_HD bool affine_is_inf(const Affine& p) { return fp_is_zero_exact(p.x) && fp_is_zero_exact(p.y); }
 RONK_HD Xyzz xyzz_inf() { Xyzz r; r.X = fp_zero(); r.Y = fp_zero(); r.ZZ = fp_zero(); r.ZZZ = fp_zero(); return r; }
 RONK_HD bool xyzz_is_inf(const Xyzz& p) { return fp_is_zero(p.ZZ); }
 // y^2 == x^3 + 3

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) msm_prepare_kernel(const u64* __restrict_
   p.x = bn254::fp_load(pts + (size_t)i * 8);
   p.y = bn254::fp_load(pts + (size_t)i * 8 + 4);
   bool ok = !bn254::fp_geq_p(p.x) && !bn254::fp_geq_p(p.y);
-  if (ok && !(bn254::fp_is_zero(p.x) && bn254::fp_is_zero(p.y))) {
+  if (ok && !(bn254::fp_is_zero_exact(p.x) && bn254::fp_is_zero_exact(p.y))) {
     p.x = bn254::fp_to_mont(p.x);
     p.y = bn254::fp_to_mont(p.y);
     ok = bn254::affine_on_curve(p);

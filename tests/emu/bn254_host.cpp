@@ -10,15 +10,15 @@ extern "C" {
 void h_fp_mul(const u64* a, const u64* b, u64* out) {
   fp_store(out, fp_from_mont(fp_mul(fp_to_mont(fp_load(a)), fp_to_mont(fp_load(b)))));
 }
-void h_fp_add(const u64* a, const u64* b, u64* out) { fp_store(out, fp_add(fp_load(a), fp_load(b))); }
-void h_fp_sub(const u64* a, const u64* b, u64* out) { fp_store(out, fp_sub(fp_load(a), fp_load(b))); }
+void h_fp_add(const u64* a, const u64* b, u64* out) { fp_store(out, fp_canon(fp_add(fp_load(a), fp_load(b)))); }
+void h_fp_sub(const u64* a, const u64* b, u64* out) { fp_store(out, fp_canon(fp_sub(fp_load(a), fp_load(b)))); }
 void h_fp_inv(const u64* a, u64* out) { fp_store(out, fp_from_mont(fp_inv(fp_to_mont(fp_load(a))))); }
 int h_fp_geq_p(const u64* a) { return fp_geq_p(fp_load(a)) ? 1 : 0; }
 
 static Affine load_affine(const u64* p) {
   Affine a;
   a.x = fp_load(p); a.y = fp_load(p + 4);
-  if (!(fp_is_zero(a.x) && fp_is_zero(a.y))) { a.x = fp_to_mont(a.x); a.y = fp_to_mont(a.y); }
+  if (!(fp_is_zero_exact(a.x) && fp_is_zero_exact(a.y))) { a.x = fp_to_mont(a.x); a.y = fp_to_mont(a.y); }
   return a;
 }
 int h_on_curve(const u64* p) { return affine_on_curve(load_affine(p)) ? 1 : 0; }
