@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(256) lagrange_fast_terms_kernel(Ops ops, const
 }
 template <class Ops>
 __global__ void __launch_bounds__(256) lagrange_fast_finish_kernel(Ops ops, const u64* __restrict__ part_sum, size_t nparts,
-                                                                    size_t n, u64 x, u64* out) {
+                                                                    size_t n, u64 x, u64* out, const int* only_if_zero) {
   __shared__ u64 rs[256];
+  if (only_if_zero && *only_if_zero != 0) return;   // not an omega^i table: the general kernels write the value
   u64 s = 0;
   for (size_t i = threadIdx.x; i < nparts; i += 256) s = ops.add(s, part_sum[i]);
   rs[threadIdx.x] = s;
@@ -269,8 +270,9 @@ __global__ void __launch_bounds__(256) lagrange_fast_finish_kernel(Ops ops, cons
 template <class Ops>
 __global__ void __launch_bounds__(256) lagrange_terms_kernel(Ops ops, const u64* __restrict__ c, const u64* __restrict__ nodes,
                                                               size_t n, u64 x, u64* __restrict__ part_sum,
-                                                              u64* __restrict__ part_prod, int* flag) {
+                                                              u64* __restrict__ part_prod, int* flag, const int* skip_if_zero) {
   __shared__ u64 chunk[256];
+  if (skip_if_zero && *skip_if_zero == 0) return;   // the O(n) form applies (lagrange_check_kernel) and computes the value
   __shared__ u64 rs[256];
   __shared__ u64 rp[256];
   const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -309,9 +311,11 @@ __global__ void __launch_bounds__(256) lagrange_terms_kernel(Ops ops, const u64*
 }
 template <class Ops>
 __global__ void __launch_bounds__(256) lagrange_finish_kernel(Ops ops, const u64* __restrict__ part_sum,
-                                                               const u64* __restrict__ part_prod, size_t nparts, u64* out) {
+                                                               const u64* __restrict__ part_prod, size_t nparts, u64* out,
+                                                               const int* skip_if_zero) {
   __shared__ u64 rs[256];
   __shared__ u64 rp[256];
+  if (skip_if_zero && *skip_if_zero == 0) return;
   u64 s = 0, p = 1;
   for (size_t i = threadIdx.x; i < nparts; i += 256) { s = ops.add(s, part_sum[i]); p = ops.mul(p, part_prod[i]); }
   rs[threadIdx.x] = s;

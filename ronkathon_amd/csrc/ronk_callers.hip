@@ -268,7 +268,8 @@ extern "C" int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uin
     FIELD_DISPATCH(f, {
       hipLaunchKernelGGL((lagrange_check_kernel<decltype(ops)>), dim3((u32)((n + 255) / 256)), dim3(256), 0, s, ops, d_nodes, n, pr, d_status);
       hipLaunchKernelGGL((lagrange_fast_terms_kernel<decltype(ops)>), dim3(gb), dim3(256), 0, s, ops, d_c, d_nodes, n, x % p, ws.u());
-      hipLaunchKernelGGL((lagrange_fast_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ws.u(), (size_t)gb, n, x % p, d_out);
+      hipLaunchKernelGGL((lagrange_fast_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ws.u(), (size_t)gb, n, x % p, d_out,
+                         (const int*)nullptr);
     });
     HIPCHK(hipGetLastError());
     return RONK_OK;
@@ -276,13 +277,33 @@ extern "C" int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uin
   if (n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;  // O(n^2) weights, as in the reference
   const u32 blocks = (u32)((n + 255) / 256);
   WsLease ws;
-  RCHK(ws.acquire((size_t)blocks * 16 + 64, s));
+  RCHK(ws.acquire((size_t)blocks * 24 + 128, s));
   u64* ds = ws.u(); u64* dp = ws.u() + blocks;
   int* flag = d_status ? d_status : (int*)(ws.u() + 2 * (size_t)blocks);   // a scratch word when the caller does not ask
+  // From 256 nodes on the O(n) form is tried first ON THE DEVICE: lagrange_check_kernel leaves `sel` at 0 for an omega^i table
+  // (what Lagrange::new builds), the O(n) kernels then write the value and the general O(n^2) kernels return at once;
+  // any other table sets `sel` and it is the other way round (2^16 nodes: ~5 ms -> ~0.05 ms for the usual table).
+  int* sel = nullptr;
+  if (n >= 256) {
+    sel = (int*)(ws.u() + 2 * (size_t)blocks + 1);
+    u64* fs = ws.u() + 2 * (size_t)blocks + 2;
+    HIPCHK(hipMemsetAsync(sel, 0, 4, s));
+    LagPrimes pr;
+    pr.count = 0;
+    { size_t m = n; for (size_t q = 2; q * q <= m; q++) if (m % q == 0) { pr.q[pr.count++] = q; while (m % q == 0) m /= q; }
+      if (m > 1) pr.q[pr.count++] = m; }
+    FIELD_DISPATCH(f, {
+      hipLaunchKernelGGL((lagrange_check_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, s, ops, d_nodes, n, pr, sel);
+      hipLaunchKernelGGL((lagrange_fast_terms_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, s, ops, d_c, d_nodes, n, x % p, fs);
+      hipLaunchKernelGGL((lagrange_fast_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, fs, (size_t)blocks, n, x % p, d_out,
+                         (const int*)sel);
+    });
+  }
   FIELD_DISPATCH(f, {
     hipLaunchKernelGGL((lagrange_terms_kernel<decltype(ops)>), dim3(blocks), dim3(256), 0, s, ops, d_c, d_nodes, n, x % p,
-                       ds, dp, flag);
-    hipLaunchKernelGGL((lagrange_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ds, dp, (size_t)blocks, d_out);
+                       ds, dp, flag, (const int*)sel);
+    hipLaunchKernelGGL((lagrange_finish_kernel<decltype(ops)>), dim3(1), dim3(256), 0, s, ops, ds, dp, (size_t)blocks, d_out,
+                       (const int*)sel);
   });
   HIPCHK(hipGetLastError());
   return RONK_OK;

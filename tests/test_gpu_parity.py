@@ -1005,6 +1005,21 @@ def test_lagrange_evaluate_vs_oracle(R, orc):
             assert np.array_equal(lag.basis.nodes, nodes)
             for x in [int(v) for v in splitmix_field(n + 99, 3, p)] + [int(nodes[n // 2]), 0]:
                 assert int(lag.evaluate(x)) == orc.lagrange_eval(p, c, nodes, x), (p, n, x)
+    # >= 256 nodes: the device picks the O(n) form for omega^i tables and the general formula for anything else
+    F = R.PrimeField(GP)
+    for n in (256, 510, 1024):
+        c = splitmix_field(n + 1, n)
+        nodes = orc.lagrange_nodes(GP, GG, n)
+        other = np.unique(splitmix_field(n + 2, n + 50))[:n]            # distinct, unstructured
+        shuffled = nodes.copy(); shuffled[[3, 9]] = shuffled[[9, 3]]     # the same set, not in omega^i order
+        for tab in (nodes, other, shuffled):
+            lag = R.Polynomial(F, c, R.Lagrange(tab))
+            for x in (int(splitmix_field(n, 1)[0]), int(tab[5])):
+                assert int(lag.evaluate(x)) == orc.lagrange_eval(GP, c, tab, x), (n, x)
+    dup = orc.lagrange_nodes(GP, GG, 256).copy(); dup[17] = dup[200]
+    with pytest.raises(R.RonkPanic) as e:
+        R.Polynomial(F, splitmix_field(5, 256), R.Lagrange(dup)).evaluate(3)
+    assert e.value.code == -2
     # coincident nodes: the reference panics on ONE.div(ZERO)
     bad = R.Polynomial(R.PlutoBaseField, [1, 2, 3], R.Lagrange([5, 7, 5]))
     with pytest.raises(R.RonkPanic) as e:
