@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bn254.h"
+#include "msm_common.h"
 
 namespace ronk {
 
@@ -27,30 +28,6 @@ using bn254::Fp;
 using bn254::Xyzz;
 typedef uint64_t u64;
 typedef uint32_t u32;
-
-struct MsmShape {
-  u32 n;        // points
-  u32 c;        // window bits
-  u32 W;        // windows, W*c >= 257
-  u32 NB;       // buckets per window = 2^(c-1), weights 1 .. NB
-};
-
-// signed digit w of a 256-bit scalar (4 x u64 little endian) given the carry from the digit below; updates the carry
-__device__ __forceinline__ int msm_digit(const u64* k, u32 w, u32 c, u32* carry) {
-  const u32 bit = w * c;
-  u32 raw = 0;
-  if (bit < 256) {
-    const u32 word = bit >> 6, off = bit & 63;
-    u64 v = k[word] >> off;
-    if (off + c > 64 && word + 1 < 4) v |= k[word + 1] << (64 - off);
-    raw = (u32)(v & ((1u << c) - 1));
-  }
-  raw += *carry;
-  const u32 half = 1u << (c - 1);
-  if (raw > half) { *carry = 1; return (int)raw - (int)(1u << c); }
-  *carry = 0;
-  return (int)raw;
-}
 
 __global__ void __launch_bounds__(256) msm_prepare_kernel(const u64* __restrict__ pts, u32 n, Affine* __restrict__ out,
                                                            int* __restrict__ status) {

@@ -88,21 +88,6 @@ struct MsmWork {
   }
 };
 
-// host tail: rows[w*c + k] = Q_k of window w  ->  sum_w 2^(c w) sum_k 2^k Q_k, affine standard form
-void msm_host_tail(const MsmShape& sh, const Xyzz* rows, u64 out[8]) {
-  Xyzz total = bn254::xyzz_inf();
-  for (int w = (int)sh.W - 1; w >= 0; w--) {
-    for (u32 i = 0; i < sh.c; i++) total = bn254::xyzz_dbl(total);
-    Xyzz win = bn254::xyzz_inf();
-    for (int k = (int)sh.c - 1; k >= 0; k--) {
-      win = bn254::xyzz_dbl(win);
-      win = bn254::xyzz_add(win, rows[(size_t)w * sh.c + k]);
-    }
-    total = bn254::xyzz_add(total, win);
-  }
-  bn254::xyzz_store_affine(total, out);
-}
-
 // offsets[0..m] = exclusive prefix sums of counts[0..m)
 void msm_scan(MsmWork& wk, const u32* counts, size_t m, u32* offsets, hipStream_t s) {
   u32 per = 4;

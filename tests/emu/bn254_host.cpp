@@ -1,7 +1,10 @@
 // bn254_host.cpp -- TEST INFRASTRUCTURE: csrc/bn254.h compiled for the host behind a C interface, so that
 // tests/test_bn254_host.py can check the field and group arithmetic (the same source the kernels and the MSM's host tail
 // use) against oracle/bn254.py on the CPU-only container.  Never linked into the product library.
+#include <vector>
+
 #include "../../ronkathon_amd/csrc/bn254.h"
+#include "../../ronkathon_amd/csrc/msm_common.h"
 
 using namespace bn254;
 
@@ -57,5 +60,41 @@ void h_scalar_mul(const u64* p, const u64* k, u64* out) {
     if ((k[i >> 6] >> (i & 63)) & 1) xyzz_madd(acc, ap, false);
   }
   xyzz_store_affine(acc, out);
+}
+
+// The bucket-method pipeline of msm_kernels.h restated sequentially on the host with the SAME shared pieces (msm_digit,
+// the carry-bit mask, the bit-plane reduction, msm_host_tail): window bits c, W = ceil(257 / c) windows, 2^(c-1) buckets.
+// Returns 0, or 1 if the per-window digit from the carry mask ever differs from the rippled one.
+int h_msm_pipeline(const u64* points, const u64* scalars, u32 n, u32 c, u64* out) {
+  ronk::MsmShape sh;
+  sh.n = n; sh.c = c; sh.W = (257 + c - 1) / c; sh.NB = 1u << (c - 1);
+  std::vector<Xyzz> buckets((size_t)sh.W * sh.NB, xyzz_inf());
+  int bad = 0;
+  for (u32 i = 0; i < n; i++) {
+    const Affine pt = load_affine(points + (size_t)i * 8);
+    const u64* k = scalars + (size_t)i * 4;
+    u32 carry = 0;
+    u64 mask = 0;
+    for (u32 w = 0; w < sh.W; w++) { mask |= (u64)carry << w; (void)ronk::msm_digit(k, w, c, &carry); }
+    if (carry) bad = 1;                                   // W*c >= 257: nothing is carried out of the top window
+    carry = 0;
+    for (u32 w = 0; w < sh.W; w++) {
+      u32 cm = (u32)(mask >> w) & 1;
+      const int dm = ronk::msm_digit(k, w, c, &cm);       // what the sort kernels compute (window on its own)
+      const int d = ronk::msm_digit(k, w, c, &carry);     // rippled
+      if (d != dm) bad = 1;
+      if (d == 0) continue;
+      const u32 b = (u32)(d < 0 ? -d : d) - 1;
+      if (b >= sh.NB) { bad = 1; continue; }
+      xyzz_madd(buckets[(size_t)w * sh.NB + b], pt, d < 0);
+    }
+  }
+  std::vector<Xyzz> rows((size_t)sh.W * c, xyzz_inf());
+  for (u32 w = 0; w < sh.W; w++)
+    for (u32 kk = 0; kk < c; kk++)
+      for (u32 b = 0; b < sh.NB; b++)
+        if (((b + 1) >> kk) & 1) rows[(size_t)w * c + kk] = xyzz_add(rows[(size_t)w * c + kk], buckets[(size_t)w * sh.NB + b]);
+  ronk::msm_host_tail(sh, rows.data(), out);
+  return bad;
 }
 }

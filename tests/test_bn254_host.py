@@ -15,7 +15,7 @@ SO = os.path.join(ROOT, "build", "libbn254_host.so")
 @pytest.fixture(scope="module")
 def H():
     src = os.path.join(ROOT, "tests", "emu", "bn254_host.cpp")
-    deps = [src, os.path.join(ROOT, "ronkathon_amd", "csrc", "bn254.h"), os.path.join(ROOT, "ronkathon_amd", "csrc", "bn254_consts.h")]
+    deps = [src] + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("bn254.h", "bn254_consts.h", "msm_common.h")]
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, src])
@@ -77,3 +77,26 @@ def test_group_law(H):
     for k in (0, 1, 2, o.R - 1, o.R, 2**256 - 1, rng.randrange(2**256)):
         H.h_scalar_mul(w8(pts[0]), w4(k), out)
         assert rdpt(out) == o.mul(k, pts[0]), k
+
+
+def test_msm_pipeline_on_host(H):
+    """the bucket-method pipeline of csrc/msm_kernels.h -- signed-digit recoding (rippled and from the per-scalar carry mask
+    the sort kernels use), buckets, bit-plane reduction, host tail -- restated sequentially with the shared pieces of
+    csrc/msm_common.h, for every window size, against the oracle's fold (kzg::commit, src/kzg/setup.rs:48-60)"""
+    from oracle import bn254 as o
+    rng = random.Random(11)
+    base = o.multiples(40)
+    for c in range(5, 17):
+        n = 30
+        pts = [base[rng.randrange(40)] if rng.random() < 0.85 else None for _ in range(n)]
+        ks = [rng.choice([0, 1, (1 << (c - 1)), (1 << (c - 1)) + 1, (1 << c) - 1, o.R - 1, 2**256 - 1, rng.randrange(2**256), rng.randrange(o.R)])
+              for _ in range(n)]
+        pw = (C.c_uint64 * (8 * n))(); sw = (C.c_uint64 * (4 * n))()
+        for i, (pt, k) in enumerate(zip(pts, ks)):
+            x, y = (0, 0) if pt is None else pt
+            for j in range(4):
+                pw[8 * i + j] = (x >> (64 * j)) & (2**64 - 1); pw[8 * i + 4 + j] = (y >> (64 * j)) & (2**64 - 1)
+                sw[4 * i + j] = (k >> (64 * j)) & (2**64 - 1)
+        out = (C.c_uint64 * 8)()
+        assert H.h_msm_pipeline(pw, sw, n, c, out) == 0, c
+        assert rdpt(out) == o.msm(pts, ks), c
