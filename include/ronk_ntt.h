@@ -178,7 +178,10 @@ int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t d, uint64_t
 int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_t k, size_t n, uint64_t* xs, uint64_t* ys);
 /* Reed-Solomon Message::decode (src/codes/reed_solomon.rs:54-106): Lagrange interpolation through the first k
  * coordinates (xs[j], ys[j]) of a (possibly erased) codeword -> the k message coefficients.  Coincident nodes are
- * the reference's `numerator / denominator` panic -> RONK_ERR_ZERO_INVERSE.  k <= 2^14 (O(k^2) work). */
+ * the reference's `numerator / denominator` panic -> RONK_ERR_ZERO_INVERSE.  k <= 2^14 (O(k^2) work) for arbitrary nodes; for
+ * the node sequences Message::encode produces (xs[j] = q^j, q of any order > k; Goldilocks) an O(k log k) form -- two
+ * convolutions on the NTT path, the same interpolating polynomial -- is chosen on the device from k = 1024 on and covers
+ * k <= 2^21; other node sets of that size are RONK_ERR_UNSUPPORTED (the _dev form: bit 2 of *d_status, then required). */
 int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out);
 /* Batched Message::encode::<N> on device (src/codes/reed_solomon.rs:42-52), the production shape of a
  * Reed-Solomon / low-degree extension (1024 x 2^16): d_msgs holds plan.batch compact messages of k coefficients,

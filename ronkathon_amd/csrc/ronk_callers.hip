@@ -482,25 +482,66 @@ extern "C" int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_
 
 // Message::decode (codes/reed_solomon.rs:54-106): the first k coordinates -> the k message coefficients.
 // Device resident: d_xs / d_ys hold CANONICAL residues; d_status (may be NULL) is set non-zero for coincident nodes.
+// Message::decode for x_j = q^j in O(K log K) (interp_kernels.h): two linear convolutions on the NTT path.  `sel` (device word,
+// zeroed by the caller) gets bit 2 when the nodes are not such a sequence; the result is written only when it stays 0.
+// Synchronises `s` once (temporaries).
+static int rs_decode_fast_dev(const u64* d_xs, const u64* d_ys, size_t k, u64* d_out, int* sel, hipStream_t s) {
+  const u64 P = RONK_GOLDILOCKS_P, G = RONK_GOLDILOCKS_G;
+  DevBuf B, arev, b, conv, M, srev, conv2, tot;
+  RCHK(B.alloc((k + 1) * 8)); RCHK(arev.alloc(k * 8)); RCHK(b.alloc((2 * k - 1) * 8)); RCHK(conv.alloc((3 * k - 2) * 8));
+  RCHK(M.alloc((k + 1) * 8)); RCHK(srev.alloc(k * 8)); RCHK(conv2.alloc(2 * k * 8)); RCHK(tot.alloc(1025 * 8));
+  const size_t m = k + 1;
+  const u32 nb = (u32)((m + 256 * RSF_PER - 1) / (256 * RSF_PER));
+  hipLaunchKernelGGL(rsf_check_kernel, dim3((u32)((k + 255) / 256)), dim3(256), 0, s, d_xs, k, sel);
+  hipLaunchKernelGGL(rsf_factors_kernel, dim3(grid_for(m)), dim3(256), 0, s, d_xs, k, B.u());
+  hipLaunchKernelGGL(rsf_scan_totals_kernel, dim3(nb), dim3(256), 0, s, (const u64*)B.u(), m, tot.u());
+  hipLaunchKernelGGL(rsf_scan_mid_kernel, dim3(1), dim3(1024), 0, s, tot.u(), nb);
+  hipLaunchKernelGGL(rsf_scan_apply_kernel, dim3(nb), dim3(256), 0, s, B.u(), m, (const u64*)tot.u());
+  hipLaunchKernelGGL(rsf_prepare_kernel, dim3(grid_for(2 * k - 1)), dim3(256), 0, s, d_xs, d_ys, (const u64*)B.u(), k, arev.u(), b.u(),
+                     M.u());
+  HIPCHK(hipGetLastError());
+  RCHK(ronk_poly_mul_dev(P, G, arev.u(), k, b.u(), 2 * k - 1, conv.u(), s));
+  hipLaunchKernelGGL(rsf_unchirp_kernel, dim3(grid_for(k)), dim3(256), 0, s, d_xs, (const u64*)conv.u(), k, srev.u());
+  HIPCHK(hipGetLastError());
+  RCHK(ronk_poly_mul_dev(P, G, srev.u(), k, M.u(), k + 1, conv2.u(), s));
+  hipLaunchKernelGGL(rsf_extract_kernel, dim3(grid_for(k)), dim3(256), 0, s, (const u64*)conv2.u(), k, (const int*)sel, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));   // the temporaries above are freed on return
+  return RONK_OK;
+}
+static const size_t RS_FAST_MAX_K = (size_t)1 << 21;
+
 extern "C" int ronk_rs_decode_dev(uint64_t p, const uint64_t* d_xs, const uint64_t* d_ys, size_t k, uint64_t* d_out,
                                   int* d_status, void* stream) {
   if (k == 0) return RONK_OK;
   if (!d_xs || !d_ys || !d_out) return RONK_ERR_INVALID;
-  if (k > RS_DECODE_MAX_K) return RONK_ERR_UNSUPPORTED;
   RCHK(need_device());
   FieldCtx f;
   RCHK(make_field(p, &f));
   hipStream_t s = (hipStream_t)stream;
+  static const size_t fast_min = [] { const char* e = getenv("RONK_RS_FAST_MIN"); return e ? (size_t)atol(e) : (size_t)1024; }();
+  const bool try_fast = f.kind == F_GL && k >= fast_min && k >= 2 && k <= RS_FAST_MAX_K;
+  if (k > RS_DECODE_MAX_K) {
+    // beyond the O(K^2) kernels only the geometric node sequences of Message::encode are covered: bit 2 of *d_status otherwise
+    if (!try_fast || !d_status) return RONK_ERR_UNSUPPORTED;
+    return rs_decode_fast_dev(d_xs, d_ys, k, d_out, d_status, s);
+  }
   const u32 nblk = (u32)((k + 255) / 256);
   WsLease ws;
-  RCHK(ws.acquire((k + (k + 1) + (size_t)nblk * k + 8) * 8, s));
+  RCHK(ws.acquire((k + (k + 1) + (size_t)nblk * k + 16) * 8, s));
   u64* dw = ws.u(); u64* dm = dw + k; u64* dpart = dm + (k + 1);
   int* flag = d_status ? d_status : (int*)(dpart + (size_t)nblk * k);
+  int* sel = nullptr;
+  if (try_fast) {   // the device decides: `sel` stays 0 for x_j = q^j (fast kernels write the result, the others return at once)
+    sel = (int*)(dpart + (size_t)nblk * k + 1);
+    HIPCHK(hipMemsetAsync(sel, 0, 4, s));
+    RCHK(rs_decode_fast_dev(d_xs, d_ys, k, d_out, sel, s));
+  }
   FIELD_DISPATCH(f, {
-    hipLaunchKernelGGL((rs_weights_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, d_xs, d_ys, k, dw, flag);
-    hipLaunchKernelGGL((master_poly_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, s, ops, d_xs, k, dm);
-    hipLaunchKernelGGL((rs_accumulate_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, d_xs, dw, dm, k, dpart);
-    hipLaunchKernelGGL((rs_finish_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, dpart, (size_t)nblk, k, d_out);
+    hipLaunchKernelGGL((rs_weights_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, d_xs, d_ys, k, dw, flag, (const int*)sel);
+    hipLaunchKernelGGL((master_poly_kernel<decltype(ops)>), dim3(1), dim3(1024), 0, s, ops, d_xs, k, dm, (const int*)sel);
+    hipLaunchKernelGGL((rs_accumulate_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, d_xs, dw, dm, k, dpart, (const int*)sel);
+    hipLaunchKernelGGL((rs_finish_kernel<decltype(ops)>), dim3(nblk), dim3(256), 0, s, ops, dpart, (size_t)nblk, k, d_out, (const int*)sel);
   });
   HIPCHK(hipGetLastError());
   return RONK_OK;
@@ -508,7 +549,7 @@ extern "C" int ronk_rs_decode_dev(uint64_t p, const uint64_t* d_xs, const uint64
 extern "C" int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k, uint64_t* out) {
   if (k == 0) return RONK_OK;
   if (!xs || !ys || !out) return RONK_ERR_INVALID;
-  if (k > RS_DECODE_MAX_K) return RONK_ERR_UNSUPPORTED;
+  if (k > RS_FAST_MAX_K) return RONK_ERR_UNSUPPORTED;
   RCHK(need_device());
   std::vector<u64> hx(k), hy(k);
   for (size_t i = 0; i < k; i++) { hx[i] = xs[i] % p; hy[i] = ys[i] % p; }
@@ -520,7 +561,8 @@ extern "C" int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys
   RCHK(ronk_rs_decode_dev(p, dx.u(), dy.u(), k, dout.u(), (int*)dflag.p, 0));
   int hflag = 0;
   HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
-  if (hflag) return RONK_ERR_ZERO_INVERSE;  // coincident nodes: numerator / ZERO
+  if (hflag & 4) return RONK_ERR_UNSUPPORTED;  // more than 2^14 nodes that are not q^j
+  if (hflag) return RONK_ERR_ZERO_INVERSE;     // coincident nodes: numerator / ZERO
   HIPCHK(hipMemcpy(out, dout.p, k * 8, hipMemcpyDeviceToHost));
   return RONK_OK;
 }

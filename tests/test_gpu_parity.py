@@ -1178,3 +1178,29 @@ def test_lagrange_evaluate_large(R, orc):
         bad = nodes.copy(); bad[777] = bad[778]
         out = C.c_uint64(0)
         assert L.lib.ronk_lagrange_eval(GP, L.ptr(y), L.ptr(bad), n, 2, C.byref(out)) == -9
+
+
+def test_rs_decode_fast_path_small_sizes(R):
+    """the O(K log K) decode (x_j = q^j) forced on from K = 2, against the oracle, in its own process"""
+    import subprocess, sys
+    e = dict(os.environ, RONK_RS_FAST_MIN="2")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "rs_fast_check.py")],
+                         capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0 and "rs fast check ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
+
+
+def test_rs_decode_large_roundtrip(R, orc):
+    """Message::decode(encode(msg)) == msg (src/codes/reed_solomon.rs:136-218 round trips) far beyond the O(K^2) kernels:
+    K = 2^16 of N = 2^17, K = 3 * 2^14 of N = 3 * 2^15, K = 2^20 of N = 2^21; the default path at K = 2^12; and
+    RONK_ERR_UNSUPPORTED for a large node set that is not geometric"""
+    from ronkathon_amd import _lib as L
+    for k, N in ((1 << 12, 1 << 13), (1 << 16, 1 << 17), (3 << 14, 3 << 15), (1 << 20, 1 << 21)):
+        msg = splitmix_field(k % 977, k)
+        full = np.empty(N, dtype=np.uint64); nodes = np.empty(N, dtype=np.uint64)
+        L.check(L.lib.ronk_dft(GP, GG, L.ptr(np.concatenate([msg, np.zeros(N - k, dtype=np.uint64)])), L.ptr(full), N))
+        L.check(L.lib.ronk_lagrange_nodes(GP, GG, L.ptr(nodes), N))
+        out = np.zeros(k, dtype=np.uint64)
+        L.check(L.lib.ronk_rs_decode(GP, L.ptr(nodes), L.ptr(full), k, L.ptr(out)))
+        assert np.array_equal(out, msg), (k, N)
+    bad = nodes[: 1 << 15].copy(); bad[[5, 9]] = bad[[9, 5]]
+    assert L.lib.ronk_rs_decode(GP, L.ptr(bad), L.ptr(full), 1 << 15, L.ptr(out)) == -9
