@@ -188,6 +188,12 @@ int ronk_rs_decode(uint64_t p, const uint64_t* xs, const uint64_t* ys, size_t k,
  * d_ys receives plan.batch x N y-coordinates (x_i = omega_N^i: ronk_lagrange_nodes).  The zero padding of
  * `Polynomial::from(message)` is implicit (no padded copy) for Goldilocks plans with N >= 2^13. */
 int ronk_rs_encode_batch_dev(ronk_plan* plan, const uint64_t* d_msgs, size_t k, uint64_t* d_ys, void* stream);
+/* Low-degree extension: a batch of polynomials given by their values on {omega_K^i} (plan_k: n = K) -> their values on
+ * coset_shift * {omega_N^i} (plan_n: n = N >= K, same batch and modulus).  = Message::encode::<N> of lagrange_poly.ifft()
+ * (src/polynomial/mod.rs:430-453, src/codes/reed_solomon.rs:42-52), the coefficients multiplied by coset_shift^i first when
+ * coset_shift != 1 (Goldilocks only).  d_coeffs: batch x K scratch that receives the coefficients; d_out: batch x N. */
+int ronk_lde_batch_dev(ronk_plan* plan_k, ronk_plan* plan_n, const uint64_t* d_evals, uint64_t* d_coeffs, uint64_t* d_out,
+                       uint64_t coset_shift, void* stream);
 
 /* kzg::commit (src/kzg/setup.rs:45-60): sum_i points[i] * scalars[i] with the reference's AffinePoint Add / Mul<ScalarField>
  * (src/curve/mod.rs:152-211) on y^2 = x^3 + a x + b over the quadratic extension F_p[u]/(u^2 - nr) of a small prime

@@ -90,6 +90,7 @@ _SIG = {
     "ronk_rs_encode": (_int, [_u64, _u64, _vp, _sz, _sz, _vp, _vp]),
     "ronk_rs_decode": (_int, [_u64, _vp, _vp, _sz, _vp]),
     "ronk_rs_encode_batch_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "ronk_lde_batch_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),
     "ronk_curve_msm": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "ronk_msm_bn254": (_int, [_vp, _vp, _sz, _vp]),
     "ronk_msm_bn254_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),

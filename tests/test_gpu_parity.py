@@ -1204,3 +1204,28 @@ def test_rs_decode_large_roundtrip(R, orc):
         assert np.array_equal(out, msg), (k, N)
     bad = nodes[: 1 << 15].copy(); bad[[5, 9]] = bad[[9, 5]]
     assert L.lib.ronk_rs_decode(GP, L.ptr(bad), L.ptr(full), 1 << 15, L.ptr(out)) == -9
+
+
+def test_low_degree_extension_batch(R, orc):
+    """row N2's "iNTT -> zero-pad -> NTT": values on {omega_K^i} -> values on shift * {omega_N^i}, batched, against the oracle
+    (ifft, then the polynomial evaluated on the extended domain); shift = 1 and a coset; single- and multi-pass plan sizes"""
+    import torch
+    from ronkathon_amd import _lib as L
+    for lk, ln, batch in ((4, 6, 3), (10, 12, 5), (12, 14, 2), (14, 15, 3), (16, 17, 1)):
+        K, N = 1 << lk, 1 << ln
+        pk = L.Plan(GP, GG, lk, batch); pn = L.Plan(GP, GG, ln, batch)
+        ev = splitmix_field(lk * 31 + batch, K * batch)
+        d_ev = torch.from_numpy(ev.view(np.int64)).cuda()
+        d_co = torch.empty(K * batch, dtype=torch.int64, device="cuda"); d_out = torch.empty(N * batch, dtype=torch.int64, device="cuda")
+        for shift in (1, 7, 0x123456789ABCDEF % GP):
+            L.check(L.lib.ronk_lde_batch_dev(pk.h, pn.h, d_ev.data_ptr(), d_co.data_ptr(), d_out.data_ptr(), shift, 0))
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy().view(np.uint64)
+            for b in range(batch):
+                co = orc.ifft(GP, GG, ev[b * K:(b + 1) * K])
+                sc = np.array([orc.mul(GP, int(co[i]), pow(shift, i, GP)) for i in range(K)], dtype=np.uint64) if shift != 1 else co
+                want = orc.fft(GP, GG, np.concatenate([sc, np.zeros(N - K, dtype=np.uint64)]))
+                assert np.array_equal(got[b * N:(b + 1) * N], want), (lk, ln, b, shift)
+                if shift == 1:   # an extension: the values on the K-point sub-domain are the original ones
+                    assert np.array_equal(got[b * N:(b + 1) * N][:: N // K], ev[b * K:(b + 1) * K])
+        pk.close(); pn.close()
