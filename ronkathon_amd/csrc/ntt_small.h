@@ -62,7 +62,8 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
         const i64 off = in_row(p0 + i * q);
         // lin = offset inside the polynomial (everything but the b1 term): >= in_valid reads as ZERO (From<[F;N]> padding)
         const u64 lin = (u64)((i64)b2 * a.in_sb2 + (i64)t * a.in_st + (i64)c * a.in_sc + off);
-        const bool ok = live && (a.in_valid == ~(u64)0 || lin < a.in_valid);
+        const u64 valid = (b1 && a.in_valid1 != ~(u64)0) ? a.in_valid1 : a.in_valid;
+        const bool ok = live && (valid == ~(u64)0 || lin < valid);
         x[i] = ok ? in[off] : 0;
         if (a.in2 && ok) x[i] = gl64::mul(x[i], (a.in2 + (in - a.in))[off]);   // fused pointwise product
       }

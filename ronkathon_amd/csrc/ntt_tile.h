@@ -71,6 +71,8 @@ struct TileArgs {
   // (everything but the b1 term), loads with lin >= in_valid read as ZERO and stores with lin >= out_valid are
   // dropped.  ~0 = no limit.
   u64 in_valid, out_valid;
+  u64 in_valid1;   // the input limit of batch entries b1 >= 1 when it differs from in_valid (~0: the same): the two operands
+                   // of a polynomial multiply transformed as ONE batch of two
   // Staged I/O for single-pass plans of tiny transforms (n = 16, 32; plan.h): the tile -- C whole polynomials -- is one contiguous
   // run of R*C elements on both sides, but a lane's own accesses are only M*8 bytes long (n = 16: one polynomial per
   // lane, 128-byte lane stride, outputs in bit-reversed order).  With stage_io the run is copied HBM <-> LDS with fully
@@ -264,7 +266,7 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
   TileArgs a = a_in;                             // what the instantiation knows replaces what the launch says
   if constexpr (CFG::LOGC >= 0) a.logc = CFG::LOGC;
   if constexpr (KIND != 0) {
-    a.stage_io = 0; a.in2 = nullptr; a.in_valid = a.out_valid = ~(u64)0; a.scale = 1;
+    a.stage_io = 0; a.in2 = nullptr; a.in_valid = a.out_valid = a.in_valid1 = ~(u64)0; a.scale = 1;
     if constexpr (KIND != 3) a.tw_full = nullptr;
     a.nb2 = 1; a.in_sb2 = a.out_sb2 = 0; a.out_sc = 1;
     a.xb1 = a.xb2 = a.x0 = a.yb1 = a.yb2 = a.y0 = 0;
@@ -350,8 +352,9 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
     for (int i = 0; i < 16; i++) x[i] = (u64)(tid * 16 + i);
   } else if (live && a.in_valid != ~(u64)0) {
     const u64 lin0 = (u64)b2 * (u64)a.in_sb2 + (u64)t * (u64)a.in_st;
+    const u64 valid = (b1 && a.in_valid1 != ~(u64)0) ? a.in_valid1 : a.in_valid;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = (lin0 + joff[i] < a.in_valid) ? ld_g<NARROW>(in, joff[i]) : 0;
+    for (int i = 0; i < 16; i++) x[i] = (lin0 + joff[i] < valid) ? ld_g<NARROW>(in, joff[i]) : 0;
   } else if (live) {
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = ld_g<NARROW>(in, joff[i]);

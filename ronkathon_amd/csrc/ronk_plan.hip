@@ -288,6 +288,8 @@ extern "C" int ronk_plan_time_passes(ronk_plan* pl, const uint64_t* d_in, uint64
 struct CacheEntry {
   ronk_plan* pl = nullptr;
   u64 *fa = nullptr, *fb = nullptr;  // poly_mul operands, n elements each (lazy)
+  ronk_plan* pl2 = nullptr;          // the same size with batch 2: both operands of a multiply in ONE pair of launches (lazy)
+  u64* fab = nullptr;                // its output: [2][n]
   hipEvent_t done = nullptr;
   uint64_t stamp = 0;
   int pins = 0;                      // users outside g_cache_mu (never evicted while pinned)
@@ -300,6 +302,8 @@ static void cache_entry_free(CacheEntry* e) {
   if (e->pl) ronk_plan_destroy(e->pl);
   if (e->fa) (void)hipFree(e->fa);
   if (e->fb) (void)hipFree(e->fb);
+  if (e->pl2) ronk_plan_destroy(e->pl2);
+  if (e->fab) (void)hipFree(e->fab);
   if (e->done) (void)hipEventDestroy(e->done);
   delete e;
 }
@@ -480,9 +484,25 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
   std::lock_guard<std::mutex> lk(g_cache_mu);
   CacheEntry* e = nullptr;
   RCHK(cache_get(p, g, (u32)k, &e));
+  ronk_plan* pl = e->pl;
+  static const bool no_pair = getenv("RONK_MUL_NO_PAIR") != nullptr;   // A/B: the two forward transforms one after the other
+  if (pl->fast && pl->fwd.pd.passes.size() > 1 && !no_pair && d_a != d_b) {   // (a square passes the same buffer twice: stride 0 is the "unchanged" sentinel)
+    // Both operands as ONE batch of two (batch stride = the distance between the caller's buffers, each with its own
+    // zero-padding limit): 512 instead of 2 x 256 tiles per pass at 2^22, so the load / store phases of one operand's
+    // tiles run under the arithmetic of the other's -- what two streams do for independent transforms.
+    // (from 2^20 on with 4-column tiles, two workgroups per CU: the configuration that lets two transforms overlap)
+    if (!e->pl2) RCHK(k >= 20 ? ronk_plan_create_tuned(&e->pl2, p, g, (u32)k, 2, pl->device, 2, -1)
+                              : ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
+    if (!e->fab) HIPCHK(hipMalloc((void**)&e->fab, 2 * N * 8));
+    HIPCHK(hipStreamWaitEvent(s, e->done, 0));
+    const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
+    RCHK(e->pl2->fwd.run(d_a, nullptr, e->fab, e->pl2->d_tmp, s, (u64)d, ~(u64)0, stride, 0, (u64)d2));
+    RCHK(transform_dev(pl, true, e->fab, e->fab + N, d_out, s, ~(u64)0, (u64)m));
+    HIPCHK(hipEventRecord(e->done, s));
+    return RONK_OK;
+  }
   if (!e->fa) HIPCHK(hipMalloc((void**)&e->fa, N * 8));
   if (!e->fb) HIPCHK(hipMalloc((void**)&e->fb, N * 8));
-  ronk_plan* pl = e->pl;
   HIPCHK(hipStreamWaitEvent(s, e->done, 0));                                // previous use of this entry's scratch
   // From<[F;N]> zero padding (mod.rs:503-515) is implicit: the forward transforms read the operands in place and
   // treat indices >= d (d2) as ZERO; the inverse loads NTT(a)*NTT(b) (pointwise product fused into the load) and

@@ -129,7 +129,8 @@ struct CompiledPlan {
   // sharded four-step: chunk j starts j*Cwc columns further right, ronk_dist.hip)
   // sb0 / sbn: launch the pass for polynomials [sb0, sb0 + sbn) of the batch only (sbn = 0: all of them)
   int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u32 sb0 = 0, u32 sbn = 0) const {
+             u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u32 sb0 = 0, u32 sbn = 0,
+             u64 in_valid1 = ~(u64)0) const {
     const PassDesc& ps = pd.passes[idx];
     TileArgs a = ps.args;
     const u64* bufs_in[3] = {in, out, tmp};
@@ -139,6 +140,7 @@ struct CompiledPlan {
     a.out = bufs_out[ps.out_buf];
     if (ps.in_buf == BUF_IN) {
       a.in_valid = in_valid;
+      a.in_valid1 = in_valid1;
       if (in_poly_stride) a.in_sb1 = (i64)in_poly_stride;   // nb1 is the batch axis of every multi-pass plan (plan.h)
     }
     if (ps.out_buf == BUF_OUT) a.out_valid = out_valid;
@@ -165,7 +167,7 @@ struct CompiledPlan {
   // instead of streaming the whole batch (512 MiB for 1024 x 2^16) through HBM between the passes.
   // RONK_SUB_BATCH_MIB: slice size in MiB of coefficients (0 = off).
   int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0) const {
+          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u64 in_valid1 = ~(u64)0) const {
     static const long slice_mib = [] { const char* e = getenv("RONK_SUB_BATCH_MIB"); return e ? atol(e) : 0L; }();
     const u64 n = (u64)1 << pd.log2n;
     if (slice_mib > 0 && pd.passes.size() >= 2 && pd.batch > 1) {
@@ -177,13 +179,13 @@ struct CompiledPlan {
         for (u64 b0 = 0; b0 < pd.batch; b0 += per) {
           const u32 cnt = (u32)(pd.batch - b0 < per ? pd.batch - b0 : per);
           for (size_t i = 0; i < pd.passes.size(); i++)
-            RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, (u32)b0, cnt));
+            RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, (u32)b0, cnt, in_valid1));
         }
         return RONK_OK;
       }
     }
     for (size_t i = 0; i < pd.passes.size(); i++)
-      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add));
+      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, 0, 0, in_valid1));
     return RONK_OK;
   }
 };

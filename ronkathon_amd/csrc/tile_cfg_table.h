@@ -6,6 +6,6 @@
 //   KIND 2 (row pass)                                    2^16 .. 2^22
 #pragma once
 #define RONK_CFG_TABLE(X)                                                                     \
-  X(10, 4, 1) X(10, 3, 1) X(11, 3, 1) X(11, 2, 1)                                             \
+  X(10, 4, 1) X(10, 3, 1) X(10, 2, 1) X(11, 3, 1) X(11, 2, 1)                                          \
   X(8, 4, 3) X(9, 4, 3) X(10, 4, 3) X(11, 3, 3) X(11, 2, 3)                                   \
-  X(8, 4, 2) X(9, 4, 2) X(10, 4, 2) X(10, 3, 2) X(11, 3, 2) X(11, 2, 2)
+  X(8, 4, 2) X(9, 4, 2) X(10, 4, 2) X(10, 3, 2) X(10, 2, 2) X(11, 3, 2) X(11, 2, 2)
