@@ -140,3 +140,18 @@ def test_small_kernel_fused_multiply_arguments(emu):
     """implicit zero padding on load (in_valid) and truncation on store (out_valid) through the small kernel"""
     for args in ((13, 1, 0, 4, 18, 25, 3000, 0, 1), (13, 1, 1, 4, 18, 25, 0, 5000, 1), (16, 2, 0, 4, 18, 25, 40000, 0, 1)):
         run(emu, *args)
+
+
+@pytest.mark.parametrize("k,batch,want_tiles", [(20, 1, 256), (21, 1, 256), (21, 2, 128), (22, 1, 256)])
+def test_planner_narrows_tiles_until_every_cu_has_one(emu, k, batch, want_tiles):
+    """auto_tiles: a pass of fewer than 256 workgroups gets narrower tiles (not below 4 columns); the specialised kernels
+    still cover the resulting shapes, and the transform is still the oracle's"""
+    out = subprocess.run([emu, str(k), str(batch), "0", "4", "18", "25", "0", "0", "1"], capture_output=True, text=True, timeout=900)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+    passes = [l for l in lines if l.startswith("pass")]
+    assert len(passes) == 2
+    for l in passes:
+        f = dict(t.split("=") for t in l.split()[1:])
+        assert int(f["tiles"]) == want_tiles and int(f["grid"]) == want_tiles * batch, l
+        assert f["kernel"].startswith("cfg:"), l
