@@ -6,7 +6,7 @@
 // in the CPU-only container.  It is built and run by tests/test_emu_kernel.py only; the
 // product library never contains or calls it.
 //
-// usage: emu_tile <log2n> <batch> <inverse 0|1> <max_logc> [twf_max_log] [three_pass_from] [in_valid] [out_valid] [auto_tiles]
+// usage: emu_tile <log2n> <batch> <inverse 0|1> <max_logc> [twf_max_log] [three_pass_from] [in_valid] [out_valid] [auto_tiles] [in_valid1]
 //        (prints OK or the first mismatch)
 #include <stdio.h>
 #include <stdlib.h>
@@ -205,6 +205,7 @@ int main(int argc, char** argv) {
   int three_from = argc > 6 ? atoi(argv[6]) : 25;
   u64 in_valid = argc > 7 ? strtoull(argv[7], 0, 10) : 0, out_valid = argc > 8 ? strtoull(argv[8], 0, 10) : 0;
   bool auto_tiles = argc > 9 && atoi(argv[9]) != 0;   // the planner's own per-pass tile rules (ronk_plan_create's default)
+  u64 in_valid1 = argc > 10 ? strtoull(argv[10], 0, 10) : 0;   // TileArgs::in_valid1: the limit of batch entries >= 1 (paired multiply operands)
   PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
@@ -224,6 +225,7 @@ int main(int argc, char** argv) {
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
     if (in_valid && p.in_buf == BUF_IN) a.in_valid = in_valid;
+    if (in_valid1 && p.in_buf == BUF_IN) a.in_valid1 = in_valid1;
     if (out_valid && p.out_buf == BUF_OUT) a.out_valid = out_valid;
     lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);   // + room for the LDS-staged round twiddles
     g_cfg_used = 0;
@@ -236,7 +238,7 @@ int main(int argc, char** argv) {
            g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
            g_cfg_used == 12 ? "half:row" : p.small ? "small" : "generic");
   }
-  if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
+  if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = (b && in_valid1) ? in_valid1 : in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
   for (u64 b = 0; b < batch; b++) {
     int rc = inv ? orc_ifft(gl64::P, 7, &in[b * n], &ref[b * n], n) : orc_fft(gl64::P, 7, &in[b * n], &ref[b * n], n);
     if (rc) { printf("oracle rc %d\n", rc); return 1; }

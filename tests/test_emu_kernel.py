@@ -155,3 +155,11 @@ def test_planner_narrows_tiles_until_every_cu_has_one(emu, k, batch, want_tiles)
         f = dict(t.split("=") for t in l.split()[1:])
         assert int(f["tiles"]) == want_tiles and int(f["grid"]) == want_tiles * batch, l
         assert f["kernel"].startswith("cfg:"), l
+
+
+@pytest.mark.parametrize("args", [(14, 2, 0, 4, 18, 25, 3000, 0, 1, 5000), (20, 2, 0, 2, 18, 25, 300000, 0, 0, 700001),
+                                  (13, 2, 0, 4, 18, 25, 8000, 0, 0, 17)])
+def test_paired_multiply_operands(emu, args):
+    """TileArgs::in_valid1: a batch of two whose entries have different zero-padding limits (the two operands of a
+    polynomial multiply transformed by one pair of launches) -- small kernel, tile kernel with 4-column tiles, tile kernel"""
+    run(emu, *args)
