@@ -60,26 +60,36 @@ KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", 
 VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
 
 
-def kernel_source_hash():
-    """sha256 over the tile-kernel sources: PMC / census files record it, so stale counters are detected"""
+# the scan workloads run kernels of scan_kernels.h only: their counters stay valid while THAT file is unchanged
+SCAN_SOURCES = ("ronkathon_amd/csrc/scan_kernels.h",)
+SOURCES_BY_WORKLOAD = {"open22": SCAN_SOURCES, "eval22": SCAN_SOURCES}
+
+
+def kernel_source_hash(files=KERNEL_SOURCES):
+    """sha256 over the kernel sources a measurement depends on (default: the tile-kernel sources): PMC / census files
+    record it, so stale counters are detected"""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in files:
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def load_if_current(path):
-    """a committed measurement file (profiles/latest_*.json) -- only if it was taken on the current kernel sources"""
+def load_if_current(path, workload=None):
+    """a committed measurement file (profiles/latest_*.json) -- only if it was taken on the current kernel sources: the
+    tile-kernel sources (`kernel_source_hash`), or, for a workload with its own source list, those (`workload_source_hash`)"""
     try:
         with open(os.path.join(ROOT, path)) as f:
             d = json.load(f)
     except Exception:  # noqa: BLE001
         return None, "missing"
-    if d.get("kernel_source_hash") != kernel_source_hash():
-        return None, "stale (kernel sources changed since %s was taken)" % path
-    return d, None
+    if d.get("kernel_source_hash") == kernel_source_hash():
+        return d, None
+    own = SOURCES_BY_WORKLOAD.get(workload)
+    if own and d.get("workload_source_hash") == kernel_source_hash(own):
+        return d, None
+    return None, "stale (kernel sources changed since %s was taken)" % path
 
 
 def cpu_baseline_mul(log2n, budget_s=10.0):
@@ -536,7 +546,7 @@ def main():
     # bench.py cannot read PMCs itself: it reports the committed measurement of the dominant kernel IF that file was
     # taken on the current kernel sources (hash stored in the file), else null.
     traffic, traffic_note, valu = None, None, None
-    pmc, why = load_if_current("profiles/latest_pmc_%s.json" % wl)
+    pmc, why = load_if_current("profiles/latest_pmc_%s.json" % wl, wl)
     if pmc and log2n == wl_log2n and batch == wl_batch:
         kern = None
         for kname, c in pmc.get("counters", {}).items():
