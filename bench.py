@@ -208,6 +208,14 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="sharded: column chunks of the exchange (0 = default, up to 4)")
     ap.add_argument("--samples", type=int, default=5, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed plans")
+    ap.add_argument("--mode", default="auto", choices=["auto", "many", "batch", "streams"],
+                    help="ntt22: how the K transforms of a region reach the library -- many: ONE plan handle (in_flight = 2), "
+                         "ronk_ntt_forward_many_dev with --group arrays per call; batch: ONE plan of batch --group, K/group calls; "
+                         "streams: one plan per caller stream (--streams), the round-1/2 protocol; auto = many")
+    ap.add_argument("--group", type=int, default=0, help="many / batch: polynomials per library call (default 16, at most K)")
+    ap.add_argument("--rotate", type=int, default=-1,
+                    help="distinct input AND output buffers the steps cycle through (HBM-cold protocol; default 8 for ntt22 "
+                         "= 512 MiB touched between two uses of a buffer, else 1 = the same buffers every step)")
     args = ap.parse_args()
 
     import torch
@@ -363,18 +371,45 @@ def main():
         args.streams = 1
     # S independent transforms in flight: each stream has its own plan (scratch), input and output, so
     # the load/store phases of one transform overlap the VALU-bound butterflies of another.
+    mode = args.mode if wl == "ntt22" else "streams"
+    if mode == "auto":
+        mode = "many"
+    group = 1
+    if mode in ("many", "batch"):
+        group = max(1, min(args.group or 16, args.steps))
+        if mode == "batch":
+            while args.steps % group:          # a region is exactly K transforms = K/group calls
+                group -= 1
+        args.streams = 1
     S = max(1, args.streams) if wl in ("ntt22", "batch16") else 1
+    R_cold = args.rotate if args.rotate >= 1 else (8 if wl == "ntt22" else 1)
     main_stream = torch.cuda.current_stream()
     streams = [main_stream] + [torch.cuda.Stream() for _ in range(S - 1)]
-    xs = [torch.from_numpy(synth(n * batch, 0x5EED0000 + rank * 16 + i).view(np.int64)).cuda() for i in range(S)]
+    pb = batch * (group if mode == "batch" else 1)          # polynomials per buffer
+    xs = [torch.from_numpy(synth(n * pb, 0x5EED0000 + rank * 16 + i).view(np.int64)).cuda() for i in range(S)]
     ys = [torch.empty_like(xs[0]) for _ in range(S)]
+    # rotation pool (per stream): buffer r > 0 is buffer 0 rolled by r*977 elements -- distinct canonical data, and every
+    # step reads and writes memory that was last touched R steps ago
+    xpool = [[xs[k]] + [torch.roll(xs[k], 977 * r) for r in range(1, R_cold)] for k in range(S)]
+    ypool = [[ys[k]] + [torch.empty_like(ys[k]) for _ in range(1, R_cold)] for k in range(S)]
     # several transforms in flight -> narrower tiles (two workgroups per CU); one at a time -> default plan
     tile_lc = 2 if (S > 1 and log2n >= 20) else -1
     if args.tile_logc >= -1 and args.tile_logc != -2:
         tile_lc = args.tile_logc
-    plans = [L.Plan(P, G, log2n, batch, local_rank, tile_log2_columns=tile_lc, twiddle_matrix_log2_max=args.twf) for _ in range(S)]
-    lat_plan = L.Plan(P, G, log2n, batch, local_rank, twiddle_matrix_log2_max=args.twf) if tile_lc >= 0 else plans[0]
+    if mode == "many":      # ONE handle; the library keeps two transforms in flight (ronk_plan_opts::in_flight)
+        plans = [L.Plan(P, G, log2n, batch, local_rank, tile_log2_columns=args.tile_logc if args.tile_logc >= -1 else -1,
+                        twiddle_matrix_log2_max=args.twf, in_flight=2)]
+    elif mode == "batch":   # ONE handle, `group` polynomials per call; in_flight left to the library (2 at this size)
+        plans = [L.Plan(P, G, log2n, pb, local_rank, tile_log2_columns=args.tile_logc if args.tile_logc >= -1 else -1,
+                        twiddle_matrix_log2_max=args.twf)]
+    else:
+        plans = [L.Plan(P, G, log2n, batch, local_rank, tile_log2_columns=tile_lc, twiddle_matrix_log2_max=args.twf,
+                        in_flight=1 if wl == "ntt22" else -1) for _ in range(S)]
+    # latency plan: one transform at a time on one stream, library defaults
+    lat_plan = (L.Plan(P, G, log2n, batch, local_rank, twiddle_matrix_log2_max=args.twf, in_flight=1)
+                if (wl == "ntt22" and (tile_lc >= 0 or mode != "streams")) else plans[0])
     x, y, plan, stream = xs[0], ys[0], plans[0], main_stream.cuda_stream
+    rot = {"R": R_cold, "lat": False}     # what run() cycles over: set before each measurement
     if wl == "mul22":
         b = torch.from_numpy(synth(n // 2, 0x5EED1000 + rank).view(np.int64)).cuda()
         a = x[: n // 2].contiguous()
@@ -403,11 +438,28 @@ def main():
             plan.inverse_dev(y.data_ptr(), y.data_ptr(), stream)
         else:
             k = i % S
-            plans[k].forward_dev(xs[k].data_ptr(), ys[k].data_ptr(), streams[k].cuda_stream)
+            r = (i // S) % rot["R"]
+            plans[k].forward_dev(xpool[k][r].data_ptr(), ypool[k][r].data_ptr(), streams[k].cuda_stream)
 
     def run(count):
-        for i in range(count):
-            step(i)
+        if wl == "ntt22" and rot["lat"]:               # one transform at a time, default plan, one stream
+            for i in range(count):
+                r = i % rot["R"]
+                lat_plan.forward_dev(xpool[0][r].data_ptr(), ypool[0][r].data_ptr(), stream)
+        elif wl == "ntt22" and mode == "many":         # `count` transforms as calls of `group` arrays
+            i = 0
+            while i < count:
+                g_ = min(group, count - i)
+                idx = [(i + j) % rot["R"] for j in range(g_)]
+                plans[0].forward_many_dev([xpool[0][r].data_ptr() for r in idx], [ypool[0][r].data_ptr() for r in idx], stream)
+                i += g_
+        elif wl == "ntt22" and mode == "batch":        # count/group calls of `group` polynomials each
+            for c_ in range(count // group):
+                r = c_ % rot["R"]
+                plans[0].forward_dev(xpool[0][r].data_ptr(), ypool[0][r].data_ptr(), stream)
+        else:
+            for i in range(count):
+                step(i)
 
     # ---- verification (outside every timed region; the oracle is the CHECKER here, never the thing measured): every
     # plan that is timed below transforms one input and is compared with the oracle's restatement of
@@ -420,21 +472,38 @@ def main():
         checked = []
         if wl in ("ntt22", "batch16"):
             xh = to_np(xs[0])
-            rows = sorted({0, batch - 1, batch // 2})
+            rows = sorted({0, pb - 1, pb // 2})
             refs = {r: orc.fft(P, G, xh[r * n:(r + 1) * n]) for r in rows}
             seen = []
             for pl_ in plans + [lat_plan]:
                 if any(pl_ is q for q in seen):
                     continue
+                if pl_.batch != pb:        # the latency plan of the batch mode transforms one polynomial of the buffer
+                    rows_, nb_ = [0], 1
+                else:
+                    rows_, nb_ = rows, pb
                 seen.append(pl_)
                 ys[0].zero_()
                 pl_.forward_dev(xs[0].data_ptr(), ys[0].data_ptr(), stream)
                 torch.cuda.synchronize()
                 yh = to_np(ys[0])
-                for r in rows:
+                for r in rows_:
                     if not np.array_equal(yh[r * n:(r + 1) * n], refs[r]):
                         raise SystemExit("bench.py: plan output differs from the oracle (polynomial %d) -- refusing to time it" % r)
             checked.append("%d timed plan(s) x %d polynomial(s) == oracle.fft" % (len(seen), len(rows)))
+            if wl == "ntt22" and mode == "many":
+                # the timed entry point itself: three arrays in one call (both lanes, the second one twice), all three
+                # outputs against the oracle
+                kk = min(3, R_cold)
+                for r in range(kk):
+                    ypool[0][r].zero_()
+                plans[0].forward_many_dev([xpool[0][r].data_ptr() for r in range(kk)], [ypool[0][r].data_ptr() for r in range(kk)], stream)
+                torch.cuda.synchronize()
+                for r in range(kk):
+                    want = refs[0] if r == 0 else orc.fft(P, G, to_np(xpool[0][r]))
+                    if not np.array_equal(to_np(ypool[0][r]), want):
+                        raise SystemExit("bench.py: ronk_ntt_forward_many_dev array %d differs from the oracle" % r)
+                checked.append("ronk_ntt_forward_many_dev: %d arrays in one call == oracle.fft" % kk)
         elif wl == "mul22":
             step(0); torch.cuda.synchronize()
             ah, bh, oh = to_np(a), to_np(b), to_np(out)
@@ -492,47 +561,73 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    SAMPLES = max(1, args.samples)
+
+    def timed_regions():
+        """SAMPLES regions of exactly K steps; wall seconds per region (max over ranks)"""
+        out_ = []
+        for _ in range(SAMPLES):
+            sync_all()
+            t0_ = time.perf_counter()
+            run(args.steps)
+            sync_all()
+            out_.append(time.perf_counter() - t0_)
+        if world > 1:
+            tt = torch.tensor(out_, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out_ = [float(v) for v in tt.tolist()]
+        return out_
+
+    def device_regions():
+        """the same K steps, SAMPLES back-to-back regions delimited by HIP events on the launch stream (torch's current
+        stream IS the launch stream; the side lanes join it before the event), ONE synchronisation at the end: the
+        device never idles between regions.  Milliseconds per region."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(SAMPLES + 1)]
+        evs[0].record()
+        for i in range(SAMPLES):
+            run(args.steps)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        return [evs[i].elapsed_time(evs[i + 1]) for i in range(SAMPLES)]
+
+    rot["R"], rot["lat"] = R_cold, False
     run(args.warmup)
     torch.cuda.synchronize()
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.05:
         run(max(1, args.steps))
         torch.cuda.synchronize()
-    SAMPLES = max(1, args.samples)
-    dts = []
-    for _ in range(SAMPLES):
-        sync_all()
-        t0 = time.perf_counter()
-        run(args.steps)
-        sync_all()
-        dts.append(time.perf_counter() - t0)
-    if world > 1:
-        tt = torch.tensor(dts, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dts = [float(v) for v in tt.tolist()]
+    dts = timed_regions()                                 # the protocol of `value`: throughput mode, R_cold buffers
     dt = float(np.median(dts))
     dt_min = float(min(dts))
-
-    value = world * args.steps * batch / dt          # whole-job units per second (polynomials, products, ...)
-
-    # Roofline of the dominant kernel: the same K steps again, one at a time on ONE stream with the default plan,
-    # bracketed by HIP events recorded on the launch stream (torch's current stream IS the launch stream here);
-    # median of SAMPLES regions as above.
-    S_saved, S, plan0 = S, 1, plans[0]
-    plans[0] = lat_plan
+    value = world * args.steps * batch / dt               # whole-job units per second (polynomials, products, ...)
+    # same regime on the device clock (events); with several CALLER streams an event on one of them does not bracket the
+    # others' work: the wall time of the region stands in
+    thr_dev_ms = float(np.median(device_regions())) if S == 1 else dt * 1e3
+    warm = None
+    if R_cold > 1:                                        # the same buffers every step (Infinity-Cache resident inputs)
+        rot["R"] = 1
+        run(max(10, args.steps))
+        dts_w = timed_regions()
+        warm = {"value": world * args.steps * batch / float(np.median(dts_w)), "ms_per_step": float(np.median(dts_w)) / args.steps * 1e3,
+                "rotate": 1}
+    # Latency regime: the same K steps one at a time on ONE stream with the default plan (kernel durations add up)
+    S_saved, S = S, 1
+    rot["R"], rot["lat"] = R_cold, wl == "ntt22"
+    if not rot["lat"]:
+        plan0, plans[0] = plans[0], lat_plan
     run(max(10, args.steps))
-    # SAMPLES back-to-back regions delimited by events on the launch stream, ONE synchronisation at the end: the device
-    # never idles between regions (short K would otherwise measure the clock ramp after every host sync)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(SAMPLES + 1)]
-    evs[0].record()
-    for i in range(SAMPLES):
-        run(args.steps)
-        evs[i + 1].record()
-    torch.cuda.synchronize()
-    dev_ms_samples = [evs[i].elapsed_time(evs[i + 1]) for i in range(SAMPLES)]
-    S = S_saved
-    plans[0] = plan0
+    dev_ms_samples = device_regions()
     dev_ms = float(np.median(dev_ms_samples))
+    lat_warm_ms = None
+    if R_cold > 1:
+        rot["R"] = 1
+        run(max(10, args.steps))
+        lat_warm_ms = float(np.median(device_regions()))
+    rot["R"], rot["lat"] = R_cold, False
+    S = S_saved
+    if wl != "ntt22":
+        plans[0] = plan0
 
     # per-kernel device time (hipEvents on the launch stream) for the roofline of the dominant kernel
     pass_ms = None
@@ -540,7 +635,9 @@ def main():
         pass_ms = lat_plan.time_passes(x.data_ptr(), y.data_ptr(), inverse=False, iters=50, stream=stream)
     alg_bytes_step = wl_bytes_per_n * (batch / wl_batch) * n
     step_s = (dev_ms / 1e3) / args.steps                             # device time per step on the launch stream
-    achieved = alg_bytes_step / step_s / 1e9
+    achieved = alg_bytes_step / step_s / 1e9              # latency regime
+    thr_step_s = (thr_dev_ms / 1e3) / args.steps                     # throughput regime (device clock, same regime as value)
+    achieved_thr = alg_bytes_step / thr_step_s / 1e9
     # HBM bytes per launch from the PMC passes of the same command under rocprofv3 (tools/profile.sh ->
     # tools/rocprof_summary.py; FETCH_SIZE x2 gfx950 correction, calibrated on this kernel's known byte count).
     # bench.py cannot read PMCs itself: it reports the committed measurement of the dominant kernel IF that file was
@@ -548,22 +645,26 @@ def main():
     traffic, traffic_note, valu = None, None, None
     pmc, why = load_if_current("profiles/latest_pmc_%s.json" % wl, wl)
     if pmc and log2n == wl_log2n and batch == wl_batch:
-        kern = None
-        for kname, c in pmc.get("counters", {}).items():
-            if "_hbm_bytes_per_launch" in c and (kern is None or c.get("_avg_us", 0) > pmc["counters"][kern].get("_avg_us", 0)):
-                kern = kname
-        if kern:
-            c = pmc["counters"][kern]
-            traffic = c["_hbm_bytes_per_launch"]["total"]
-            traffic_note = ("HBM bytes per launch of %s (rocprofv3 PMC: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
-                            "profiles/%s)" % (kern, pmc.get("source", "latest_pmc_%s.json" % wl)))
+        # every kernel of the step that moved data (the passes of a transform; the two scan kernels of a division): the
+        # step's traffic and VALU count are SUMS over them, each counted once per step
+        kerns = [kname for kname, c in pmc.get("counters", {}).items()
+                 if "_hbm_bytes_per_launch" in c and "copyBuffer" not in kname and "fillBuffer" not in kname]
+        kerns.sort(key=lambda kname: -pmc["counters"][kname].get("_avg_us", 0))
+        if kerns:
+            cs = [pmc["counters"][kname] for kname in kerns]
+            traffic = sum(c["_hbm_bytes_per_launch"]["total"] for c in cs)
+            traffic_note = ("fabric-side bytes per STEP = sum over the %d kernel(s) of a step (%s) of FETCH_SIZE x2 (gfx950 "
+                            "correction) + WRITE_SIZE per launch (rocprofv3 PMC, profiles/%s); these counters include "
+                            "Infinity-Cache hits (MI355X_MICROARCH.md), so this is traffic at the L2's memory side, an upper "
+                            "bound on HBM bytes" % (len(kerns), "; ".join("%s: %.0f" % (k_[:60], c["_hbm_bytes_per_launch"]["total"])
+                                                                         for k_, c in zip(kerns, cs)),
+                                                  pmc.get("source", "latest_pmc_%s.json" % wl)))
             if wl == "ntt22":
-                traffic_note += ("; algorithmic share per launch = %d bytes (8*n: each launch of the two-pass plan reads and "
-                                 "writes the whole vector once, so ~2x is inherent to two passes, anything above is re-reads)" % (8 * n))
-            if "SQ_INSTS_VALU" in c:
-                launches_per_step = plan.num_passes() if wl in ("ntt22", "batch16") else 1
-                valu = {"insts_per_coeff": c["SQ_INSTS_VALU"]["avg"] * 64.0 * launches_per_step / (n * batch),
-                        "source": "SQ_INSTS_VALU x 64 lanes x %d launches / coefficients (PMC, same file)" % launches_per_step}
+                traffic_note += ("; algorithmic bytes per step = %d (16*n); a two-pass plan moves 2x that by construction, "
+                                 "anything above is re-reads / split lines" % (16 * n))
+            if all("SQ_INSTS_VALU" in c for c in cs):
+                valu = {"insts_per_coeff": sum(c["SQ_INSTS_VALU"]["avg"] for c in cs) * 64.0 / (n * batch),
+                        "source": "sum over the step's %d kernel(s) of SQ_INSTS_VALU x 64 lanes / coefficients (PMC, same file)" % len(kerns)}
     else:
         traffic_note = "no current PMC file for this workload/kernel (%s): re-run tools/profile.sh" % why
     # Secondary ceiling: 64-bit modular arithmetic is VALU-issue bound.  Static census of the executed
@@ -581,20 +682,39 @@ def main():
                                  "transform: how close the kernel is to its own arithmetic ceiling"})
         elif valu is None:
             valu = {"note": "census " + why_c}
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+    # `achieved` / `frac` follow `value`: the throughput regime, R_cold buffers, device clock over the timed region.  The
+    # latency regime (one transform at a time: kernel durations add up) and the warm variants are reported beside it.
+    roofline = {"bound": "hbm", "achieved": achieved_thr, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_thr / HBM_PEAK_GBS, "frac_throughput": achieved_thr / HBM_PEAK_GBS,
+                "frac_latency": achieved / HBM_PEAK_GBS,
+                "frac_throughput_warm": (alg_bytes_step * warm["value"] / world / batch / 1e9 / HBM_PEAK_GBS) if warm else None,
+                "frac_latency_warm": (alg_bytes_step / (lat_warm_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS) if lat_warm_ms else None,
+                "rotate": R_cold,
+                "traffic": traffic,
                 "traffic_note": traffic_note,
                 "kernel": wl_kernel or "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n,
                                                                                          plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "device_us_per_step_min": min(dev_ms_samples) * 1e3 / args.steps,
-                "note": "achieved/frac: one transform at a time on ONE stream, default plan (kernel durations), median of %d "
-                        "regions of %d steps; value: %d streams%s" % (SAMPLES, args.steps, S, ", plans tuned for concurrency "
-                                                                     "(tile_log2_columns=2)" if tile_lc >= 0 else ""),
+                "note": "achieved / frac / frac_throughput: the regime of `value` (%s), HIP events on the launch stream over the "
+                        "timed region, inputs and outputs cycling over %d buffer pairs (%d MiB touched between two uses of a "
+                        "buffer); frac_latency: one transform at a time on ONE stream, default plan (kernel durations add up), "
+                        "same rotation; *_warm: the same buffers every step (inputs stay in the 256 MiB Infinity Cache); median of "
+                        "%d regions of %d steps" % (
+                            {"many": "ONE plan handle, in_flight = 2, ronk_ntt_forward_many_dev, %d arrays per call" % group,
+                             "batch": "ONE plan handle of batch %d" % group,
+                             "streams": "%d caller streams, one plan each" % S}[mode] if wl == "ntt22" else "one stream",
+                            R_cold, R_cold * 2 * pb * n * 8 >> 20, SAMPLES, args.steps),
                 "throughput_GBs": alg_bytes_step * args.steps / dt / 1e9,
                 "pass_us": [m * 1e3 for m in pass_ms] if pass_ms else None,
                 "valu": valu}
 
+    # how many ranks really took part (an all-reduce of 1 over the job): the driver can check it against --gpus
+    ranks_seen = 1
+    if world > 1:
+        one_ = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(one_)
+        ranks_seen = int(one_.item())
     if rank == 0:
         res = {"metric": "forward NTTs/s, degree 2^%d, 64-bit Goldilocks prime" % log2n if wl == "ntt22" else wl,
                "value": value, "unit": wl_unit,
@@ -610,6 +730,11 @@ def main():
                           % (log2n, batch) if wl in ("ntt22", "batch16") else wl,
                           "log2n": log2n, "batch": batch, "streams": S, "parallelism": "independent polynomials per GPU (x%d)" % world},
                "roofline": roofline}
+        if warm:
+            res["warm"] = warm
+        res["config"].update({"mode": mode, "group": group, "rotate": R_cold, "plan_handles": len(plans),
+                              "in_flight": plans[0].in_flight() if hasattr(L.lib, "ronk_plan_in_flight") else None})
+        res["ranks_seen"] = ranks_seen
         if not args.no_cpu and world == 1 and wl == "ntt22":       # reported at N = 1 only (bench contract)
             res["cpu_baseline"] = cpu_baseline(log2n)
         if not args.no_cpu and world == 1 and wl in ("batch16", "rs16"):

@@ -23,7 +23,8 @@
  *  - re-entrant: plans are immutable after creation.  A plan owns ONE scratch buffer: calls on one stream are
  *    ordered by the stream, and a `_dev` call that arrives on another stream than the plan's previous call is made
  *    to wait (event) for that call, so concurrent streams never corrupt each other -- they serialise on the plan.
- *    For transforms that should overlap, use one plan per stream.  (While a stream is being captured into a
+ *    For transforms that should overlap, hand the library a batch or several arrays per call (ronk_plan_opts::in_flight,
+ *    ronk_ntt_forward_many_dev) or use one plan per stream.  (While a stream is being captured into a
  *    hipGraph the guard is skipped: a captured graph must own its plan.)
  *  - the 64-bit hot path is the Goldilocks field p = 2^64 - 2^32 + 1 with generator g = 7;
  *    any other odd prime p < 2^64 (e.g. the reference's F_101, F_17, F_127) runs through a
@@ -101,6 +102,25 @@ int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, ui
  * twiddle_matrix_log2_max = largest full inter-pass twiddle matrix (default 18 = L2-resident only). */
 int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                            int tile_log2_columns, int twiddle_matrix_log2_max);
+/* Same through an options block (start from RONK_PLAN_OPTS_DEFAULT, then set what you need; -1 = default everywhere).
+ * in_flight: 1 = every call runs on the caller's stream only; 2 = the library keeps TWO transforms in flight behind
+ * this one handle: a batched call (batch >= 2, multi-pass sizes) runs the second half of the batch on an internal side
+ * stream -- fork / join by events on the caller's stream, so stream order as the caller sees it is unchanged -- and
+ * ronk_ntt_forward_many_dev / _inverse_many_dev spread K independent arrays over the two lanes.  -1 = automatic
+ * (2 for batches of 2^19 .. 2^22-point transforms, else 1).  The reference has no counterpart (its fft() is a
+ * single-threaded recursion, src/polynomial/mod.rs:295-323); this is how a caller with many independent polynomials
+ * (kzg / Reed-Solomon batches) gets the concurrent rate without managing streams and plans itself. */
+typedef struct ronk_plan_opts {
+  int tile_log2_columns;        /* as in ronk_plan_create_tuned */
+  int twiddle_matrix_log2_max;  /* as in ronk_plan_create_tuned */
+  int in_flight;                /* -1 auto, 1, 2 */
+  int reserved[5];              /* zero */
+} ronk_plan_opts;
+#define RONK_PLAN_OPTS_DEFAULT { -1, -1, -1, { 0, 0, 0, 0, 0 } }
+int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
+                          const ronk_plan_opts* opts);
+/* 1 or 2: the lanes the plan actually uses (see ronk_plan_opts::in_flight) */
+int ronk_plan_in_flight(const ronk_plan* plan);
 int ronk_plan_destroy(ronk_plan* plan);
 /* Which kernel family the plan runs on: 1 = the tiled Goldilocks path (p = 2^64 - 2^32 + 1 with the explicit generator 7,
  * 2^4 <= n <= 2^30) -- the tuned one; 0 = the generic radix-2 path (any other odd prime, Goldilocks with another
@@ -116,6 +136,14 @@ int ronk_ntt_inverse(ronk_plan* plan, const uint64_t* in, uint64_t* out);
 /* device-resident forms; in == out is allowed; asynchronous on `stream` */
 int ronk_ntt_forward_dev(ronk_plan* plan, const uint64_t* d_in, uint64_t* d_out, void* stream);
 int ronk_ntt_inverse_dev(ronk_plan* plan, const uint64_t* d_in, uint64_t* d_out, void* stream);
+/* `count` independent arrays of [batch][n] elements each in one call (Polynomial::fft / ifft of `count` unrelated
+ * polynomials, src/polynomial/mod.rs:273-292, :430-453): d_in / d_out are HOST arrays of `count` DEVICE pointers.
+ * With in_flight = 2 the arrays alternate between the caller's stream and the plan's side stream (second scratch);
+ * asynchronous on `stream`, which sees the results of all of them in stream order. */
+int ronk_ntt_forward_many_dev(ronk_plan* plan, const uint64_t* const* d_in, uint64_t* const* d_out, size_t count,
+                              void* stream);
+int ronk_ntt_inverse_many_dev(ronk_plan* plan, const uint64_t* const* d_in, uint64_t* const* d_out, size_t count,
+                              void* stream);
 /* Lagrange::<F>::new's node table [omega^i], i < n (polynomial/mod.rs:358-365) */
 int ronk_lagrange_nodes(uint64_t p, uint64_t g, uint64_t* nodes, size_t n);
 

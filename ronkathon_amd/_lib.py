@@ -66,6 +66,10 @@ _SIG = {
     "ronk_vec_mul_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
     "ronk_plan_create": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int]),
     "ronk_plan_create_tuned": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int, _int, _int]),
+    "ronk_plan_create_opts": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _u64, _int, _vp]),
+    "ronk_plan_in_flight": (_int, [_vp]),
+    "ronk_ntt_forward_many_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _vp]),
+    "ronk_ntt_inverse_many_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _vp]),
     "ronk_plan_destroy": (_int, [_vp]),
     "ronk_plan_path": (_int, [_vp]),
     "ronk_ntt_forward": (_int, [_vp, _vp, _vp, _vp]),
@@ -155,15 +159,39 @@ def out_scalar(fn, *args):
     return o.value
 
 
+class PlanOpts(C.Structure):
+    """ronk_plan_opts (include/ronk_ntt.h)"""
+    _fields_ = [("tile_log2_columns", _int), ("twiddle_matrix_log2_max", _int), ("in_flight", _int), ("reserved", _int * 5)]
+
+    def __init__(self, tile_log2_columns=-1, twiddle_matrix_log2_max=-1, in_flight=-1):
+        super().__init__(tile_log2_columns, twiddle_matrix_log2_max, in_flight)
+
+
 class Plan:
     """RAII wrapper of ronk_plan: (p, g, n = 2^log2n, batch) on one device."""
 
-    def __init__(self, p, g, log2n, batch=1, device=-1, tile_log2_columns=-1, twiddle_matrix_log2_max=-1):
+    def __init__(self, p, g, log2n, batch=1, device=-1, tile_log2_columns=-1, twiddle_matrix_log2_max=-1, in_flight=-1):
         self.h = None
         h = _vp()
-        check(lib.ronk_plan_create_tuned(C.byref(h), p, g, log2n, batch, device, tile_log2_columns,
-                                         twiddle_matrix_log2_max))
+        if in_flight == -1 and not hasattr(lib, "ronk_plan_create_opts"):   # an older build in an A/B run
+            check(lib.ronk_plan_create_tuned(C.byref(h), p, g, log2n, batch, device, tile_log2_columns,
+                                             twiddle_matrix_log2_max))
+        else:
+            opts = PlanOpts(tile_log2_columns, twiddle_matrix_log2_max, in_flight)
+            check(lib.ronk_plan_create_opts(C.byref(h), p, g, log2n, batch, device, C.byref(opts)))
         self.h, self.p, self.g, self.log2n, self.n, self.batch = h, p, g, log2n, 1 << log2n, batch
+
+    def in_flight(self):
+        """lanes the plan keeps in flight (ronk_plan_opts::in_flight resolved): 1 or 2"""
+        return lib.ronk_plan_in_flight(self.h)
+
+    def forward_many_dev(self, d_ins, d_outs, stream=0, inverse=False):
+        """`len(d_ins)` independent [batch][n] device arrays in one call (ronk_ntt_forward_many_dev)"""
+        k = len(d_ins)
+        a = (_vp * k)(*d_ins)
+        b = (_vp * k)(*d_outs)
+        f = lib.ronk_ntt_inverse_many_dev if inverse else lib.ronk_ntt_forward_many_dev
+        check(f(self.h, a, b, k, stream))
 
     def close(self):
         if getattr(self, "h", None):

@@ -18,6 +18,15 @@ extern "C" int ronk_plan_destroy(ronk_plan* pl) {
   if (pl->d_wtab_f) (void)hipFree(pl->d_wtab_f);
   if (pl->d_wtab_i) (void)hipFree(pl->d_wtab_i);
   if (pl->scratch_ev) (void)hipEventDestroy(pl->scratch_ev);
+  if (pl->d_tmp2) (void)hipFree(pl->d_tmp2);
+  if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+  if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+  if (pl->side) (void)hipStreamDestroy(pl->side);
+  for (auto e : pl->st_ev) (void)hipEventDestroy(e);
+  if (pl->st_h2d) (void)hipStreamDestroy(pl->st_h2d);
+  if (pl->st_d2h) (void)hipStreamDestroy(pl->st_d2h);
+  if (pl->st_exec) (void)hipStreamDestroy(pl->st_exec);
+  if (pl->h_pin) (void)hipHostFree(pl->h_pin);
   delete pl;
   return RONK_OK;
 }
@@ -30,7 +39,23 @@ extern "C" int ronk_plan_path(const ronk_plan* pl) { return pl ? (pl->fast ? 1 :
 
 extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                                       int tile_log2_columns, int twiddle_matrix_log2_max) {
+  ronk_plan_opts o;
+  memset(&o, 0, sizeof o);
+  o.tile_log2_columns = tile_log2_columns;
+  o.twiddle_matrix_log2_max = twiddle_matrix_log2_max;
+  o.in_flight = -1;
+  return ronk_plan_create_opts(out, p, g, log2n, batch, device, &o);
+}
+
+extern "C" int ronk_plan_in_flight(const ronk_plan* pl) { return pl ? pl->in_flight : RONK_ERR_INVALID; }
+
+extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
+                                     const ronk_plan_opts* opts) {
+  const int tile_log2_columns = opts ? opts->tile_log2_columns : -1;
+  const int twiddle_matrix_log2_max = opts ? opts->twiddle_matrix_log2_max : -1;
+  int in_flight = opts ? opts->in_flight : -1;
   if (!out || batch == 0 || log2n > 36) return RONK_ERR_INVALID;
+  if (in_flight < -1 || in_flight == 0 || in_flight > 2) return RONK_ERR_INVALID;
   *out = nullptr;
   RCHK(ronk_check_prime(p));                                   // PrimeField::new -> is_prime
   if (p < 2) return RONK_ERR_INVALID;
@@ -58,6 +83,16 @@ extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, u
     // 0.429 per 2^26 coefficients against C = 16.
     int max_logc = log2n <= 12 ? 0 : 4;
     bool auto_tiles = true;   // per-pass tile preferences of plan.h apply unless a width was asked for
+    // Two halves of the batch in flight on two streams (in_flight = 2; auto = for batches of two-pass transforms of
+    // 2^19 .. 2^22 points): both passes get 4-column tiles -- two workgroups per CU -- unless a width was asked for, the
+    // configuration in which two independent kernels overlap.  RONK_IN_FLIGHT=1 / 2 overrides auto.
+    if (in_flight < 0) {
+      in_flight = (batch >= 2 && log2n >= 19 && log2n <= 22) ? 2 : 1;
+      if (const char* e = getenv("RONK_IN_FLIGHT")) { int v = atoi(e); if (v == 1 || v == 2) in_flight = v; }
+    }
+    if (in_flight == 2 && log2n >= 19 && log2n <= 22 && tile_log2_columns < 0 && !getenv("RONK_MAX_LOGC")) {
+      max_logc = 2; auto_tiles = false;
+    }
     if (const char* e = getenv("RONK_MAX_LOGC")) { int v = atoi(e); if (v >= 0 && v <= 8) { max_logc = v; auto_tiles = false; } }
     if (tile_log2_columns >= 0 && tile_log2_columns <= 8) { max_logc = tile_log2_columns; auto_tiles = false; }
     if (getenv("RONK_WG_FLOOR_LOG")) auto_tiles = false;
@@ -99,6 +134,14 @@ extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, u
     hipError_t e = hipMalloc((void**)&pl->d_tmp, n * batch * 8);
     if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(scratch)");
   }
+  // the side lane exists for multi-pass tile plans only (single-pass plans have nothing to overlap with themselves)
+  if (!rc && in_flight == 2 && pl->fast && pl->fwd.pd.passes.size() >= 2) {
+    hipError_t e = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) rc = hip_fail(e, "side stream");
+    else pl->in_flight = 2;
+  }
   if (rc) { ronk_plan_destroy(pl); return rc; }
   *out = pl;
   return RONK_OK;
@@ -129,36 +172,116 @@ static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* ou
   return RONK_OK;
 }
 
+// order `s` behind the previous user of the plan's scratch (see ronk_plan::scratch_ev); caller holds stream_mu
+static void scratch_acquire(ronk_plan* pl, hipStream_t s) {
+  if (!pl->scratch_used || pl->scratch_stream == s) return;
+  // first time the plan is seen on a second stream: nothing was recorded behind the previous call (single-stream users
+  // never pay for an event) -- drain the device once, from now on every call leaves an event behind
+  if (!pl->scratch_multi || !pl->scratch_ev_valid || hipStreamWaitEvent(s, pl->scratch_ev, 0) != hipSuccess)
+    (void)hipDeviceSynchronize();
+  pl->scratch_multi = true;
+}
+static void scratch_release(ronk_plan* pl, hipStream_t s) {
+  pl->scratch_stream = s; pl->scratch_used = true;
+  if (!pl->scratch_multi) return;
+  hipError_t e = hipSuccess;
+  if (!pl->scratch_ev) e = hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(pl->scratch_ev, s);
+  pl->scratch_ev_valid = e == hipSuccess;
+  if (e != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }   // nothing left in flight to guard against
+}
+
 int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s, u64 in_valid,
-                  u64 out_valid) {
+                  u64 out_valid, u64 in_poly_stride, u64 in_valid1, u64* tmp_override) {
   if (!pl || !in || !out) return RONK_ERR_INVALID;
-  // The plan's scratch buffer is shared by every call on the plan.  Calls on ONE stream are ordered by the stream; when a
-  // call arrives on a different stream than the previous one, it is made to wait for that stream's tail (an event recorded
-  // there now, i.e. after the previous transform), so two streams can never interleave inside the scratch.  Costs
-  // nothing while a plan stays on one stream (the benchmarked pattern: one plan per stream).
-  if (pl->d_tmp && (pl->fast ? (inverse ? pl->inv : pl->fwd).pd.needs_tmp : true)) {
-    std::lock_guard<std::mutex> lk(pl->stream_mu);
+  // The plan's scratch buffer is shared by every call on the plan.  Calls on ONE stream are ordered by the stream; a call
+  // that arrives on a different stream than the previous one waits for the event that call left behind (scratch_acquire),
+  // so two streams can never interleave inside the scratch.  The lock is held across the enqueue: two host threads
+  // cannot interleave their launches either.  Costs nothing while a plan stays on one stream.
+  // (a capturing stream cannot wait for an event recorded outside its capture: a captured graph owns its plan)
+  const CompiledPlan* cp = pl->fast ? &(inverse ? pl->inv : pl->fwd) : nullptr;
+  u64* const tmp = tmp_override ? tmp_override : pl->d_tmp;
+  const bool uses_tmp = tmp && (cp ? cp->pd.needs_tmp : true);
+  std::unique_lock<std::mutex> lk(pl->stream_mu, std::defer_lock);
+  bool guard = false;
+  if (uses_tmp && !tmp_override) {
+    lk.lock();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (pl->scratch_used && pl->scratch_stream != s) (void)hipStreamIsCapturing(s, &cap);
-    // (a capturing stream cannot wait for an event recorded outside its capture: a captured graph owns its plan)
-    if (pl->scratch_used && pl->scratch_stream != s && cap == hipStreamCaptureStatusNone) {
-      if (!pl->scratch_ev) HIPCHK(hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(pl->scratch_ev, pl->scratch_stream));
-      HIPCHK(hipStreamWaitEvent(s, pl->scratch_ev, 0));
-    }
-    pl->scratch_stream = s; pl->scratch_used = true;
+    (void)hipStreamIsCapturing(s, &cap);
+    guard = cap == hipStreamCaptureStatusNone;
+    if (guard) scratch_acquire(pl, s);
   }
-  if (pl->fast) {
+  int rc;
+  if (cp) {
     // in == out is safe: a single-pass plan rewrites exactly the tile it read; multi-pass plans
     // read BUF_IN only in pass 1 and write BUF_OUT only in the last pass.
-    return (inverse ? pl->inv : pl->fwd).run(in, in2, out, pl->d_tmp, s, in_valid, out_valid);
+    if (pl->in_flight == 2 && cp->sliceable() && !tmp_override) {
+      // two halves of the batch, the second on the side stream: fork after everything already queued on `s`, join before
+      // anything queued later (stream order as seen by the caller is unchanged)
+      const u32 h = (u32)((pl->batch + 1) / 2), h2 = (u32)(pl->batch - h);
+      hipError_t e = hipEventRecord(pl->ev_fork, s);
+      if (e == hipSuccess) e = hipStreamWaitEvent(pl->side, pl->ev_fork, 0);
+      if (e != hipSuccess) return hip_fail(e, "fork");
+      rc = cp->run_slice(h, h2, in, in2, out, tmp, pl->side, in_valid, out_valid, in_poly_stride, in_valid1);
+      if (!rc) rc = cp->run_slice(0, h, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, in_valid1);
+      e = hipEventRecord(pl->ev_join, pl->side);
+      if (e == hipSuccess) e = hipStreamWaitEvent(s, pl->ev_join, 0);
+      if (e != hipSuccess) { (void)hipDeviceSynchronize(); if (!rc) rc = hip_fail(e, "join"); }
+    } else {
+      rc = cp->run(in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, 0, in_valid1);
+    }
+  } else if (in2 || in_valid != ~(u64)0 || out_valid != ~(u64)0 || in_poly_stride) {
+    rc = RONK_ERR_UNSUPPORTED;
+  } else if (pl->log2n == 0) {  // n = 1: fft/ifft are the identity (the recursion returns at n <= 1)
+    rc = RONK_OK;
+    if (in != out) {
+      hipError_t e = hipMemcpyAsync(out, in, pl->batch * 8, hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync");
+    }
+  } else {
+    rc = generic_transform(pl, inverse, in, out, s);
   }
-  if (in2 || in_valid != ~(u64)0 || out_valid != ~(u64)0) return RONK_ERR_UNSUPPORTED;
-  if (pl->log2n == 0) {  // n = 1: fft/ifft are the identity (the recursion returns at n <= 1)
-    if (in != out) HIPCHK(hipMemcpyAsync(out, in, pl->batch * 8, hipMemcpyDeviceToDevice, s));
+  if (guard) scratch_release(pl, s);
+  return rc;
+}
+
+// K independent [batch][n] arrays in ONE call (a batch-1 plan: K polynomials that live in unrelated buffers): with
+// in_flight = 2 the arrays go round-robin over the caller's stream and the plan's side stream (which has its own scratch),
+// each lane running its transforms back to back; fork / join on `stream` as above.
+static int many_dev(ronk_plan* pl, bool inverse, const uint64_t* const* d_in, uint64_t* const* d_out, size_t count, hipStream_t s) {
+  if (!pl || !d_in || !d_out) return RONK_ERR_INVALID;
+  if (count == 0) return RONK_OK;
+  for (size_t i = 0; i < count; i++) if (!d_in[i] || !d_out[i]) return RONK_ERR_INVALID;
+  const CompiledPlan* cp = pl->fast ? &(inverse ? pl->inv : pl->fwd) : nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (pl->in_flight != 2 || !cp || count < 2 || cap != hipStreamCaptureStatusNone) {
+    for (size_t i = 0; i < count; i++) RCHK(transform_dev(pl, inverse, d_in[i], nullptr, d_out[i], s));
     return RONK_OK;
   }
-  return generic_transform(pl, inverse, in, out, s);
+  std::lock_guard<std::mutex> lk(pl->stream_mu);
+  if (!pl->d_tmp2) HIPCHK(hipMalloc((void**)&pl->d_tmp2, pl->n * pl->batch * 8));
+  scratch_acquire(pl, s);
+  HIPCHK(hipEventRecord(pl->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
+  int rc = RONK_OK;
+  for (size_t i = 0; i < count && !rc; i++) {
+    const bool lane1 = (i & 1) != 0;
+    rc = cp->run(d_in[i], nullptr, d_out[i], lane1 ? pl->d_tmp2 : pl->d_tmp, lane1 ? pl->side : s);
+  }
+  hipError_t e = hipEventRecord(pl->ev_join, pl->side);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, pl->ev_join, 0);
+  if (e != hipSuccess) { (void)hipDeviceSynchronize(); if (!rc) rc = hip_fail(e, "join"); }
+  scratch_release(pl, s);
+  return rc;
+}
+extern "C" int ronk_ntt_forward_many_dev(ronk_plan* pl, const uint64_t* const* d_in, uint64_t* const* d_out, size_t count,
+                                         void* st) {
+  return many_dev(pl, false, d_in, d_out, count, (hipStream_t)st);
+}
+extern "C" int ronk_ntt_inverse_many_dev(ronk_plan* pl, const uint64_t* const* d_in, uint64_t* const* d_out, size_t count,
+                                         void* st) {
+  return many_dev(pl, true, d_in, d_out, count, (hipStream_t)st);
 }
 // Batched Message::encode::<N> on device (codes/reed_solomon.rs:42-52): the y-coordinates of `batch` codewords,
 // ys[b][i] = message_b(omega_N^i), from compact messages msgs[b][0..k).  Multi-pass Goldilocks plans read the
@@ -168,7 +291,7 @@ extern "C" int ronk_rs_encode_batch_dev(ronk_plan* pl, const uint64_t* d_msgs, s
   if (k > pl->n) return RONK_ERR_INDEX;   // assert_ge::<N, K>()
   hipStream_t s = (hipStream_t)st;
   if (pl->fast && pl->fwd.pd.passes.size() > 1)
-    return pl->fwd.run(d_msgs, nullptr, d_ys, pl->d_tmp, s, (u64)k, ~(u64)0, (u64)k);
+    return transform_dev(pl, false, d_msgs, nullptr, d_ys, s, (u64)k, ~(u64)0, (u64)k);
   const size_t total = pl->n * pl->batch;
   hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_msgs, k, d_ys, (size_t)pl->n, total);
   HIPCHK(hipGetLastError());
@@ -491,12 +614,13 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     // zero-padding limit): 512 instead of 2 x 256 tiles per pass at 2^22, so the load / store phases of one operand's
     // tiles run under the arithmetic of the other's -- what two streams do for independent transforms.
     // (from 2^20 on with 4-column tiles, two workgroups per CU: the configuration that lets two transforms overlap)
+    // (2^19 .. 2^22: that plan runs its two polynomials on two streams, ronk_plan::in_flight)
     if (!e->pl2) RCHK(k >= 20 ? ronk_plan_create_tuned(&e->pl2, p, g, (u32)k, 2, pl->device, 2, -1)
                               : ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
     if (!e->fab) HIPCHK(hipMalloc((void**)&e->fab, 2 * N * 8));
     HIPCHK(hipStreamWaitEvent(s, e->done, 0));
     const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
-    RCHK(e->pl2->fwd.run(d_a, nullptr, e->fab, e->pl2->d_tmp, s, (u64)d, ~(u64)0, stride, 0, (u64)d2));
+    RCHK(transform_dev(e->pl2, false, d_a, nullptr, e->fab, s, (u64)d, ~(u64)0, stride, (u64)d2));
     RCHK(transform_dev(pl, true, e->fab, e->fab + N, d_out, s, ~(u64)0, (u64)m));
     HIPCHK(hipEventRecord(e->done, s));
     return RONK_OK;

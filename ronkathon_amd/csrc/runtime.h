@@ -156,6 +156,8 @@ struct CompiledPlan {
       a.out += (i64)sb0 * a.out_sb1;
       grid = ps.grid / a.nb1 * sbn;
       a.nb1 = sbn;
+      // a slice that starts past polynomial 0 sees its first polynomial as b1 = 0: its padding limit is the one of b1 >= 1
+      if (sb0 >= 1 && ps.in_buf == BUF_IN && in_valid1 != ~(u64)0) a.in_valid = in_valid1;
     }
     hipError_t e = ps.small ? launch_small(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s)
                             : launch_tile(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s);
@@ -188,6 +190,18 @@ struct CompiledPlan {
       RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, 0, 0, in_valid1));
     return RONK_OK;
   }
+  // every pass of the plan for polynomials [sb0, sb0 + sbn) of the batch only (multi-pass plans whose batch axis is b1)
+  int run_slice(u32 sb0, u32 sbn, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
+                u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 in_valid1 = ~(u64)0) const {
+    for (size_t i = 0; i < pd.passes.size(); i++)
+      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, 0, sb0, sbn, in_valid1));
+    return RONK_OK;
+  }
+  bool sliceable() const {   // the batch is axis b1 of every pass (two- and three-pass plans)
+    if (pd.passes.size() < 2 || pd.batch < 2) return false;
+    for (auto& ps : pd.passes) if (ps.args.nb1 != pd.batch) return false;
+    return true;
+  }
 };
 
 struct ronk_plan {
@@ -205,13 +219,31 @@ struct ronk_plan {
   u64* d_wtab_f = nullptr; u64* d_wtab_i = nullptr;
   u64 w_f = 0, w_i = 0, n_inv = 1;
   std::mutex mu;
-  // cross-stream guard of d_tmp (transform_dev)
+  // cross-stream guard of d_tmp (transform_dev): once a plan has been seen on more than one stream, every transform
+  // that touches the scratch records `scratch_ev` at its END on its own stream, and a call arriving on another stream
+  // waits for that already-recorded event -- the previous stream's handle is never used again (it may be gone)
   std::mutex stream_mu;
-  hipStream_t scratch_stream = nullptr;
+  hipStream_t scratch_stream = nullptr;   // identity of the last user, compared only
   hipEvent_t scratch_ev = nullptr;
-  bool scratch_used = false;
+  bool scratch_used = false, scratch_multi = false, scratch_ev_valid = false;
+  // Library-side concurrency (ronk_plan_opts::in_flight = 2): a batched call is split in two halves of the batch axis,
+  // the second half on an internal side stream (event fork / join on the caller's stream), so that the load / store
+  // phases of one half's workgroups run under the arithmetic of the other's -- what two caller streams with two plans
+  // do, behind ONE plan handle.  The halves use disjoint slices of d_tmp.  `d_tmp2`: a second scratch for
+  // ronk_ntt_forward_many_dev (independent [batch][n] arrays round-robin over the two lanes).
+  int in_flight = 1;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  u64* d_tmp2 = nullptr;
+  // pinned staging ring of the host-pointer entry points (ronk_plan.hip transform_host)
+  void* h_pin = nullptr;
+  size_t h_pin_bytes = 0;
+  hipStream_t st_h2d = nullptr, st_d2h = nullptr, st_exec = nullptr;
+  std::vector<hipEvent_t> st_ev;
 };
 
 // ronk_plan.hip
+// in_poly_stride / in_valid1: see CompiledPlan::launch; tmp_override: a caller-owned scratch (the caller orders its uses)
 int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s,
-                  u64 in_valid = ~(u64)0, u64 out_valid = ~(u64)0);
+                  u64 in_valid = ~(u64)0, u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 in_valid1 = ~(u64)0,
+                  u64* tmp_override = nullptr);
