@@ -106,8 +106,9 @@ int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log
  * in_flight: 1 = every call runs on the caller's stream only; 2 = the library keeps TWO transforms in flight behind
  * this one handle: a batched call (batch >= 2, multi-pass sizes) runs the second half of the batch on an internal side
  * stream -- fork / join by events on the caller's stream, so stream order as the caller sees it is unchanged -- and
- * ronk_ntt_forward_many_dev / _inverse_many_dev spread K independent arrays over the two lanes.  -1 = automatic
- * (2 for batches of 2^19 .. 2^22-point transforms, else 1).  The reference has no counterpart (its fft() is a
+ * ronk_ntt_forward_many_dev / _inverse_many_dev spread K independent arrays over the two lanes.  -1 = automatic = 1
+ * (measured: the lanes pay for independent arrays, not for the halves of one batched launch).
+ * The reference has no counterpart (its fft() is a
  * single-threaded recursion, src/polynomial/mod.rs:295-323); this is how a caller with many independent polynomials
  * (kzg / Reed-Solomon batches) gets the concurrent rate without managing streams and plans itself. */
 typedef struct ronk_plan_opts {

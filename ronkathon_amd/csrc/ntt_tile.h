@@ -251,19 +251,27 @@ RONK_HD void st_g(u64* base, u32 off, u64 v) {
 // ABL: ablation mask for tools/ubench only (wrong results by design; 0 in the product):
 //   1 no inter-pass twiddle   2 no round twiddles   4 no butterflies   8 no LDS exchange
 //   16 no global loads        32 no global stores        64 twiddle values without table loads
-template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
-RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
-  constexpr int R = 1 << LOGR;
-  constexpr int Q = (LOGR + 3) / 4;              // rounds
-  constexpr int LOGLAST = LOGR - 4 * (Q - 1);    // 1..4
-  constexpr int RLAST = 1 << LOGLAST;
-  constexpr int M = R / 16;                      // threads per column
+// What a tile's lanes know about themselves: the launch arguments with everything the instantiation knows folded in,
+// the lane's coordinates and the wave-uniform bases.  Built by tile_ctx() for a (work-item, block) pair; the load
+// half (tile_load) and the arithmetic / store half (tile_compute) of a tile both start from it, so that a persistent
+// kernel can issue the loads of its NEXT tile before it computes the current one (tile_kernel_def.h, *_pipe).
+struct TileCtx {
+  TileArgs a;
+  u32 logc, C, c, m, t, b1, b2, col0, col;
+  const u64* in;
+  u64* out;
+  u32 in_sj, out_sk, in_lane, out_lane;
+  bool live;
+};
+
+template <int LOGR, class CFG>
+RONK_HD TileCtx tile_ctx(const TileArgs& a_in, u32 tid, u32 bid) {
   constexpr int KIND = CFG::KIND;
   constexpr bool NARROW = KIND != 0;
   constexpr int SH = NARROW ? 3 : 0;             // lane offsets in bytes (NARROW) or elements
-  static_assert(LOGR >= 4 && LOGR <= 12, "pass size");
-
-  TileArgs a = a_in;                             // what the instantiation knows replaces what the launch says
+  TileCtx x;
+  TileArgs& a = x.a;
+  a = a_in;                                      // what the instantiation knows replaces what the launch says
   if constexpr (CFG::LOGC >= 0) a.logc = CFG::LOGC;
   if constexpr (KIND != 0) {
     a.stage_io = 0; a.in2 = nullptr; a.in_valid = a.out_valid = a.in_valid1 = ~(u64)0; a.scale = 1;
@@ -276,38 +284,47 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
   if constexpr (KIND == 3) { a.tf_sc = 1; a.tf_sb2 = 0; a.tf_sk = (u32)a.ncols; }
   if constexpr (KIND == 2) { a.in_sj = 1; a.tw_log = 0; }
 
-  const u32 logc = a.logc;
-  const u32 C = 1u << logc;
-  const u32 c = tid & (C - 1);
-  const u32 m = tid >> logc;  // [0, M)
+  x.logc = a.logc;
+  x.C = 1u << x.logc;
+  x.c = tid & (x.C - 1);
+  x.m = tid >> x.logc;  // [0, M)
 
   // block -> (tile, b1, b2).  Everything that depends only on the block is wave-uniform (SGPRs);
   // per-lane addressing is a 32-bit offset from that base (a sub-problem has < 2^32 elements; NARROW: bytes).
-  const u32 t = bid % a.tiles;
+  x.t = bid % a.tiles;
   const u32 bb = bid / a.tiles;
-  const u32 b1 = bb % a.nb1, b2 = bb / a.nb1;
-  const u32 col0 = t << logc;
-  const u32 col = col0 + c;
-  const u64* in = a.in + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st;
-  u64* out = a.out + (i64)b1 * a.out_sb1 + (i64)b2 * a.out_sb2 + (i64)t * a.out_st;
-  const u32 in_sj = (u32)a.in_sj << SH, out_sk = (u32)a.out_sk << SH;
-  const u32 in_lane = c * ((u32)a.in_sc << SH), out_lane = c * ((u32)a.out_sc << SH);
+  x.b1 = bb % a.nb1; x.b2 = bb / a.nb1;
+  x.col0 = x.t << x.logc;
+  x.col = x.col0 + x.c;
+  x.in = a.in + (i64)x.b1 * a.in_sb1 + (i64)x.b2 * a.in_sb2 + (i64)x.t * a.in_st;
+  x.out = a.out + (i64)x.b1 * a.out_sb1 + (i64)x.b2 * a.out_sb2 + (i64)x.t * a.out_st;
+  x.in_sj = (u32)a.in_sj << SH; x.out_sk = (u32)a.out_sk << SH;
+  x.in_lane = x.c * ((u32)a.in_sc << SH); x.out_lane = x.c * ((u32)a.out_sc << SH);
+  x.live = KIND != 0 ? true : x.col < a.ncols;  // ragged last tile: dead columns compute on zeros
+  return x;
+}
 
-  const bool live = KIND != 0 ? true : col < a.ncols;  // ragged last tile: dead columns compute on zeros
+// ---- the tile body --------------------------------------------------------------------
+//
+// LOGR = 4*(Q-1) + LOGLAST, Q rounds; radices 16,..,16,2^LOGLAST.
+// ABL: ablation mask for tools/ubench only (wrong results by design; 0 in the product):
+//   1 no inter-pass twiddle   2 no round twiddles   4 no butterflies   8 no LDS exchange
+//   16 no global loads        32 no global stores        64 twiddle values without table loads
 
-  u64 x[16];
-
-  // LDS-staged round twiddles: table behind the image; filled now (its loads are in flight together with the tile's),
-  // visible after the barrier that follows the first register round
-  constexpr bool LDSTW = CFG::LDSTW && Q > 1;
-  constexpr bool HALF = CFG::HALF && Q > 1;      // two-phase 32-bit exchanges (TileCfg); never with staged I/O or LDSTW
-  static_assert(!(HALF && LDSTW), "HALF and LDSTW exclude each other");
-  u32* const l32 = reinterpret_cast<u32*>(lds);  // the image as 4-byte cells (HALF)
-  const u32 IMG = (u32)(R + R / 16) << logc;               // elements of the tile image
-  if constexpr (LDSTW) {
-    const u32 Tn = (u32)(R / 16) << logc;
-    for (u32 e = tid; e < (u32)R; e += Tn) lds[IMG + e] = a.wr[e];
-  }
+// first half: the 16 coefficients of this lane, rows j = i*M + m, straight from HBM (or through the staged image)
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+RONK_HD void tile_load(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barrier&& barrier) {
+  constexpr int R = 1 << LOGR;
+  constexpr int M = R / 16;                      // threads per column
+  constexpr int KIND = CFG::KIND;
+  constexpr bool NARROW = KIND != 0;
+  const TileArgs& a = cx.a;
+  const u32 logc = cx.logc, c = cx.c, m = cx.m, t = cx.t, b1 = cx.b1, b2 = cx.b2;
+  const u64* in = cx.in;
+  const u32 in_sj = cx.in_sj, in_lane = cx.in_lane;
+  const bool live = cx.live;
+  constexpr int SH = NARROW ? 3 : 0;
+  (void)c; (void)tid; (void)lds;
 
   // ---- round 1: j = j1*M + m, straight from HBM
   u32 joff[16];
@@ -332,7 +349,7 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
     for (int i = 0; i < 16; i++) joff[i] = j0 + i * step;
   }
   const u32 T = (u32)(R / 16) << logc;                     // work-items of the tile
-  const u64 tile_cols = a.ncols - col0 < (u64)C ? a.ncols - col0 : (u64)C;
+  const u64 tile_cols = a.ncols - cx.col0 < (u64)cx.C ? a.ncols - cx.col0 : (u64)cx.C;
   const u32 stage_valid = (u32)tile_cols * (u32)R;         // elements of the tile that exist (ragged last tile)
   if (a.stage_io && !(ABL & 16)) {
 #pragma unroll
@@ -367,6 +384,43 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], ld_g<NARROW>(in2, joff[i]));
   }
+}
+
+// second half: the register rounds, the LDS exchanges between them, the output twiddle and the stores
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barrier&& barrier) {
+  constexpr int R = 1 << LOGR;
+  constexpr int Q = (LOGR + 3) / 4;              // rounds
+  constexpr int LOGLAST = LOGR - 4 * (Q - 1);    // 1..4
+  constexpr int RLAST = 1 << LOGLAST;
+  constexpr int M = R / 16;                      // threads per column
+  constexpr int KIND = CFG::KIND;
+  constexpr bool NARROW = KIND != 0;
+  constexpr int SH = NARROW ? 3 : 0;             // lane offsets in bytes (NARROW) or elements
+  static_assert(LOGR >= 4 && LOGR <= 12, "pass size");
+  const TileArgs& a = cx.a;
+  const u32 logc = cx.logc, C = cx.C, c = cx.c, m = cx.m, t = cx.t, b1 = cx.b1, b2 = cx.b2, col0 = cx.col0, col = cx.col;
+  u64* out = cx.out;
+  const u32 out_sk = cx.out_sk, out_lane = cx.out_lane;
+  const bool live = cx.live;
+  (void)C; (void)col0; (void)SH;
+
+  // LDS-staged round twiddles: table behind the image; filled now (its loads are in flight together with the tile's),
+  // visible after the barrier that follows the first register round
+  constexpr bool LDSTW = CFG::LDSTW && Q > 1;
+  constexpr bool HALF = CFG::HALF && Q > 1;      // two-phase 32-bit exchanges (TileCfg); never with staged I/O or LDSTW
+  static_assert(!(HALF && LDSTW), "HALF and LDSTW exclude each other");
+  u32* const l32 = reinterpret_cast<u32*>(lds);  // the image as 4-byte cells (HALF)
+  const u32 IMG = (u32)(R + R / 16) << logc;               // elements of the tile image
+  if constexpr (LDSTW) {
+    const u32 Tn = (u32)(R / 16) << logc;
+    for (u32 e = tid; e < (u32)R; e += Tn) lds[IMG + e] = a.wr[e];
+  }
+  const u32 T = (u32)(R / 16) << logc;                     // work-items of the tile
+  const u64 tile_cols = a.ncols - col0 < (u64)C ? a.ncols - col0 : (u64)C;
+  const u32 stage_valid = (u32)tile_cols * (u32)R;         // elements of the tile that exist (ragged last tile)
+  (void)T; (void)stage_valid;
+
   // rounds that are followed by a table twiddle on every output but X[0] take the lazy last stage
   if (!(ABL & 4)) { if (Q > 1) Dif<16, INV, true>::run(x); else Dif<16, INV>::run(x); }
 
@@ -595,6 +649,15 @@ RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier
     }
   }
   if ((ABL & 32) && keep == 0x123456789ull) outp[0] = keep;  // keeps x live, never true in practice
+}
+
+// one tile, start to finish
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
+  const TileCtx cx = tile_ctx<LOGR, CFG>(a_in, tid, bid);
+  u64 x[16];
+  tile_load<LOGR, INV, ABL, CFG>(cx, lds, tid, x, barrier);
+  tile_compute<LOGR, INV, ABL, CFG>(cx, lds, tid, x, barrier);
 }
 
 }  // namespace ronk

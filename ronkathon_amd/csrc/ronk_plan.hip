@@ -83,11 +83,14 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // 0.429 per 2^26 coefficients against C = 16.
     int max_logc = log2n <= 12 ? 0 : 4;
     bool auto_tiles = true;   // per-pass tile preferences of plan.h apply unless a width was asked for
-    // Two halves of the batch in flight on two streams (in_flight = 2; auto = for batches of two-pass transforms of
-    // 2^19 .. 2^22 points): both passes get 4-column tiles -- two workgroups per CU -- unless a width was asked for, the
-    // configuration in which two independent kernels overlap.  RONK_IN_FLIGHT=1 / 2 overrides auto.
+    // Two lanes (in_flight = 2): a second stream with its own scratch for ronk_ntt_forward_many_dev, and the second half of
+    // a batched call on it.  At 2^19 .. 2^22 both passes then get 4-column tiles -- two workgroups per CU -- unless a width
+    // was asked for: the configuration in which two independent kernels overlap.  Automatic = 1: measured
+    // (round 3, HBM-cold) the lanes pay for independent arrays (many_dev: 17.6 k -> 22.9 k NTT/s at 2^22) but not for the
+    // halves of ONE batched launch pair, whose workgroups drift apart by themselves (2^22 x 16: 20.9 k without, 20.1 k
+    // with; multiply 2^22: 157 vs 169 us).  RONK_IN_FLIGHT=1 / 2 overrides automatic.
     if (in_flight < 0) {
-      in_flight = (batch >= 2 && log2n >= 19 && log2n <= 22) ? 2 : 1;
+      in_flight = 1;
       if (const char* e = getenv("RONK_IN_FLIGHT")) { int v = atoi(e); if (v == 1 || v == 2) in_flight = v; }
     }
     if (in_flight == 2 && log2n >= 19 && log2n <= 22 && tile_log2_columns < 0 && !getenv("RONK_MAX_LOGC")) {

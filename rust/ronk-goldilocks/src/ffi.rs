@@ -1,17 +1,47 @@
-//! `extern "C"` block for include/ronk_ntt.h (the subset the shim calls) and the code -> panic mapping.
+//! `extern "C"` block for include/ronk_ntt.h (every entry point the shim calls) and the code -> panic mapping.
 //!
 //! Every function returns 0 or a negative `RONK_ERR_*`; the reference reports the same conditions by panicking, so
 //! [`check`] panics with `ronk_strerror(code)`, which repeats the reference's panic texts ("n must divide p^q - 1",
 //! `called Option::unwrap() on a None value`, ...): `#[should_panic]` tests such as
 //! ronkathon `src/polynomial/tests.rs:46-55` and `src/algebra/field/prime/mod.rs:386-391` keep passing.
-use core::ffi::{c_char, c_int};
+//!
+//! tests/test_cpp_host_mirror.py (engine repository) checks every declaration below against the header: same symbol,
+//! same number of parameters, same parameter TYPES (u64 = uint64_t, usize = size_t, c_int = int, ...).
+use core::ffi::{c_char, c_int, c_void};
 
 pub const P: u64 = 0xFFFF_FFFF_0000_0001;
 pub const G: u64 = 7;
 
+/// `ronk_plan` (opaque)
+#[repr(C)]
+pub struct RonkPlan {
+  _private: [u8; 0],
+}
+/// `ronk_sharded_plan` (opaque)
+#[repr(C)]
+pub struct RonkShardedPlan {
+  _private: [u8; 0],
+}
+/// `ronk_plan_opts`: -1 = library default for every field
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct RonkPlanOpts {
+  pub tile_log2_columns:       c_int,
+  pub twiddle_matrix_log2_max: c_int,
+  /// 1 = caller's stream only, 2 = two transforms in flight behind one handle, -1 = automatic
+  pub in_flight:               c_int,
+  pub reserved:                [c_int; 5],
+}
+impl Default for RonkPlanOpts {
+  fn default() -> Self { Self { tile_log2_columns: -1, twiddle_matrix_log2_max: -1, in_flight: -1, reserved: [0; 5] } }
+}
+
 extern "C" {
   pub fn ronk_strerror(code: c_int) -> *const c_char;
   pub fn ronk_last_hip_error() -> *const c_char;
+  pub fn ronk_device_count(count: *mut c_int) -> c_int;
+
+  // ---- host-pointer one-shot forms (what `Polynomial<_, Goldilocks, D>` with its inline `[F; D]` calls)
   /// `Polynomial::<Monomial,F,D>::fft` (src/polynomial/mod.rs:273-323); `nodes` may be null
   pub fn ronk_fft(p: u64, g: u64, input: *const u64, output: *mut u64, nodes: *mut u64, n: usize) -> c_int;
   /// `Polynomial::<Lagrange<F>,F,D>::ifft` (src/polynomial/mod.rs:430-484)
@@ -32,6 +62,63 @@ extern "C" {
   pub fn ronk_rs_decode(p: u64, xs: *const u64, ys: *const u64, k: usize, out: *mut u64) -> c_int;
   /// `kzg::commit` (src/kzg/setup.rs:48-60) over BN254 G1: points n x [x: 4 limbs, y: 4 limbs], scalars n x 4 limbs
   pub fn ronk_msm_bn254(points: *const u64, scalars: *const u64, n: usize, out: *mut u64) -> c_int;
+
+  // ---- plans and device-resident forms (device.rs: `Plan`, `DevicePoly`): coefficients stay in HBM between calls
+  pub fn ronk_plan_create(out: *mut *mut RonkPlan, p: u64, g: u64, log2n: u32, batch: u64, device: c_int) -> c_int;
+  pub fn ronk_plan_create_tuned(
+    out: *mut *mut RonkPlan, p: u64, g: u64, log2n: u32, batch: u64, device: c_int, tile_log2_columns: c_int,
+    twiddle_matrix_log2_max: c_int,
+  ) -> c_int;
+  pub fn ronk_plan_create_opts(
+    out: *mut *mut RonkPlan, p: u64, g: u64, log2n: u32, batch: u64, device: c_int, opts: *const RonkPlanOpts,
+  ) -> c_int;
+  pub fn ronk_plan_in_flight(plan: *const RonkPlan) -> c_int;
+  pub fn ronk_plan_destroy(plan: *mut RonkPlan) -> c_int;
+  /// host pointers through the plan's pinned staging ring (`nodes` may be null)
+  pub fn ronk_ntt_forward(plan: *mut RonkPlan, input: *const u64, output: *mut u64, nodes: *mut u64) -> c_int;
+  pub fn ronk_ntt_inverse(plan: *mut RonkPlan, input: *const u64, output: *mut u64) -> c_int;
+  /// device pointers, asynchronous on `stream` (a hipStream_t; null = the null stream)
+  pub fn ronk_ntt_forward_dev(plan: *mut RonkPlan, d_in: *const u64, d_out: *mut u64, stream: *mut c_void) -> c_int;
+  pub fn ronk_ntt_inverse_dev(plan: *mut RonkPlan, d_in: *const u64, d_out: *mut u64, stream: *mut c_void) -> c_int;
+  /// `count` unrelated device arrays in one call (two lanes inside the library)
+  pub fn ronk_ntt_forward_many_dev(
+    plan: *mut RonkPlan, d_in: *const *const u64, d_out: *const *mut u64, count: usize, stream: *mut c_void,
+  ) -> c_int;
+  pub fn ronk_ntt_inverse_many_dev(
+    plan: *mut RonkPlan, d_in: *const *const u64, d_out: *const *mut u64, count: usize, stream: *mut c_void,
+  ) -> c_int;
+  pub fn ronk_poly_mul_dev(
+    p: u64, g: u64, d_a: *const u64, d: usize, d_b: *const u64, d2: usize, d_out: *mut u64, stream: *mut c_void,
+  ) -> c_int;
+  pub fn ronk_poly_eval_dev(p: u64, d_c: *const u64, d: usize, x: u64, d_out: *mut u64, stream: *mut c_void) -> c_int;
+  /// `kzg::open`'s `poly.div([-z, 1])` (src/kzg/setup.rs:63-78): quotient by b0 + b1 x, remainder's constant term
+  pub fn ronk_poly_div_linear_dev(
+    p: u64, d_c: *const u64, d: usize, b0: u64, b1: u64, d_quot: *mut u64, d_rem: *mut u64, stream: *mut c_void,
+  ) -> c_int;
+  pub fn ronk_poly_divrem_dev(
+    p: u64, d_a: *const u64, d: usize, d_b: *const u64, d2: usize, d_quot: *mut u64, d_rem: *mut u64,
+    d_status: *mut c_int, stream: *mut c_void,
+  ) -> c_int;
+  pub fn ronk_vec_add_dev(p: u64, a: *const u64, b: *const u64, out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+  pub fn ronk_vec_sub_dev(p: u64, a: *const u64, b: *const u64, out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+  pub fn ronk_vec_mul_dev(p: u64, a: *const u64, b: *const u64, out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+  pub fn ronk_dev_alloc(ptr: *mut *mut c_void, bytes: usize) -> c_int;
+  pub fn ronk_dev_free(ptr: *mut c_void) -> c_int;
+  pub fn ronk_memcpy_h2d(dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+  pub fn ronk_memcpy_d2h(dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+  pub fn ronk_dev_sync() -> c_int;
+
+  // ---- the sharded four-step transform (BASELINE config 5: 2^26 over the GPUs of one node) as one call
+  pub fn ronk_sharded_plan_create(
+    out: *mut *mut RonkShardedPlan, log2n: u32, inverse: c_int, devices: *const c_int, ndev: c_int, chunks: c_int,
+  ) -> c_int;
+  pub fn ronk_sharded_plan_destroy(plan: *mut RonkShardedPlan) -> c_int;
+  pub fn ronk_sharded_plan_info(
+    plan: *const RonkShardedPlan, rows: *mut u64, cols: *mut u64, per_rank: *mut u64, chunks: *mut c_int,
+  ) -> c_int;
+  pub fn ronk_ntt_sharded_dev(plan: *mut RonkShardedPlan, d_in: *const *const u64, d_out: *const *mut u64) -> c_int;
+  pub fn ronk_sharded_sync(plan: *mut RonkShardedPlan) -> c_int;
+  pub fn ronk_ntt_sharded(plan: *mut RonkShardedPlan, input: *const u64, output: *mut u64) -> c_int;
 }
 
 /// 0 -> (), anything else -> the reference's panic

@@ -224,6 +224,158 @@ def test_planner_default_for_big_batches_vs_oracle(R, orc, k, batch):
     plan.close()
 
 
+class _DevArr:
+    """a device array of uint64 through the library's own helpers (no torch in this file)"""
+
+    def __init__(self, host=None, n=0):
+        import ctypes as C
+        from ronkathon_amd import _lib as L
+        self.L, self.n = L, int(host.size if host is not None else n)
+        self.h = C.c_void_p()
+        L.check(L.lib.ronk_dev_alloc(C.byref(self.h), self.n * 8))
+        if host is not None:
+            a = L.arr(host)
+            L.check(L.lib.ronk_memcpy_h2d(self.h, L.ptr(a), self.n * 8))
+
+    @property
+    def ptr(self):
+        return self.h.value
+
+    def get(self):
+        out = np.empty(self.n, dtype=np.uint64)
+        self.L.check(self.L.lib.ronk_dev_sync())
+        self.L.check(self.L.lib.ronk_memcpy_d2h(self.L.ptr(out), self.h, self.n * 8))
+        return out
+
+    def free(self):
+        if self.h:
+            self.L.lib.ronk_dev_free(self.h)
+            self.h = None
+
+
+@pytest.mark.parametrize("k,batch", [(19, 2), (20, 3), (21, 2), (22, 2), (22, 5)])
+def test_in_flight_lanes_vs_oracle(R, orc, k, batch):
+    """ronk_plan_opts::in_flight: the second half of the batch runs on the plan's side stream (event fork / join); 1, 2 and
+    auto give the oracle's values for every polynomial, forward and inverse (reference src/polynomial/mod.rs:273-323,
+    :430-484), odd batches included (halves of different size)"""
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    x = splitmix_field(0x5EED0700 + 31 * k + batch, n * batch)
+    want_f = [orc.fft(GP, GG, x[b * n:(b + 1) * n]) for b in range(batch)]
+    want_i = orc.ifft(GP, GG, x[(batch - 1) * n:])
+    for lanes in (1, 2, -1):
+        plan = L.Plan(GP, GG, k, batch, in_flight=lanes)
+        assert plan.in_flight() == (2 if lanes == 2 else 1)      # automatic = 1 (DESIGN.md 5.2)
+        y = plan.forward(x)
+        for b in range(batch):
+            assert np.array_equal(y[b * n:(b + 1) * n], want_f[b]), ("forward", k, batch, lanes, b)
+        z = plan.inverse(x)
+        assert np.array_equal(z[(batch - 1) * n:], want_i), ("inverse", k, batch, lanes)
+        assert np.array_equal(plan.inverse(y), x)
+        plan.close()
+
+
+def test_in_flight_outside_window_is_one(R):
+    from ronkathon_amd import _lib as L
+    for k, batch in ((16, 8), (12, 64), (23, 2), (22, 1), (22, 4)):
+        plan = L.Plan(GP, GG, k, batch)
+        assert plan.in_flight() == 1
+        plan.close()
+
+
+@pytest.mark.parametrize("k,count", [(19, 5), (22, 4), (16, 3), (11, 3)])
+def test_forward_many_dev_vs_oracle(R, orc, k, count):
+    """ronk_ntt_forward_many_dev / _inverse_many_dev: `count` unrelated device arrays in one call on a batch-1 plan with two
+    lanes (own scratch per lane); sizes outside the two-lane window run the arrays one after the other"""
+    from ronkathon_amd import _lib as L
+    n = 1 << k
+    plan = L.Plan(GP, GG, k, 1, in_flight=2)
+    xs = [splitmix_field(0x5EED0800 + 7 * k + i, n) for i in range(count)]
+    din = [_DevArr(x) for x in xs]
+    dout = [_DevArr(n=n) for _ in xs]
+    for rep in range(2):     # twice: the second call reuses both scratches behind the first
+        plan.forward_many_dev([d.ptr for d in din], [d.ptr for d in dout])
+    ys = [d.get() for d in dout]
+    for i in range(count):
+        assert np.array_equal(ys[i], orc.fft(GP, GG, xs[i])), (k, i)
+    plan.forward_many_dev([d.ptr for d in dout], [d.ptr for d in dout], inverse=True)   # in place
+    for i in range(count):
+        assert np.array_equal(dout[i].get(), xs[i]), ("roundtrip", k, i)
+    for d in din + dout:
+        d.free()
+    plan.close()
+
+
+def test_batch16_of_2_22_vs_oracle(R, orc):
+    """16 polynomials of 2^22 coefficients through ONE plan handle (one launch pair, and two lanes of 8): every polynomial
+    against the oracle"""
+    from ronkathon_amd import _lib as L
+    k, batch = 22, 16
+    n = 1 << k
+    x = splitmix_field(0x5EED0900, n * batch)
+    want = [orc.fft(GP, GG, x[b * n:(b + 1) * n]) for b in range(batch)]
+    for lanes in (-1, 2):
+        plan = L.Plan(GP, GG, k, batch, in_flight=lanes)
+        assert plan.in_flight() == (2 if lanes == 2 else 1)
+        y = plan.forward(x)
+        for b in range(batch):
+            assert np.array_equal(y[b * n:(b + 1) * n], want[b]), (lanes, b)
+        plan.close()
+
+
+def test_config3_full_vector_2_22(R, orc):
+    """BASELINE configs[2], element for element: the product of two 2^21-coefficient polynomials (NTT size 2^22) against
+    ifft(fft(a) * fft(b)) computed by the oracle (three oracle transforms) -- every one of the 2^22 - 1 coefficients"""
+    F = R.GoldilocksField
+    d = 1 << 21
+    a = splitmix_field(0x5EED0A11, d); b = splitmix_field(0x5EED0A12, d)
+    prod = (R.Polynomial.new(F, a) * R.Polynomial.new(F, b)).coefficients
+    z = np.zeros(d, dtype=np.uint64)
+    fa, fb = orc.fft(GP, GG, np.concatenate([a, z])), orc.fft(GP, GG, np.concatenate([b, z]))
+    want = orc.ifft(GP, GG, orc.vec_mul(GP, fa, fb))
+    assert int(want[-1]) == 0
+    assert np.array_equal(prod, want[:2 * d - 1])
+
+
+def test_config4_sixteen_rows_vs_oracle(R, orc):
+    """BASELINE configs[3]: 16 of the 1024 rows (first, last, both sides of every quarter, a few inside) against the oracle"""
+    from ronkathon_amd import _lib as L
+    n, batch = 1 << 16, 1024
+    x = splitmix_field(0x5EED0044, n * batch)
+    plan = L.Plan(GP, GG, 16, batch)
+    y = plan.forward(x)
+    for b in (0, 1, 2, 17, 255, 256, 257, 500, 511, 512, 513, 767, 768, 1000, 1022, 1023):
+        assert np.array_equal(y[b * n:(b + 1) * n], orc.fft(GP, GG, x[b * n:(b + 1) * n])), b
+    plan.close()
+
+
+def test_plan_seen_on_several_streams(R, orc):
+    """the scratch guard (transform_dev): a plan used on stream A, then on B (A destroyed in between), then on the null
+    stream -- every result correct, no call fails because of the dead handle"""
+    import ctypes as C
+    from ronkathon_amd import _lib as L
+    hip = C.CDLL("libamdhip64.so")
+    k = 20
+    n = 1 << k
+    plan = L.Plan(GP, GG, k, 1, in_flight=1)
+    x = splitmix_field(0x5EED0B00, n)
+    want = orc.fft(GP, GG, x)
+    din, dout = _DevArr(x), _DevArr(n=n)
+    sa, sb = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(sa)) == 0 and hip.hipStreamCreate(C.byref(sb)) == 0
+    plan.forward_dev(din.ptr, dout.ptr, sa.value)
+    assert hip.hipStreamSynchronize(sa) == 0
+    assert np.array_equal(dout.get(), want)
+    assert hip.hipStreamDestroy(sa) == 0
+    for s_ in (sb.value, 0, sb.value, sb.value, 0):
+        plan.forward_dev(din.ptr, dout.ptr, s_)
+    assert np.array_equal(dout.get(), want)
+    assert hip.hipStreamDestroy(sb) == 0
+    plan.forward_dev(din.ptr, dout.ptr, 0)
+    assert np.array_equal(dout.get(), want)
+    din.free(); dout.free(); plan.close()
+
+
 def test_field_mul_carry_paths_on_gpu(R, orc):
     """gl64::mul / mul_2exp use v_mad_u64_u32's carry-out and hand-written borrow chains (csrc/gl64.h): products of
     edge values that hit every wrap/borrow branch, through the element-wise C ABI, against the oracle."""
