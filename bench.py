@@ -212,7 +212,7 @@ def main():
                     help="ntt22: how the K transforms of a region reach the library -- many: ONE plan handle (in_flight = 2), "
                          "ronk_ntt_forward_many_dev with --group arrays per call; batch: ONE plan of batch --group, K/group calls; "
                          "streams: one plan per caller stream (--streams), the round-1/2 protocol; auto = many")
-    ap.add_argument("--group", type=int, default=0, help="many / batch: polynomials per library call (default 16, at most K)")
+    ap.add_argument("--group", type=int, default=0, help="many / batch: polynomials per library call (default 32, at most K)")
     ap.add_argument("--rotate", type=int, default=-1,
                     help="distinct input AND output buffers the steps cycle through (HBM-cold protocol; default 8 for ntt22 "
                          "= 512 MiB touched between two uses of a buffer, else 1 = the same buffers every step)")
@@ -376,7 +376,7 @@ def main():
         mode = "many"
     group = 1
     if mode in ("many", "batch"):
-        group = max(1, min(args.group or 16, args.steps))
+        group = max(1, min(args.group or 32, args.steps))
         if mode == "batch":
             while args.steps % group:          # a region is exactly K transforms = K/group calls
                 group -= 1
@@ -564,19 +564,25 @@ def main():
     SAMPLES = max(1, args.samples)
 
     def timed_regions():
-        """SAMPLES regions of exactly K steps; wall seconds per region (max over ranks)"""
-        out_ = []
+        """SAMPLES regions of exactly K steps, each bracketed by barrier + synchronize on both sides: wall seconds per region
+        (max over ranks) and, for the SAME regions, the device time between two HIP events recorded on the launch stream
+        right after the opening and right before the closing synchronisation (milliseconds, this rank)"""
+        out_, dev_ = [], []
         for _ in range(SAMPLES):
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             sync_all()
             t0_ = time.perf_counter()
+            e0_.record()
             run(args.steps)
+            e1_.record()
             sync_all()
             out_.append(time.perf_counter() - t0_)
+            dev_.append(e0_.elapsed_time(e1_))
         if world > 1:
             tt = torch.tensor(out_, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             out_ = [float(v) for v in tt.tolist()]
-        return out_
+        return out_, dev_
 
     def device_regions():
         """the same K steps, SAMPLES back-to-back regions delimited by HIP events on the launch stream (torch's current
@@ -597,18 +603,18 @@ def main():
     while time.perf_counter() - t_spin < 0.05:
         run(max(1, args.steps))
         torch.cuda.synchronize()
-    dts = timed_regions()                                 # the protocol of `value`: throughput mode, R_cold buffers
+    dts, dts_dev = timed_regions()                        # the protocol of `value`: throughput mode, R_cold buffers
     dt = float(np.median(dts))
     dt_min = float(min(dts))
     value = world * args.steps * batch / dt               # whole-job units per second (polynomials, products, ...)
     # same regime on the device clock (events); with several CALLER streams an event on one of them does not bracket the
     # others' work: the wall time of the region stands in
-    thr_dev_ms = float(np.median(device_regions())) if S == 1 else dt * 1e3
+    thr_dev_ms = float(np.median(dts_dev)) if S == 1 else dt * 1e3
     warm = None
     if R_cold > 1:                                        # the same buffers every step (Infinity-Cache resident inputs)
         rot["R"] = 1
         run(max(10, args.steps))
-        dts_w = timed_regions()
+        dts_w, _ = timed_regions()
         warm = {"value": world * args.steps * batch / float(np.median(dts_w)), "ms_per_step": float(np.median(dts_w)) / args.steps * 1e3,
                 "rotate": 1}
     # Latency regime: the same K steps one at a time on ONE stream with the default plan (kernel durations add up)

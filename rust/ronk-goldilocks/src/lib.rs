@@ -6,6 +6,9 @@
 //!   `Polynomial<B, F, D>`, `src/kzg`, `src/codes` -- compiles against it unchanged.
 //! * [`polynomial::Accelerated`] / [`polynomial::AcceleratedLagrange`] -- `fft` / `ifft` / `dft` / `Mul` / `Div` / `Rem` /
 //!   `evaluate` on the GPU through the C ABI (include/ronk_ntt.h), bit-exact with the reference's CPU results.
+//! * [`device::HeapPoly`] / [`device::DevicePoly`] / [`device::Plan`] / [`device::ShardedPlan`] -- heap- and HBM-resident
+//!   polynomials for the sizes the inline `[F; D]` of the reference cannot hold (2^22 coefficients = 32 MiB per value),
+//!   plans, K transforms per call, and the transform sharded over the GPUs of a node.
 //! * [`bn254::commit`] -- `kzg::commit` (src/kzg/setup.rs:48-60) over BN254 G1 through the GPU's bucket-method MSM.
 //! * `in_tree/` -- how the same bodies become specialisations when vendored inside ronkathon, so call sites do not change.
 //!
@@ -16,9 +19,11 @@
 #![feature(effects)]
 
 pub mod bn254;
+pub mod device;
 pub mod ffi;
 pub mod field;
 pub mod polynomial;
 
+pub use device::{DevicePoly, HeapPoly, Plan, ShardedPlan};
 pub use field::Goldilocks;
 pub use polynomial::{rs_decode, Accelerated, AcceleratedLagrange};

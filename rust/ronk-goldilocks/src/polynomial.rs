@@ -23,6 +23,19 @@ fn cptr<const D: usize>(a: &[Goldilocks; D]) -> *const u64 { a.as_ptr() as *cons
 #[inline]
 fn mptr<const D: usize>(a: &mut [Goldilocks; D]) -> *mut u64 { a.as_mut_ptr() as *mut u64 }
 
+/// A zeroed `[Goldilocks; N]` on the HEAP: the output buffers of the methods below never live in this crate's stack
+/// frames (`[Goldilocks::ZERO; N]` as a local is N * 8 bytes of stack -- 32 MiB at the headline size).  The array is moved
+/// out of the box only into the returned `Polynomial`, i.e. into the caller's return slot: the reference's value type
+/// keeps `[F; D]` inline (mod.rs:34-44), so a caller that wants D >= 2^17 needs a large stack for the VALUE itself --
+/// or `device::HeapPoly` / `device::DevicePoly`, which have no such limit.
+#[inline]
+fn heap_zeroed<const N: usize>() -> Box<[Goldilocks; N]> {
+  match vec![Goldilocks::ZERO; N].into_boxed_slice().try_into() {
+    Ok(b) => b,
+    Err(_) => unreachable!("the vector has exactly N elements"),
+  }
+}
+
 /// Operations on a monomial-basis polynomial over Goldilocks, executed by libronk_ntt.so on the GPU.
 pub trait Accelerated<const D: usize> {
   /// `Polynomial::fft` (mod.rs:273-323): natural order in and out, omega = 7^((p-1)/D); also fills `Lagrange::nodes`.
@@ -45,18 +58,20 @@ pub trait Accelerated<const D: usize> {
 
 impl<const D: usize> Accelerated<D> for Polynomial<Monomial, Goldilocks, D> {
   fn fft_gpu(&self) -> Polynomial<Lagrange<Goldilocks>, Goldilocks, D> {
-    let mut out = [Goldilocks::ZERO; D];
+    let mut out = heap_zeroed::<D>();
     let mut nodes = vec![Goldilocks::ZERO; D];
-    check(unsafe { ffi::ronk_fft(P, G, cptr(&self.coefficients), mptr(&mut out), nodes.as_mut_ptr() as *mut u64, D) });
-    Polynomial { coefficients: out, basis: Lagrange { nodes } }
+    check(unsafe { ffi::ronk_fft(P, G, cptr(&self.coefficients), mptr(&mut *out), nodes.as_mut_ptr() as *mut u64, D) });
+    Polynomial { coefficients: *out, basis: Lagrange { nodes } }
   }
 
   fn dft_gpu(&self) -> Polynomial<Lagrange<Goldilocks>, Goldilocks, D> {
-    let mut out = [Goldilocks::ZERO; D];
+    // two calls: the values (any D | p - 1: direct kernel or Bluestein on the NTT path) and the node table omega^i, which
+    // only ronk_fft returns alongside (it exists for powers of two only; the table itself is the same call either way)
+    let mut out = heap_zeroed::<D>();
     let mut nodes = vec![Goldilocks::ZERO; D];
-    check(unsafe { ffi::ronk_dft(P, G, cptr(&self.coefficients), mptr(&mut out), D) });
+    check(unsafe { ffi::ronk_dft(P, G, cptr(&self.coefficients), mptr(&mut *out), D) });
     check(unsafe { ffi::ronk_lagrange_nodes(P, G, nodes.as_mut_ptr() as *mut u64, D) });
-    Polynomial { coefficients: out, basis: Lagrange { nodes } }
+    Polynomial { coefficients: *out, basis: Lagrange { nodes } }
   }
 
   fn evaluate_gpu(&self, x: Goldilocks) -> Goldilocks {
@@ -71,17 +86,17 @@ impl<const D: usize> Accelerated<D> for Polynomial<Monomial, Goldilocks, D> {
   ) -> Polynomial<Monomial, Goldilocks, { D + D2 - 1 }>
   where [(); D + D2 - 1]:
   {
-    let mut out = [Goldilocks::ZERO; D + D2 - 1];
-    check(unsafe { ffi::ronk_poly_mul(P, G, cptr(&self.coefficients), D, cptr(&rhs.coefficients), D2, mptr(&mut out)) });
-    Polynomial::<Monomial, Goldilocks, { D + D2 - 1 }>::new(out)
+    let mut out = heap_zeroed::<{ D + D2 - 1 }>();
+    check(unsafe { ffi::ronk_poly_mul(P, G, cptr(&self.coefficients), D, cptr(&rhs.coefficients), D2, mptr(&mut *out)) });
+    Polynomial::<Monomial, Goldilocks, { D + D2 - 1 }>::new(*out)
   }
 
   fn quotient_and_remainder_gpu<const D2: usize>(&self, rhs: &Polynomial<Monomial, Goldilocks, D2>) -> (Self, Self) {
-    let (mut q, mut r) = ([Goldilocks::ZERO; D], [Goldilocks::ZERO; D]);
+    let (mut q, mut r) = (heap_zeroed::<D>(), heap_zeroed::<D>());
     check(unsafe {
-      ffi::ronk_poly_divrem(P, cptr(&self.coefficients), D, cptr(&rhs.coefficients), D2, mptr(&mut q), mptr(&mut r))
+      ffi::ronk_poly_divrem(P, cptr(&self.coefficients), D, cptr(&rhs.coefficients), D2, mptr(&mut *q), mptr(&mut *r))
     });
-    (Polynomial::<Monomial, Goldilocks, D>::new(q), Polynomial::<Monomial, Goldilocks, D>::new(r))
+    (Polynomial::<Monomial, Goldilocks, D>::new(*q), Polynomial::<Monomial, Goldilocks, D>::new(*r))
   }
 }
 
@@ -95,9 +110,9 @@ pub trait AcceleratedLagrange<const D: usize> {
 
 impl<const D: usize> AcceleratedLagrange<D> for Polynomial<Lagrange<Goldilocks>, Goldilocks, D> {
   fn ifft_gpu(&self) -> Polynomial<Monomial, Goldilocks, D> {
-    let mut out = [Goldilocks::ZERO; D];
-    check(unsafe { ffi::ronk_ifft(P, G, cptr(&self.coefficients), mptr(&mut out), D) });
-    Polynomial::<Monomial, Goldilocks, D>::new(out)
+    let mut out = heap_zeroed::<D>();
+    check(unsafe { ffi::ronk_ifft(P, G, cptr(&self.coefficients), mptr(&mut *out), D) });
+    Polynomial::<Monomial, Goldilocks, D>::new(*out)
   }
 
   fn evaluate_gpu(&self, x: Goldilocks) -> Goldilocks {
@@ -111,9 +126,9 @@ impl<const D: usize> AcceleratedLagrange<D> for Polynomial<Lagrange<Goldilocks>,
 
 /// `Message::decode` (src/codes/reed_solomon.rs:54-106) for Goldilocks coordinates: interpolation through the first K points
 pub fn rs_decode<const K: usize>(xs: &[Goldilocks; K], ys: &[Goldilocks; K]) -> [Goldilocks; K] {
-  let mut out = [Goldilocks::ZERO; K];
-  check(unsafe { ffi::ronk_rs_decode(P, cptr(xs), cptr(ys), K, mptr(&mut out)) });
-  out
+  let mut out = heap_zeroed::<K>();
+  check(unsafe { ffi::ronk_rs_decode(P, cptr(xs), cptr(ys), K, mptr(&mut *out)) });
+  *out
 }
 
 #[cfg(test)]
@@ -138,8 +153,9 @@ mod tests {
     let (a, b) = (poly(), Polynomial::<Monomial, Goldilocks, 2>::new([Goldilocks(5), Goldilocks(1)]));
     assert_eq!(a.mul_gpu(&b), a * b);
     let (q, r) = a.quotient_and_remainder_gpu(&b);
-    let (q0, r0) = a.quotient_and_remainder(b);
-    assert_eq!((q, r), (q0, r0));
+    // the reference's `quotient_and_remainder` is private (mod.rs:170): its public faces are `impl Div` / `impl Rem`
+    // (arithmetic.rs:121-146); `Polynomial` is `Copy`, so `a` and `b` can be used twice
+    assert_eq!((q, r), (a / b, a % b));
     assert_eq!(a.evaluate_gpu(Goldilocks(2)), a.evaluate(Goldilocks(2)));
   }
 

@@ -63,6 +63,119 @@ static void replay_arithmetic(size_t D, size_t D2) {
   free(a); free(b); free(prod); free(ref); free(q); free(r); free(qr); free(rr);
 }
 
+/* device.rs: DevicePoly::{from_host, fft, ifft, mul, evaluate, div_linear, div_rem, add, to_host}, Plan::{with_opts, forward,
+ * inverse_in_place, forward_many}, HeapPoly through the host-pointer forms, ShardedPlan::{new, info, transform_host} -- the same
+ * calls in the same order with the same buffers (device pointers from ronk_dev_alloc, the status word zeroed by a 4-byte upload) */
+static uint64_t* dev_from_host(const uint64_t* h, size_t n) {
+  void* d = NULL;
+  EXPECT(ronk_dev_alloc(&d, n * 8) == 0, "ronk_dev_alloc");
+  if (h) EXPECT(ronk_memcpy_h2d(d, h, n * 8) == 0, "ronk_memcpy_h2d");
+  return (uint64_t*)d;
+}
+static void dev_to_host(uint64_t* h, const uint64_t* d, size_t n) {
+  EXPECT(ronk_dev_sync() == 0, "ronk_dev_sync");
+  EXPECT(ronk_memcpy_d2h(h, d, n * 8) == 0, "ronk_memcpy_d2h");
+}
+static void replay_device(unsigned log2n) {
+  const size_t n = (size_t)1 << log2n;
+  uint64_t *x = fresh(n), *ref = calloc(n, 8), *got = calloc(n, 8);
+  /* DevicePoly::from_host(x).fft(): Plan::new -> ronk_plan_create_opts with the default options block */
+  ronk_plan_opts opts = RONK_PLAN_OPTS_DEFAULT;
+  ronk_plan* plan = NULL;
+  EXPECT(ronk_plan_create_opts(&plan, P, G, log2n, 1, -1, &opts) == 0, "ronk_plan_create_opts");
+  EXPECT(ronk_plan_in_flight(plan) == 1, "default in_flight");
+  uint64_t *dx = dev_from_host(x, n), *dy = dev_from_host(NULL, n);
+  EXPECT(ronk_ntt_forward_dev(plan, dx, dy, NULL) == 0, "ronk_ntt_forward_dev");
+  dev_to_host(got, dy, n);
+  EXPECT(orc_fft(P, G, x, ref, n) == 0 && !memcmp(got, ref, n * 8), "DevicePoly::fft");
+  EXPECT(ronk_ntt_inverse_dev(plan, dy, dy, NULL) == 0, "inverse_in_place");
+  dev_to_host(got, dy, n);
+  EXPECT(!memcmp(got, x, n * 8), "DevicePoly::ifft round trip");
+  /* Plan::forward_host / inverse_host (HeapPoly-sized data through the plan's pinned staging) */
+  EXPECT(ronk_ntt_forward(plan, x, got, NULL) == 0 && !memcmp(got, ref, n * 8), "Plan::forward_host");
+  EXPECT(ronk_ntt_inverse(plan, ref, got) == 0 && !memcmp(got, x, n * 8), "Plan::inverse_host");
+  EXPECT(ronk_plan_destroy(plan) == 0, "ronk_plan_destroy");
+  /* evaluate, div_linear (kzg::open: divisor [-z, 1]) */
+  uint64_t z = next_field(), *dq = dev_from_host(NULL, n), *dr = dev_from_host(NULL, 1), r = 0, y = 0;
+  EXPECT(ronk_poly_eval_dev(P, dx, n, z, dr, NULL) == 0, "ronk_poly_eval_dev");
+  dev_to_host(&y, dr, 1);
+  EXPECT(y == orc_poly_eval(P, x, n, z), "DevicePoly::evaluate");
+  EXPECT(ronk_poly_div_linear_dev(P, dx, n, P - z, 1, dq, dr, NULL) == 0, "ronk_poly_div_linear_dev");
+  dev_to_host(&r, dr, 1); dev_to_host(got, dq, n);
+  { uint64_t div[2] = {P - z, 1}, *qr = calloc(n, 8), *rr = calloc(n, 8);
+    EXPECT(r == y, "remainder == p(z)");
+    if (n <= 4096) EXPECT(orc_poly_divrem(P, x, n, div, 2, qr, rr) == 0 && !memcmp(got, qr, n * 8) && rr[0] == r, "div_linear values");
+    else { uint64_t t = next_field();   /* p(t) == q(t) (t - z) + r */
+           EXPECT(orc_poly_eval(P, x, n, t) == orc_add(P, orc_mul(P, orc_poly_eval(P, got, n - 1, t), orc_sub(P, t, z)), r), "p = q (x - z) + r"); }
+    free(qr); free(rr); }
+  /* div_rem by a general divisor with the device status word */
+  if (n <= 4096) {
+    size_t d2 = 5;
+    uint64_t *b = fresh(d2), *db = dev_from_host(b, d2), *drem = dev_from_host(NULL, n), *qr = calloc(n, 8), *rr = calloc(n, 8);
+    int status = 0; void* dst = NULL;
+    EXPECT(ronk_dev_alloc(&dst, 8) == 0 && ronk_memcpy_h2d(dst, &status, 4) == 0, "status word");
+    EXPECT(ronk_poly_divrem_dev(P, dx, n, db, d2, dq, drem, (int*)dst, NULL) == 0, "ronk_poly_divrem_dev");
+    EXPECT(ronk_dev_sync() == 0 && ronk_memcpy_d2h(&status, dst, 4) == 0 && status == 0, "status == 0");
+    dev_to_host(got, dq, n);
+    EXPECT(orc_poly_divrem(P, x, n, b, d2, qr, rr) == 0 && !memcmp(got, qr, n * 8), "div_rem quotient");
+    dev_to_host(got, drem, n);
+    EXPECT(!memcmp(got, rr, n * 8), "div_rem remainder");
+    ronk_dev_free(db); ronk_dev_free(drem); ronk_dev_free(dst); free(b); free(qr); free(rr);
+  }
+  /* mul (d + d2 - 1 coefficients) and add */
+  { size_t d2 = n / 2 + 3;
+    uint64_t *b = fresh(d2), *db = dev_from_host(b, d2), *dp = dev_from_host(NULL, n + d2 - 1), *prod = calloc(n + d2 - 1, 8);
+    EXPECT(ronk_poly_mul_dev(P, G, dx, n, db, d2, dp, NULL) == 0, "ronk_poly_mul_dev");
+    dev_to_host(prod, dp, n + d2 - 1);
+    uint64_t t = next_field();
+    EXPECT(orc_poly_eval(P, prod, n + d2 - 1, t) == orc_mul(P, orc_poly_eval(P, x, n, t), orc_poly_eval(P, b, d2, t)), "mul homomorphism");
+    EXPECT(prod[0] == orc_mul(P, x[0], b[0]) && prod[n + d2 - 2] == orc_mul(P, x[n - 1], b[d2 - 1]), "mul end coefficients");
+    EXPECT(ronk_vec_add_dev(P, dx, dy, dq, n, NULL) == 0, "ronk_vec_add_dev");
+    dev_to_host(got, dq, n);
+    EXPECT(got[0] == orc_add(P, x[0], x[0]) && got[n - 1] == orc_add(P, x[n - 1], x[n - 1]), "DevicePoly::add");   /* dy == x after the round trip */
+    ronk_dev_free(db); ronk_dev_free(dp); free(b); free(prod); }
+  ronk_dev_free(dx); ronk_dev_free(dy); ronk_dev_free(dq); ronk_dev_free(dr);
+  free(x); free(ref); free(got);
+}
+/* Plan::with_two_lanes + forward_many / inverse_many: K device arrays, HOST arrays of device pointers */
+static void replay_many(unsigned log2n, size_t K) {
+  const size_t n = (size_t)1 << log2n;
+  ronk_plan_opts opts = RONK_PLAN_OPTS_DEFAULT;
+  opts.in_flight = 2;
+  ronk_plan* plan = NULL;
+  EXPECT(ronk_plan_create_opts(&plan, P, G, log2n, 1, -1, &opts) == 0, "create with two lanes");
+  EXPECT(ronk_plan_in_flight(plan) == (log2n > 12 ? 2 : 1), "in_flight");
+  uint64_t** xs = calloc(K, sizeof *xs);
+  const uint64_t** din = calloc(K, sizeof *din);
+  uint64_t** dout = calloc(K, sizeof *dout);
+  for (size_t i = 0; i < K; i++) { xs[i] = fresh(n); din[i] = dev_from_host(xs[i], n); dout[i] = dev_from_host(NULL, n); }
+  EXPECT(ronk_ntt_forward_many_dev(plan, din, dout, K, NULL) == 0, "ronk_ntt_forward_many_dev");
+  uint64_t *got = calloc(n, 8), *ref = calloc(n, 8);
+  for (size_t i = 0; i < K; i++) {
+    dev_to_host(got, dout[i], n);
+    EXPECT(orc_fft(P, G, xs[i], ref, n) == 0 && !memcmp(got, ref, n * 8), "forward_many values");
+  }
+  EXPECT(ronk_ntt_inverse_many_dev(plan, (const uint64_t* const*)dout, dout, K, NULL) == 0, "ronk_ntt_inverse_many_dev (in place)");
+  for (size_t i = 0; i < K; i++) { dev_to_host(got, dout[i], n); EXPECT(!memcmp(got, xs[i], n * 8), "inverse_many round trip"); }
+  for (size_t i = 0; i < K; i++) { free(xs[i]); ronk_dev_free((void*)din[i]); ronk_dev_free(dout[i]); }
+  free(xs); free(din); free(dout); free(got); free(ref);
+  EXPECT(ronk_plan_destroy(plan) == 0, "destroy");
+}
+/* ShardedPlan::new(log2n, false, &[0, 0], 0) -> info -> transform_host: two logical ranks on device 0 */
+static void replay_sharded(unsigned log2n) {
+  const size_t n = (size_t)1 << log2n;
+  int devices[2] = {0, 0};
+  ronk_sharded_plan* sp = NULL;
+  EXPECT(ronk_sharded_plan_create(&sp, log2n, 0, devices, 2, 0) == 0, "ronk_sharded_plan_create");
+  uint64_t rows = 0, cols = 0, per = 0; int chunks = 0;
+  EXPECT(ronk_sharded_plan_info(sp, &rows, &cols, &per, &chunks) == 0 && rows * cols == n && per == n / 2 && chunks >= 1, "info");
+  uint64_t *x = fresh(n), *got = calloc(n, 8), *ref = calloc(n, 8);
+  EXPECT(ronk_ntt_sharded(sp, x, got) == 0, "ronk_ntt_sharded");
+  EXPECT(orc_fft(P, G, x, ref, n) == 0 && !memcmp(got, ref, n * 8), "ShardedPlan::transform_host");
+  EXPECT(ronk_sharded_sync(sp) == 0 && ronk_sharded_plan_destroy(sp) == 0, "sync / destroy");
+  free(x); free(got); free(ref);
+}
+
 int main(void) {
   int ndev = 0;
   if (ronk_device_count(&ndev) != 0 || ndev < 1) { printf("no device\n"); return 2; }
@@ -73,6 +186,10 @@ int main(void) {
   for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); i++) replay_transforms(sizes[i]);
   replay_arithmetic(4, 2); replay_arithmetic(5, 5); replay_arithmetic(17, 17); replay_arithmetic(1000, 3);
   replay_arithmetic(3000, 3000); replay_arithmetic(1 << 15, 2);
+  /* device.rs */
+  replay_device(10); replay_device(12); replay_device(16); replay_device(20);
+  replay_many(10, 3); replay_many(16, 5); replay_many(20, 4);
+  replay_sharded(16); replay_sharded(20);
   /* rs_decode::<K> */
   { enum { K = 64 };
     uint64_t xs[K], *ys = fresh(K), out[K], ref[K];
