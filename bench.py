@@ -325,6 +325,65 @@ def main():
         print(json.dumps(res))
         return
 
+    if wl == "e2e22":
+        # The drop-in path's own rate: HOST buffers in, HOST buffers out (what `Polynomial<_, Goldilocks, D>` with its inline
+        # `[F; D]` gets through the Rust shim), PCIe both ways inside the timed region.  (a) one polynomial per call through the
+        # one-shot `ronk_fft` (cached plan); (b) `--group` polynomials per call through a batched plan, which the library
+        # pipelines over its three internal streams (upload i+1 | transform i | download i-1).  Bound: the link, not HBM.
+        PCIE_GBS = 63.0                                  # PCIe Gen5 x16 spec, one direction (MI355X_MICROARCH.md)
+        lg = args.log2n or 22
+        nn = 1 << lg
+        grp = args.group or 8
+        xh = synth(nn * grp, 0x5EED5000 + rank)
+        yh = np.empty_like(xh)
+        x1, y1 = xh[:nn].copy(), np.empty(nn, dtype=np.uint64)
+
+        def single(count):
+            for _ in range(count):
+                L.check(L.lib.ronk_fft(P, G, L.ptr(x1), L.ptr(y1), None, nn))
+        bplan = L.Plan(P, G, lg, grp, local_rank)
+
+        def batched(calls):
+            for _ in range(calls):
+                L.check(L.lib.ronk_ntt_forward(bplan.h, L.ptr(xh), L.ptr(yh), None))
+        verified = None
+        if not args.no_verify:
+            import oracle as orc
+            single(1); batched(1)
+            want = orc.fft(P, G, x1)
+            verified = bool(np.array_equal(y1, want) and np.array_equal(yh[:nn], want)
+                            and np.array_equal(yh[(grp - 1) * nn:], orc.fft(P, G, xh[(grp - 1) * nn:])))
+            assert verified, "host-pointer transform differs from the oracle"
+        steps = max(grp, args.steps - args.steps % grp)
+        single(min(args.warmup, 5)); batched(2)
+
+        def med(f, arg, units):
+            ts = []
+            for _ in range(max(1, args.samples)):
+                t0 = time.perf_counter(); f(arg); ts.append(time.perf_counter() - t0)
+            return units / float(np.median(ts)), float(np.median(ts)) / units * 1e3
+        v_b, ms_b = med(batched, steps // grp, steps)
+        v_s, ms_s = med(single, min(steps, 64), min(steps, 64))
+        link = 16.0 * nn                                  # bytes over the link per transform: 8n in + 8n out
+        res = {"metric": "forward NTTs/s end to end (host buffers in and out, PCIe inside the timed region), degree 2^%d" % lg,
+               "value": v_b * world, "unit": "NTT/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": ms_b,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "verified": verified,
+               "config": {"workload": "forward NTT n = 2^%d through the HOST-pointer entry points: value = ronk_ntt_forward on a "
+                                      "plan of batch %d (pipelined over the batch inside the library); single = one polynomial per "
+                                      "ronk_fft call; pageable numpy buffers" % (lg, grp), "log2n": lg, "group": grp},
+               "single": {"value": v_s, "ms_per_step": ms_s, "entry_point": "ronk_fft (one-shot, cached plan)",
+                          "frac_of_serial_link_floor": (link / (PCIE_GBS * 1e9)) / (ms_s / 1e3)},
+               "roofline": {"bound": "pcie", "achieved": link / (ms_b / 1e3) / 1e9, "peak": 2 * PCIE_GBS, "unit": "GB/s",
+                            "frac": link / (ms_b / 1e3) / 1e9 / (2 * PCIE_GBS), "traffic": link,
+                            "note": "bytes over the link per transform = 16*n (8n up, 8n down); peak = 63 GB/s each way, full "
+                                    "duplex (the pipelined batch keeps both directions busy); one polynomial per call uses the "
+                                    "link one way at a time: its floor is 16n / 63 GB/s (single.frac_of_serial_link_floor)"}}
+        if rank == 0:
+            print(json.dumps(res))
+        bplan.close()
+        return
+
     if wl == "sharded":
         # the in-library sharded transform (ronk_sharded_*): ONE process drives every visible GPU (or --ranks logical ranks
         # on the GPUs there are), peer-copy exchange in column chunks; device-resident blocks, K transforms pipelined

@@ -58,6 +58,7 @@ extern "C" {
 #define RONK_ERR_UNSUPPORTED (-9)   /* size outside what the kernels cover (stated per function) */
 #define RONK_ERR_NO_DEVICE (-10)    /* no HIP device: the library never computes on the CPU */
 #define RONK_ERR_NOT_ON_CURVE (-11) /* assert!(point.is_on_curve(), "Point is not on curve"), src/curve/mod.rs:79 */
+#define RONK_ERR_RCCL (-12)         /* librccl.so could not be loaded or an RCCL call failed; ronk_last_hip_error() has the text */
 
 const char* ronk_strerror(int code);
 const char* ronk_last_hip_error(void);
@@ -296,7 +297,7 @@ int ronk_curve_msm_dev(const ronk_curve* curve, const uint64_t* d_points, size_t
                        uint64_t* d_out, int* d_status, void* stream);
 
 /* ---- the sharded transform as ONE call for a single-process host (the Rust host of BASELINE config 5): rank g of
- *      ndev = devices[g]; the exchange is a mesh of peer copies over xGMI issued by the library on per-device copy
+ *      ndev = devices[g]; the exchange is a mesh of peer copies over xGMI issued by the library on per-peer copy
  *      streams, in `chunks` column chunks so that a chunk travels while the next one is computed (chunks <= 0: default,
  *      up to 4).  The reference has no counterpart: `Polynomial<B, F, D>` holds its coefficients inline
  *      (src/polynomial/mod.rs:34-44), so a degree this large never exists there.
@@ -304,6 +305,15 @@ int ronk_curve_msm_dev(const ronk_curve* curve, const uint64_t* d_points, size_t
  *      RONK_ERR_INVALID (device ordinal out of range), RONK_ERR_HIP. */
 typedef struct ronk_sharded_plan ronk_sharded_plan;
 int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev, int chunks);
+/* The same with the exchange chosen per plan: RONK_EXCHANGE_MESH = hipMemcpyPeerAsync copies, one copy stream per peer
+ * (all xGMI links of a device busy at once); RONK_EXCHANGE_RCCL = every chunk's W x W blocks as one ncclGroup of
+ * ncclSend / ncclRecv pairs (librccl.so is dlopen()ed on first use: RONK_ERR_RCCL if it is missing or a call fails;
+ * ranks must be on distinct devices, else RONK_ERR_UNSUPPORTED).  Same results either way. */
+#define RONK_EXCHANGE_MESH 0
+#define RONK_EXCHANGE_RCCL 1
+int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev, int chunks,
+                                int exchange);
+int ronk_sharded_plan_exchange(const ronk_sharded_plan* plan);
 int ronk_sharded_plan_destroy(ronk_sharded_plan* plan);
 /* R, C (n = R*C), elements per rank (n / ndev) and the number of column chunks in use; any pointer may be NULL */
 int ronk_sharded_plan_info(const ronk_sharded_plan* plan, uint64_t* rows, uint64_t* cols, uint64_t* per_rank, int* chunks);

@@ -27,6 +27,8 @@ GOLDILOCKS_G = 7
 OK, ERR_NO_ROOT, ERR_ZERO_INVERSE, ERR_NOT_POW2, ERR_NOT_PRIME = 0, -1, -2, -3, -4
 ERR_NO_GENERATOR, ERR_INDEX, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = -5, -6, -7, -8, -9, -10
 ERR_NOT_ON_CURVE = -11
+ERR_RCCL = -12
+EXCHANGE_MESH, EXCHANGE_RCCL = 0, 1
 
 
 class RonkPanic(Exception):
@@ -34,7 +36,7 @@ class RonkPanic(Exception):
 
     def __init__(self, code, detail=""):
         msg = lib.ronk_strerror(code).decode()
-        if code == ERR_HIP:
+        if code in (ERR_HIP, ERR_RCCL):
             msg += ": " + lib.ronk_last_hip_error().decode()
         super().__init__(msg + (" " + detail if detail else ""))
         self.code = code
@@ -113,6 +115,8 @@ _SIG = {
     "ronk_rs_decode_dev": (_int, [_u64, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ronk_curve_msm_dev": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "ronk_sharded_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int]),
+    "ronk_sharded_plan_create_ex": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int, _int]),
+    "ronk_sharded_plan_exchange": (_int, [_vp]),
     "ronk_sharded_plan_destroy": (_int, [_vp]),
     "ronk_sharded_plan_info": (_int, [_vp, _pu, _pu, _pu, C.POINTER(_int)]),
     "ronk_ntt_sharded_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -246,11 +250,12 @@ class ShardedPlan:
     xGMI in column chunks).  Rank g = devices[g]; the same ordinal may appear several times (logical ranks sharing a GPU:
     how the single-GPU tests drive this path)."""
 
-    def __init__(self, log2n, devices, inverse=False, chunks=0):
+    def __init__(self, log2n, devices, inverse=False, chunks=0, exchange=EXCHANGE_MESH):
         self.h = None
         h = _vp()
         devs = (_int * len(devices))(*devices)
-        check(lib.ronk_sharded_plan_create(C.byref(h), log2n, int(inverse), devs, len(devices), chunks))
+        check(lib.ronk_sharded_plan_create_ex(C.byref(h), log2n, int(inverse), devs, len(devices), chunks, exchange))
+        self.exchange = exchange
         self.h, self.n, self.ndev = h, 1 << log2n, len(devices)
         r, c, per, ch = _u64(0), _u64(0), _u64(0), _int(0)
         check(lib.ronk_sharded_plan_info(h, C.byref(r), C.byref(c), C.byref(per), C.byref(ch)))

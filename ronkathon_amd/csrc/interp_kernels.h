@@ -129,7 +129,9 @@ __global__ void __launch_bounds__(256) rsf_check_kernel(const u64* __restrict__ 
   const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= k) return;
   bool ok;
-  if (j == 0) ok = xs[0] == 1 && (k < 2 || gl64::mul(xs[k - 1], xs[1]) != 1);
+  // (q = x_1 = 0 would pass every other test -- x_j = x_{j-1} * 0 = 0 != 1 -- with coincident nodes: those belong to the
+  // general kernels, which report the reference's division by zero)
+  if (j == 0) ok = xs[0] == 1 && (k < 2 || (xs[1] != 0 && gl64::mul(xs[k - 1], xs[1]) != 1));
   else ok = xs[j] == gl64::mul(xs[j - 1], xs[1]) && xs[j] != 1;
   if (!ok) atomicOr(flag, 4);
 }

@@ -73,11 +73,14 @@ struct WsLease {
   u64* u() const { return (u64*)slot->p; }
   u32* ctl() const { return slot->ctl; }
   // look-back arrays of a one-launch scan: *cur is all LB_EMPTY now, *next is cleared by the kernel for the call after
+  // The parity advances only through lb_commit(), AFTER the launch was accepted: a failed launch never ran the kernel that
+  // clears *next, so the same (still clean) *cur must serve the following call.
   void lb_arrays(u64** cur, u64** next) {
-    const u32 par = slot->lb_calls++ & 1;
+    const u32 par = slot->lb_calls & 1;
     *cur = slot->lb + (size_t)par * LB_WORDS;
     *next = slot->lb + (size_t)(par ^ 1) * LB_WORDS;
   }
+  void lb_commit() { slot->lb_calls++; }
 };
 // the one-launch scans keep host state per call (which look-back array is clean): not for a capturing stream
 static bool stream_is_capturing(hipStream_t s) {
@@ -164,6 +167,7 @@ extern "C" int ronk_poly_eval_dev(uint64_t p, const uint64_t* d_c, size_t d, uin
       FIELD_DISPATCH(f, { hipLaunchKernelGGL((eval_onepass_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d,
                                             tab2, cur, next, d_out); });
       HIPCHK(hipGetLastError());
+      ws.lb_commit();
       return RONK_OK;
     }
     FIELD_DISPATCH(f, {
@@ -222,6 +226,7 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
       FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_onepass_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d,
                                             tab2, cur, next, d_quot, d_rem); });
       HIPCHK(hipGetLastError());
+      ws.lb_commit();
       return RONK_OK;
     }
     FIELD_DISPATCH(f, {
@@ -360,11 +365,18 @@ static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b,
   const u64 P = RONK_GOLDILOCKS_P, G = RONK_GOLDILOCKS_G;
   const size_t L = n - m + 1;                       // coefficients of the true quotient
   size_t Lp = 1; while (Lp < L) Lp <<= 1;           // Newton runs to a power-of-two precision
-  DevBuf f, g, e, h, t1, ar;
-  RCHK(f.alloc(Lp * 8)); RCHK(g.alloc(2 * Lp * 8)); RCHK(e.alloc(4 * Lp * 8)); RCHK(h.alloc(Lp * 8));
-  RCHK(t1.alloc(2 * Lp * 8)); RCHK(ar.alloc((L > d ? L : d) * 8 + 8));
+  // temporaries from the event-guarded workspace pool (one lease, carved up): nothing is allocated, freed or waited for
+  // per call, so the entry point stays asynchronous on `s`
+  struct Span { u64* p; u64* u() const { return p; } };
+  const size_t n_ar = (L > d ? L : d) + 1, n_qr = 2 * L, n_prod = L + m + 1;
+  WsLease ws;
+  RCHK(ws.acquire((Lp + 2 * Lp + 4 * Lp + Lp + 2 * Lp + n_ar + n_qr + n_prod) * 8, s));
+  u64* cur = ws.u();
+  auto take = [&](size_t cnt) { Span sp{cur}; cur += cnt; return sp; };
+  const Span f = take(Lp), g = take(2 * Lp), e = take(4 * Lp), h = take(Lp), t1 = take(2 * Lp), ar = take(n_ar), qr = take(n_qr),
+             prod = take(n_prod);
   // f = rev(b) mod x^Lp: f[i] = b[m - i] for i <= min(m, Lp - 1), ZERO above
-  HIPCHK(hipMemsetAsync(f.p, 0, Lp * 8, s));
+  HIPCHK(hipMemsetAsync(f.p, 0, Lp * 8, s));   // (Span::p)
   const size_t flen = (m + 1 < Lp) ? m + 1 : Lp;
   hipLaunchKernelGGL(dv_reverse_kernel, dim3(grid_for(flen)), dim3(256), 0, s, d_b, m, f.u(), flen);
   // g = 1 / f[0] = 1 / lead(b)   (precision 1)
@@ -379,20 +391,15 @@ static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b,
   }
   // qrev = (rev(a)[0:L] * g[0:L])[0:L]
   hipLaunchKernelGGL(dv_reverse_kernel, dim3(grid_for(L)), dim3(256), 0, s, d_a, n, ar.u(), L);
-  DevBuf qr;
-  RCHK(qr.alloc(2 * L * 8));
   RCHK(ronk_poly_mul_dev(P, G, ar.u(), L, g.u(), L, qr.u(), s));
   const size_t t = 0;                               // d2 == m + 1: every quotient coefficient is produced
   (void)d2;
   hipLaunchKernelGGL(dv_quot_kernel, dim3(grid_for(d)), dim3(256), 0, s, qr.u(), L, t, d_quot, d);
   // rem = a - quot[0:L] * b[0:m+1]
-  DevBuf prod;
-  RCHK(prod.alloc((L + m + 1) * 8));
   RCHK(ronk_poly_mul_dev(P, G, d_quot, L, d_b, m + 1, prod.u(), s));
   hipLaunchKernelGGL(dv_rem_kernel, dim3(grid_for(d)), dim3(256), 0, s, d_a, prod.u(), L + m, d_rem, d);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));                  // the DevBufs above are freed on return
-  return RONK_OK;
+  return RONK_OK;                                   // the lease's destructor leaves an event behind the last kernel
 }
 
 // quotient_and_remainder on device-resident operands: the long-division kernel that follows the reference's loop
@@ -484,12 +491,16 @@ extern "C" int ronk_rs_encode(uint64_t p, uint64_t g, const uint64_t* msg, size_
 // Device resident: d_xs / d_ys hold CANONICAL residues; d_status (may be NULL) is set non-zero for coincident nodes.
 // Message::decode for x_j = q^j in O(K log K) (interp_kernels.h): two linear convolutions on the NTT path.  `sel` (device word,
 // zeroed by the caller) gets bit 2 when the nodes are not such a sequence; the result is written only when it stays 0.
-// Synchronises `s` once (temporaries).
+// Asynchronous on `s`: the temporaries are one lease of the event-guarded workspace pool.
 static int rs_decode_fast_dev(const u64* d_xs, const u64* d_ys, size_t k, u64* d_out, int* sel, hipStream_t s) {
   const u64 P = RONK_GOLDILOCKS_P, G = RONK_GOLDILOCKS_G;
-  DevBuf B, arev, b, conv, M, srev, conv2, tot;
-  RCHK(B.alloc((k + 1) * 8)); RCHK(arev.alloc(k * 8)); RCHK(b.alloc((2 * k - 1) * 8)); RCHK(conv.alloc((3 * k - 2) * 8));
-  RCHK(M.alloc((k + 1) * 8)); RCHK(srev.alloc(k * 8)); RCHK(conv2.alloc(2 * k * 8)); RCHK(tot.alloc(1025 * 8));
+  struct Span { u64* p; u64* u() const { return p; } };
+  WsLease ws;
+  RCHK(ws.acquire(((k + 1) + k + (2 * k - 1) + (3 * k - 2) + (k + 1) + k + 2 * k + 1025) * 8, s));
+  u64* cur = ws.u();
+  auto take = [&](size_t cnt) { Span sp{cur}; cur += cnt; return sp; };
+  const Span B = take(k + 1), arev = take(k), b = take(2 * k - 1), conv = take(3 * k - 2), M = take(k + 1), srev = take(k),
+             conv2 = take(2 * k), tot = take(1025);
   const size_t m = k + 1;
   const u32 nb = (u32)((m + 256 * RSF_PER - 1) / (256 * RSF_PER));
   hipLaunchKernelGGL(rsf_check_kernel, dim3((u32)((k + 255) / 256)), dim3(256), 0, s, d_xs, k, sel);
@@ -506,7 +517,6 @@ static int rs_decode_fast_dev(const u64* d_xs, const u64* d_ys, size_t k, u64* d
   RCHK(ronk_poly_mul_dev(P, G, srev.u(), k, M.u(), k + 1, conv2.u(), s));
   hipLaunchKernelGGL(rsf_extract_kernel, dim3(grid_for(k)), dim3(256), 0, s, (const u64*)conv2.u(), k, (const int*)sel, d_out);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));   // the temporaries above are freed on return
   return RONK_OK;
 }
 static const size_t RS_FAST_MAX_K = (size_t)1 << 21;

@@ -11,6 +11,13 @@ int hip_fail(hipError_t e, const char* what) {
   return RONK_ERR_HIP;
 }
 
+// an RCCL call failed (or librccl could not be loaded: code < 0, `what` is the whole message); the text goes where the HIP
+// messages go (ronk_last_hip_error)
+int rccl_fail(int code, const char* what) {
+  g_hip_err = code < 0 ? std::string(what) : std::string(what) + ": ncclResult_t " + std::to_string(code);
+  return RONK_ERR_RCCL;
+}
+
 extern "C" const char* ronk_strerror(int code) {
   switch (code) {
     case RONK_OK: return "ok";
@@ -25,6 +32,7 @@ extern "C" const char* ronk_strerror(int code) {
     case RONK_ERR_UNSUPPORTED: return "size not supported by this kernel";
     case RONK_ERR_NO_DEVICE: return "no HIP device (libronk_ntt has no CPU path)";
     case RONK_ERR_NOT_ON_CURVE: return "Point is not on curve";
+    case RONK_ERR_RCCL: return "RCCL error";
     default: return "unknown error";
   }
 }

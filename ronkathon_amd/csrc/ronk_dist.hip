@@ -2,9 +2,10 @@
 //   * ronk_dist_*      one rank's local phases; the exchange between them is the caller's all-to-all (one process per
 //                      GPU: ronkathon_amd/dist.py issues it through torch.distributed = RCCL over xGMI)
 //   * ronk_sharded_*   the whole sharded transform inside the library for a single-process host (the Rust host of
-//                      BASELINE config 5): one compute and one copy stream per device, the exchange as a mesh of
-//                      hipMemcpyPeerAsync copies over xGMI, column chunks so that chunk j is on the links while chunk
-//                      j+1 is still being computed (SURVEY.md 8e "overlap")
+//                      BASELINE config 5): one compute stream and one copy stream PER PEER per device, the exchange as a
+//                      mesh of hipMemcpyPeerAsync copies over xGMI -- or as RCCL send/recv groups (librccl dlopen()ed) --
+//                      in column chunks so that chunk j is on the links while chunk j+1 is still being computed
+//                      (SURVEY.md 8e "overlap")
 #include "runtime.h"
 
 // ------------------------------------------------------------------------------ multi-GPU four-step
@@ -71,25 +72,89 @@ extern "C" int ronk_dist_phase2_dev(ronk_dist_plan* pl, const uint64_t* d_recv, 
 
 // ------------------------------------------------------------------------------ sharded transform, single process
 // Rank g = devices[g].  Per rank: phase-1 plan (compiled for chunk 0; chunk j shifts the twiddle's column offset),
-// phase-2 plan, scratch, send and receive buffers (n/W elements each), a compute stream and a copy stream.
-//   compute_g :  phase 1 chunk 0 | chunk 1 | ... | (wait: every rank's copies have landed) phase 2
-//   copy_g    :        (wait chunk 0) W copies | (wait chunk 1) W copies | ...
-// Buffers are reused by the next call: the copies of call k+1 wait for every phase 2 of call k (recv), and phase 1 of
-// call k+1 waits for the copies of call k on its own device (send) -- all by events, nothing blocks the host.
+// phase-2 plan, scratch, send and receive buffers (n/W elements each), a compute stream and ONE COPY STREAM PER PEER:
+// the W copies of a chunk leave on W streams, so all xGMI links of the device (point-to-point, one per peer) carry data
+// at the same time instead of one copy queue feeding them one after the other.
+//   compute_g   :  phase 1 chunk 0 | chunk 1 | ... | (wait: every sender's copies to g have landed) phase 2
+//   copy_g[h]   :        (wait chunk 0) block for h | (wait chunk 1) block for h | ...
+// Buffers are reused by the next call: the copies of call k+1 into rank h wait for phase 2 of call k on h (recv), and
+// phase 1 of call k+1 waits for the copies of call k out of its own device (send) -- all by events, nothing blocks the host.
+//
+// Exchange = RONK_EXCHANGE_RCCL: the same chunk schedule with the W x W blocks of a chunk as ONE RCCL group of
+// ncclSend / ncclRecv pairs (an all-to-all over xGMI the way north_star words it), on one communication stream per device.
+// librccl.so is dlopen()ed on first use -- the library has no link-time dependency on it -- so a host can A/B the peer-copy
+// mesh against RCCL per plan.  Ranks must then sit on distinct devices (one RCCL rank per GPU).
+#include <dlfcn.h>
+
+namespace {
+typedef void* rcclComm_t;
+struct RcclApi {
+  void* handle = nullptr;
+  int (*CommInitAll)(rcclComm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int kNcclUint64 = 5;   // ncclDataType_t::ncclUint64 (rccl.h)
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+std::string g_rccl_err;
+
+// loads librccl once; false (and a message for ronk_last_hip_error) if it is not there or lacks a symbol
+bool rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.ok) return true;
+  if (g_rccl.handle) return false;   // tried before, incomplete
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (g_rccl.handle) break;
+  }
+  if (!g_rccl.handle) { g_rccl_err = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return false; }
+  auto sym = [&](const char* n) { return dlsym(g_rccl.handle, n); };
+  g_rccl.CommInitAll = (int (*)(rcclComm_t*, int, const int*))sym("ncclCommInitAll");
+  g_rccl.CommDestroy = (int (*)(rcclComm_t))sym("ncclCommDestroy");
+  g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
+  g_rccl.Send = (int (*)(const void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclSend");
+  g_rccl.Recv = (int (*)(void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclRecv");
+  g_rccl.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+  g_rccl.ok = g_rccl.CommInitAll && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd && g_rccl.Send && g_rccl.Recv;
+  if (!g_rccl.ok) g_rccl_err = "librccl.so lacks one of ncclCommInitAll / ncclGroupStart / ncclSend / ncclRecv";
+  return g_rccl.ok;
+}
+}  // namespace
+
+int rccl_fail(int code, const char* what);   // ronk_core.hip: records the text, returns RONK_ERR_RCCL
+#define RCCLCHK(call)                                    \
+  do {                                                   \
+    int r_ = (call);                                     \
+    if (r_ != 0) return rccl_fail(r_, #call);            \
+  } while (0)
+
 struct ShardRank {
   int device = 0;
   CompiledPlan p1, p2;
   u64 *tmp = nullptr, *send = nullptr, *recv = nullptr;
   u64 *stage_in = nullptr, *stage_out = nullptr;   // host-pointer entry point only (lazy)
-  hipStream_t compute = nullptr, copy = nullptr;
-  std::vector<hipEvent_t> chunk_done;
-  hipEvent_t sent = nullptr, done = nullptr;
+  hipStream_t compute = nullptr;
+  std::vector<hipStream_t> copy;                   // [W]: the stream that carries blocks for rank h (mesh; one per destination
+                                                   // DEVICE) / [1]: the RCCL stream
+  std::vector<bool> owns;                          // copy[h] was created for h (not an alias of an earlier entry)
+  std::vector<hipEvent_t> chunk_done;              // [chunks]
+  std::vector<hipEvent_t> sent_to;                 // [W]: this rank's blocks for rank h have left (mesh) / [1] (RCCL)
+  hipEvent_t done = nullptr;                       // phase 2 has read the receive buffer
+  rcclComm_t comm = nullptr;
   bool used = false;
 };
 struct ronk_sharded_plan {
   DistShape sh;
   int ndev = 0, chunks = 1;
   bool inverse = false;
+  int exchange = RONK_EXCHANGE_MESH;
   std::vector<ShardRank> r;
   std::mutex mu;
 };
@@ -104,14 +169,18 @@ extern "C" int ronk_sharded_plan_destroy(ronk_sharded_plan* pl) {
   for (auto& k : pl->r) {
     (void)hipSetDevice(k.device);
     if (k.compute) (void)hipStreamSynchronize(k.compute);
-    if (k.copy) (void)hipStreamSynchronize(k.copy);
+    for (size_t h = 0; h < k.copy.size(); h++) if (k.copy[h] && k.owns[h]) (void)hipStreamSynchronize(k.copy[h]);
+  }
+  for (auto& k : pl->r) {
+    (void)hipSetDevice(k.device);
+    if (k.comm && g_rccl.ok) (void)g_rccl.CommDestroy(k.comm);
     k.p1.release(); k.p2.release();
     for (u64* q : {k.tmp, k.send, k.recv, k.stage_in, k.stage_out}) if (q) (void)hipFree(q);
-    for (auto e : k.chunk_done) (void)hipEventDestroy(e);
-    if (k.sent) (void)hipEventDestroy(k.sent);
+    for (auto e : k.chunk_done) if (e) (void)hipEventDestroy(e);
+    for (auto e : k.sent_to) if (e) (void)hipEventDestroy(e);
     if (k.done) (void)hipEventDestroy(k.done);
     if (k.compute) (void)hipStreamDestroy(k.compute);
-    if (k.copy) (void)hipStreamDestroy(k.copy);
+    for (size_t h = 0; h < k.copy.size(); h++) if (k.copy[h] && k.owns[h]) (void)hipStreamDestroy(k.copy[h]);
   }
   delete pl;
   return RONK_OK;
@@ -119,7 +188,13 @@ extern "C" int ronk_sharded_plan_destroy(ronk_sharded_plan* pl) {
 
 extern "C" int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev,
                                         int chunks) {
+  return ronk_sharded_plan_create_ex(out, log2n, inverse, devices, ndev, chunks, RONK_EXCHANGE_MESH);
+}
+
+extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev,
+                                           int chunks, int exchange) {
   if (!out || !devices || ndev < 1) return RONK_ERR_INVALID;
+  if (exchange != RONK_EXCHANGE_MESH && exchange != RONK_EXCHANGE_RCCL) return RONK_ERR_INVALID;
   *out = nullptr;
   if (log2n > 32) return RONK_ERR_NO_ROOT;  // 2-adicity of p - 1 is 32
   DistShape sh;
@@ -129,6 +204,12 @@ extern "C" int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n,
   HIPCHK(hipGetDeviceCount(&ndevices));
   for (int g = 0; g < ndev; g++)
     if (devices[g] < 0 || devices[g] >= ndevices) return RONK_ERR_INVALID;
+  if (exchange == RONK_EXCHANGE_RCCL) {
+    for (int g = 0; g < ndev; g++)
+      for (int h = 0; h < g; h++)
+        if (devices[g] == devices[h]) return RONK_ERR_UNSUPPORTED;   // one RCCL rank per GPU
+    if (!rccl_load()) return rccl_fail(-1, g_rccl_err.c_str());
+  }
   if (chunks <= 0) {   // default: up to 4 chunks (the exchange of chunk j hides under chunks j+1 ..)
     chunks = 4;
     while (chunks > 1 && !dist_chunks_ok(sh, chunks)) chunks >>= 1;
@@ -137,9 +218,10 @@ extern "C" int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n,
   int prev = 0;
   HIPCHK(hipGetDevice(&prev));
   ronk_sharded_plan* pl = new ronk_sharded_plan();
-  pl->sh = sh; pl->ndev = ndev; pl->chunks = chunks; pl->inverse = inverse != 0;
+  pl->sh = sh; pl->ndev = ndev; pl->chunks = chunks; pl->inverse = inverse != 0; pl->exchange = exchange;
   pl->r.resize(ndev);
   const size_t per = (size_t)(sh.n / sh.W);
+  const int ncopy = exchange == RONK_EXCHANGE_RCCL ? 1 : ndev;
   int rc = RONK_OK;
   for (int g = 0; g < ndev && !rc; g++) {
     ShardRank& k = pl->r[g];
@@ -157,18 +239,35 @@ extern "C" int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n,
     if (!rc && e == hipSuccess) e = hipMalloc((void**)&k.send, per * 8);
     if (!rc && e == hipSuccess) e = hipMalloc((void**)&k.recv, per * 8);
     if (!rc && e == hipSuccess) e = hipStreamCreateWithFlags(&k.compute, hipStreamNonBlocking);
-    if (!rc && e == hipSuccess) e = hipStreamCreateWithFlags(&k.copy, hipStreamNonBlocking);
+    // mesh: one copy stream per destination DEVICE (= per xGMI link, plus one for blocks that stay on this device); logical
+    // ranks that share a GPU share the stream -- there is one link to keep busy, and every extra stream costs queue switches
+    k.copy.assign(ncopy, nullptr); k.sent_to.assign(ncopy, nullptr); k.owns.assign(ncopy, false);
+    for (int h = 0; h < ncopy && !rc && e == hipSuccess; h++) {
+      int same = -1;
+      if (exchange != RONK_EXCHANGE_RCCL)
+        for (int h2 = 0; h2 < h && same < 0; h2++) if (devices[h2] == devices[h]) same = h2;   // an earlier rank on that device
+      if (same >= 0) k.copy[h] = k.copy[same];
+      else { e = hipStreamCreateWithFlags(&k.copy[h], hipStreamNonBlocking); k.owns[h] = e == hipSuccess; }
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&k.sent_to[h], hipEventDisableTiming);
+    }
     k.chunk_done.resize(chunks, nullptr);
     for (int j = 0; j < chunks && !rc && e == hipSuccess; j++) e = hipEventCreateWithFlags(&k.chunk_done[j], hipEventDisableTiming);
-    if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&k.sent, hipEventDisableTiming);
     if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
     if (!rc && e != hipSuccess) rc = hip_fail(e, "sharded plan resources");
+  }
+  if (!rc && exchange == RONK_EXCHANGE_RCCL) {
+    std::vector<rcclComm_t> comms(ndev, nullptr);
+    const int r_ = g_rccl.CommInitAll(comms.data(), ndev, devices);
+    if (r_ != 0) rc = rccl_fail(r_, "ncclCommInitAll");
+    else for (int g = 0; g < ndev; g++) pl->r[g].comm = comms[g];
   }
   (void)hipSetDevice(prev);
   if (rc) { ronk_sharded_plan_destroy(pl); return rc; }
   *out = pl;
   return RONK_OK;
 }
+
+extern "C" int ronk_sharded_plan_exchange(const ronk_sharded_plan* pl) { return pl ? pl->exchange : RONK_ERR_INVALID; }
 
 extern "C" int ronk_sharded_plan_info(const ronk_sharded_plan* pl, uint64_t* rows, uint64_t* cols, uint64_t* per_rank,
                                       int* chunks) {
@@ -183,35 +282,62 @@ extern "C" int ronk_sharded_plan_info(const ronk_sharded_plan* pl, uint64_t* row
 static int sharded_enqueue(ronk_sharded_plan* pl, const uint64_t* const* d_in, uint64_t* const* d_out) {
   const DistShape& sh = pl->sh;
   const int W = pl->ndev, chunks = pl->chunks;
+  const bool rccl = pl->exchange == RONK_EXCHANGE_RCCL;
   const u64 Cwc = sh.Cw / (u64)chunks, blk = sh.Rw * Cwc;
-  // phase 1 + exchange
+  // buffer reuse across calls
   for (int g = 0; g < W; g++) {
     ShardRank& k = pl->r[g];
+    if (!k.used) continue;
     RCHK(on_device(k.device));
-    if (k.used) {
-      HIPCHK(hipStreamWaitEvent(k.compute, k.sent, 0));                 // send buffer: the previous call's copies are out
-      for (int h = 0; h < W; h++) HIPCHK(hipStreamWaitEvent(k.copy, pl->r[h].done, 0));   // recv buffers: phase 2 has read them
-    }
-    for (int j = 0; j < chunks; j++) {
+    for (auto ev : k.sent_to) HIPCHK(hipStreamWaitEvent(k.compute, ev, 0));     // send buffer: the previous call's blocks are out
+    if (rccl) { for (int h = 0; h < W; h++) HIPCHK(hipStreamWaitEvent(k.copy[0], pl->r[h].done, 0)); }   // a group writes every recv buffer
+    else for (int h = 0; h < W; h++) HIPCHK(hipStreamWaitEvent(k.copy[h], pl->r[h].done, 0));           // recv of h: its phase 2 has read it
+  }
+  // phase 1 + exchange, chunk by chunk (chunk-major so that an RCCL group sees every rank's chunk j at once)
+  for (int j = 0; j < chunks; j++) {
+    for (int g = 0; g < W; g++) {
+      ShardRank& k = pl->r[g];
+      RCHK(on_device(k.device));
       u64* piece = k.send + (u64)j * sh.R * Cwc;
       RCHK(k.p1.run(d_in[g] + (u64)j * Cwc, nullptr, piece, k.tmp, k.compute, ~(u64)0, ~(u64)0, 0, (u64)j * Cwc));
       HIPCHK(hipEventRecord(k.chunk_done[j], k.compute));
-      HIPCHK(hipStreamWaitEvent(k.copy, k.chunk_done[j], 0));
+      if (rccl) { HIPCHK(hipStreamWaitEvent(k.copy[0], k.chunk_done[j], 0)); continue; }
       for (int hh = 0; hh < W; hh++) {
         const int h = (g + hh) % W;                                     // start with the local block, then ring order
         u64* dst = pl->r[h].recv + ((u64)g * chunks + j) * blk;
         const u64* src = piece + (u64)h * blk;
-        if (pl->r[h].device == k.device) HIPCHK(hipMemcpyAsync(dst, src, blk * 8, hipMemcpyDeviceToDevice, k.copy));
-        else HIPCHK(hipMemcpyPeerAsync(dst, pl->r[h].device, src, k.device, blk * 8, k.copy));
+        HIPCHK(hipStreamWaitEvent(k.copy[h], k.chunk_done[j], 0));
+        if (pl->r[h].device == k.device) HIPCHK(hipMemcpyAsync(dst, src, blk * 8, hipMemcpyDeviceToDevice, k.copy[h]));
+        else HIPCHK(hipMemcpyPeerAsync(dst, pl->r[h].device, src, k.device, blk * 8, k.copy[h]));
       }
     }
-    HIPCHK(hipEventRecord(k.sent, k.copy));
+    if (rccl) {
+      // one group: rank g sends block h of its chunk to rank h and receives block (h, j) from rank h
+      RCCLCHK(g_rccl.GroupStart());
+      int r_ = 0;
+      for (int g = 0; g < W && !r_; g++) {
+        ShardRank& k = pl->r[g];
+        const u64* piece = k.send + (u64)j * sh.R * Cwc;
+        for (int h = 0; h < W && !r_; h++) {
+          r_ = g_rccl.Send(piece + (u64)h * blk, (size_t)blk, kNcclUint64, h, k.comm, k.copy[0]);
+          if (!r_) r_ = g_rccl.Recv(k.recv + ((u64)h * chunks + j) * blk, (size_t)blk, kNcclUint64, h, k.comm, k.copy[0]);
+        }
+      }
+      const int r2 = g_rccl.GroupEnd();
+      if (r_) return rccl_fail(r_, "ncclSend / ncclRecv");
+      if (r2) return rccl_fail(r2, "ncclGroupEnd");
+    }
   }
-  // phase 2: every rank waits for every sender
+  for (int g = 0; g < W; g++) {
+    ShardRank& k = pl->r[g];
+    RCHK(on_device(k.device));
+    for (size_t h = 0; h < k.copy.size(); h++) HIPCHK(hipEventRecord(k.sent_to[h], k.copy[h]));
+  }
+  // phase 2: rank h waits for what was sent TO IT (mesh: one event per sender; RCCL: every rank's communication stream)
   for (int h = 0; h < W; h++) {
     ShardRank& k = pl->r[h];
     RCHK(on_device(k.device));
-    for (int g = 0; g < W; g++) HIPCHK(hipStreamWaitEvent(k.compute, pl->r[g].sent, 0));
+    for (int g = 0; g < W; g++) HIPCHK(hipStreamWaitEvent(k.compute, pl->r[g].sent_to[rccl ? 0 : h], 0));
     RCHK(k.p2.run(k.recv, nullptr, d_out[h], k.tmp, k.compute));
     HIPCHK(hipEventRecord(k.done, k.compute));
     k.used = true;
@@ -238,8 +364,10 @@ extern "C" int ronk_sharded_sync(ronk_sharded_plan* pl) {
   HIPCHK(hipGetDevice(&prev));
   int rc = RONK_OK;
   for (auto& k : pl->r) {
-    if (hipSetDevice(k.device) != hipSuccess || hipStreamSynchronize(k.copy) != hipSuccess ||
-        hipStreamSynchronize(k.compute) != hipSuccess) { rc = hip_fail(hipGetLastError(), "ronk_sharded_sync"); break; }
+    bool ok = hipSetDevice(k.device) == hipSuccess;
+    for (size_t h = 0; h < k.copy.size(); h++) if (k.owns[h]) ok = ok && hipStreamSynchronize(k.copy[h]) == hipSuccess;
+    ok = ok && hipStreamSynchronize(k.compute) == hipSuccess;
+    if (!ok) { rc = hip_fail(hipGetLastError(), "ronk_sharded_sync"); break; }
   }
   (void)hipSetDevice(prev);
   return rc;

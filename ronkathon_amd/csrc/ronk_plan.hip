@@ -26,7 +26,6 @@ extern "C" int ronk_plan_destroy(ronk_plan* pl) {
   if (pl->st_h2d) (void)hipStreamDestroy(pl->st_h2d);
   if (pl->st_d2h) (void)hipStreamDestroy(pl->st_d2h);
   if (pl->st_exec) (void)hipStreamDestroy(pl->st_exec);
-  if (pl->h_pin) (void)hipHostFree(pl->h_pin);
   delete pl;
   return RONK_OK;
 }
@@ -336,12 +335,78 @@ static int ensure_stage(ronk_plan* pl) {
   if (!pl->d_stage_out) HIPCHK(hipMalloc((void**)&pl->d_stage_out, bytes));
   return RONK_OK;
 }
+// Host-pointer transforms.  One polynomial: upload, transform, download -- the link is used one way at a time and the
+// transform itself (0.06 ms at 2^22) hides nowhere: 2 x 32 MiB at the measured 56 GB/s (pageable and pinned host memory copy
+// at the same rate on this platform, tools/pcie_probe.hip) is 1.19 ms of the 1.25.  A BATCH is pipelined over its
+// polynomials on three internal streams -- upload of slice i+1, transform of slice i and download of slice i-1 overlap
+// (PCIe is full duplex: 48 GB/s each way when both directions are busy), so the cost per polynomial drops from
+// upload + download to the slower of the two.  Slices are whole polynomials, at least 4 MiB, at most 64 per call.
+static int transform_host_pipelined(ronk_plan* pl, bool inverse, const u64* in, u64* out) {
+  const CompiledPlan& cp = inverse ? pl->inv : pl->fwd;
+  const u64 n = pl->n;
+  u64 per = ((u64)4 << 20) / (n * 8);                      // polynomials per slice
+  if (per < 1) per = 1;
+  if ((pl->batch + per - 1) / per > 64) per = (pl->batch + 63) / 64;
+  const u32 nsl = (u32)((pl->batch + per - 1) / per);
+  if (!pl->st_h2d) HIPCHK(hipStreamCreateWithFlags(&pl->st_h2d, hipStreamNonBlocking));
+  if (!pl->st_exec) HIPCHK(hipStreamCreateWithFlags(&pl->st_exec, hipStreamNonBlocking));
+  if (!pl->st_d2h) HIPCHK(hipStreamCreateWithFlags(&pl->st_d2h, hipStreamNonBlocking));
+  while (pl->st_ev.size() < 2 * (size_t)nsl) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    pl->st_ev.push_back(e);
+  }
+  HIPCHK(hipStreamSynchronize(0));                          // earlier null-stream users of the staging buffers / the scratch
+  // Asynchronous copies need page-locked host memory: a hipMemcpyAsync from pageable memory returns only when the copy
+  // is done (measured: the three streams then run strictly one after the other, 1.30 ms per 2^22 polynomial).  The caller's
+  // buffers are registered for the duration of the call (cheap on this platform: tools/pcie_probe.hip) and released
+  // again; buffers that are already page-locked (hipHostMalloc, an earlier registration) are used as they are, and if a
+  // registration is refused the copies simply fall back to their synchronous behaviour.
+  const size_t total_bytes = (size_t)(pl->batch * n * 8);
+  const bool reg_in = hipHostRegister(const_cast<u64*>(in), total_bytes, hipHostRegisterDefault) == hipSuccess;
+  if (!reg_in) (void)hipGetLastError();
+  const bool reg_out = hipHostRegister(out, total_bytes, hipHostRegisterDefault) == hipSuccess;
+  if (!reg_out) (void)hipGetLastError();
+  int rc = RONK_OK;
+  for (u32 i = 0; i < nsl && !rc; i++) {
+    const u64 b0 = (u64)i * per, cnt = pl->batch - b0 < per ? pl->batch - b0 : per;
+    const size_t off = (size_t)(b0 * n), bytes = (size_t)(cnt * n * 8);
+    hipEvent_t ev_in = pl->st_ev[2 * i], ev_done = pl->st_ev[2 * i + 1];
+    hipError_t e = hipMemcpyAsync(pl->d_stage_in + off, in + off, bytes, hipMemcpyHostToDevice, pl->st_h2d);
+    if (e == hipSuccess) e = hipEventRecord(ev_in, pl->st_h2d);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pl->st_exec, ev_in, 0);
+    if (e != hipSuccess) { rc = hip_fail(e, "upload"); break; }
+    rc = cp.run_slice((u32)b0, (u32)cnt, pl->d_stage_in, nullptr, pl->d_stage_out, pl->d_tmp, pl->st_exec);
+    if (rc) break;
+    e = hipEventRecord(ev_done, pl->st_exec);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pl->st_d2h, ev_done, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + off, pl->d_stage_out + off, bytes, hipMemcpyDeviceToHost, pl->st_d2h);
+    if (e != hipSuccess) rc = hip_fail(e, "download");
+  }
+  // drain all three before returning (also on errors: nothing may still touch the caller's buffers)
+  hipError_t e1 = hipStreamSynchronize(pl->st_h2d), e2 = hipStreamSynchronize(pl->st_exec), e3 = hipStreamSynchronize(pl->st_d2h);
+  if (!rc && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
+    rc = hip_fail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3, "pipeline drain");
+  if (reg_in) (void)hipHostUnregister(const_cast<u64*>(in));
+  if (reg_out) (void)hipHostUnregister(out);
+  return rc;
+}
+
 static int transform_host(ronk_plan* pl, bool inverse, const u64* in, u64* out) {
   if (!pl || !in || !out) return RONK_ERR_INVALID;
   std::lock_guard<std::mutex> lk(pl->mu);
   HIPCHK(hipSetDevice(pl->device));
   RCHK(ensure_stage(pl));
   const size_t bytes = pl->n * pl->batch * 8;
+  static const bool no_pipe = getenv("RONK_HOST_NO_PIPELINE") != nullptr;   // A/B
+  if (!no_pipe && pl->fast && (inverse ? pl->inv : pl->fwd).sliceable() && bytes >= ((size_t)8 << 20)) {
+    // the pipeline owns the scratch for the duration of the call: order it against other streams' users like any transform
+    std::lock_guard<std::mutex> lk2(pl->stream_mu);
+    if (pl->scratch_used) (void)hipDeviceSynchronize();
+    const int rc = transform_host_pipelined(pl, inverse, in, out);
+    pl->scratch_used = false;                               // everything has drained
+    return rc;
+  }
   HIPCHK(hipMemcpy(pl->d_stage_in, in, bytes, hipMemcpyHostToDevice));
   RCHK(transform_dev(pl, inverse, pl->d_stage_in, nullptr, pl->d_stage_out, 0));
   HIPCHK(hipMemcpy(out, pl->d_stage_out, bytes, hipMemcpyDeviceToHost));
@@ -443,7 +508,9 @@ static int cache_get(u64 p, u64 g, u32 log2n, CacheEntry** out) {
       *out = e;
       return RONK_OK;
     }
-  if (g_cache.size() >= 8) {  // evict the least recently used entry nobody holds (its work must have drained)
+  // 24 entries: a Newton division (ronk_callers.hip) walks a ladder of ~2 log2(n) product sizes -- 8 entries made every
+  // large division rebuild all of its plans
+  if (g_cache.size() >= 24) {  // evict the least recently used entry nobody holds (its work must have drained)
     size_t lru = g_cache.size();
     for (size_t i = 0; i < g_cache.size(); i++)
       if (g_cache[i]->pins == 0 && (lru == g_cache.size() || g_cache[i]->stamp < g_cache[lru]->stamp)) lru = i;

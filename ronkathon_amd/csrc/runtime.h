@@ -235,9 +235,7 @@ struct ronk_plan {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   u64* d_tmp2 = nullptr;
-  // pinned staging ring of the host-pointer entry points (ronk_plan.hip transform_host)
-  void* h_pin = nullptr;
-  size_t h_pin_bytes = 0;
+  // the three streams and per-slice events of the pipelined host-pointer transform (ronk_plan.hip transform_host)
   hipStream_t st_h2d = nullptr, st_d2h = nullptr, st_exec = nullptr;
   std::vector<hipEvent_t> st_ev;
 };

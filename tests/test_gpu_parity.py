@@ -542,6 +542,32 @@ def test_sharded_transform_inside_the_library(R, orc):
     assert e.value.code == -7
 
 
+def test_sharded_rccl_exchange(R, orc):
+    """RONK_EXCHANGE_RCCL: the exchange as ncclGroup{ncclSend, ncclRecv} through a dlopen()ed librccl -- on every visible GPU
+    (one rank per device; with a single GPU: one rank that sends to itself), chunked and unchunked, twice per plan; logical
+    ranks sharing a device are refused.  Same values as the peer-copy mesh and the oracle."""
+    from ronkathon_amd import _lib as L
+    ndev = R.device_count()
+    W = 1
+    while W * 2 <= ndev and W < 8:
+        W *= 2
+    for log2n, chunks in ((16, 1), (20, 2), (22, 0)):
+        x = splitmix_field(0x5EED0650 + log2n, 1 << log2n)
+        ref = orc.fft(GP, GG, x)
+        sp = L.ShardedPlan(log2n, list(range(W)), chunks=chunks, exchange=L.EXCHANGE_RCCL)
+        assert L.lib.ronk_sharded_plan_exchange(sp.h) == L.EXCHANGE_RCCL
+        assert np.array_equal(sp.transform(x), ref), (log2n, W, chunks)
+        assert np.array_equal(sp.transform(x), ref)
+        sp.close()
+        sm = L.ShardedPlan(log2n, list(range(W)), chunks=chunks)
+        assert L.lib.ronk_sharded_plan_exchange(sm.h) == L.EXCHANGE_MESH
+        assert np.array_equal(sm.transform(x), ref)
+        sm.close()
+    with pytest.raises(R.RonkPanic) as e:
+        L.ShardedPlan(16, [0, 0], exchange=L.EXCHANGE_RCCL)
+    assert e.value.code == -9
+
+
 def test_sharded_device_api_pipelines_calls(R, orc):
     """ronk_ntt_sharded_dev: device-resident column blocks in, [C][R/W] blocks out; two transforms enqueued back to back
     on the plan's own streams, then one sync"""
