@@ -181,6 +181,9 @@ RONK_HD void st_out(u64* p, u64 v) {
 //           twiddle, no scale, full tiles only
 //   KIND 3  column pass whose inter-pass twiddle is the full matrix [k][col] (plan.h maybe_full_table; it stays
 //           L2-resident up to 2^18 entries: the batched 2^16 shape)
+//   KIND 4  general twiddled pass (the phases of the multi-GPU four-step, plan.h build_dist_phase1/2): unit column strides
+//           and a two-level output twiddle omega_N^{X*Y} whose X / Y coefficients (column, b2, offsets) stay run-time scalars;
+//           rows flat or blocked (the receive buffer of the exchange)
 // KIND != 0 also means NARROW addressing: every lane offset fits 32 bits IN BYTES (n*8 < 2^32), so global accesses
 // are the `global_load v, v_off, s[base:base+1]` form with offsets built from 32-bit adds.
 // LOGC >= 0 fixes the tile width (LDS addresses become immediates); -1 = run-time.
@@ -193,12 +196,19 @@ RONK_HD void st_out(u64* p, u64 v) {
 // streams).  Costs two more barriers per exchange and 32-bit instead of 64-bit LDS instructions; same bank pattern
 // (ds_*_b32: 32-lane groups over 32 banks, ds_*_b64: 32-lane groups over 64 banks -- both need the 32 lanes' cell
 // indices distinct mod 32).
-template <int LOGC_, int KIND_, bool LDSTW_ = false, bool HALF_ = false>
+// FEAT (KIND != 0): what a specialised pass carries beyond the plain shape -- the pieces of a polynomial multiply and of a
+// batched Reed-Solomon encode.  A feature that is NOT in the mask is compiled out; one that is must be present at launch.
+//   FEAT_IN_VALID   implicit zero padding of the input (in_valid / in_valid1)
+//   FEAT_IN2        second operand, pointwise product fused into the load
+//   FEAT_OUT_VALID  truncated output
+constexpr int FEAT_IN_VALID = 1, FEAT_IN2 = 2, FEAT_OUT_VALID = 4;
+template <int LOGC_, int KIND_, bool LDSTW_ = false, bool HALF_ = false, int FEAT_ = 0>
 struct TileCfg {
   static constexpr int LOGC = LOGC_;
   static constexpr int KIND = KIND_;
   static constexpr bool LDSTW = LDSTW_;
   static constexpr bool HALF = HALF_;
+  static constexpr int FEAT = FEAT_;
 };
 // which specialised instantiations stage their round twiddles in LDS (launcher, emulator and kernel agree through this).
 // MEASURED AND SWITCHED OFF (round 2, 2^22, 2^11 x 8 tiles, the only shape where 16 KiB fit beside the image without
@@ -213,22 +223,37 @@ constexpr bool cfg_ldstw(int logr, int logc, int kind) {
   return RONK_LDS_TWIDDLES && logr == 11 && logc == 3 && (kind == 1 || kind == 2);
 }
 
-inline bool tile_cfg_matches(const TileArgs& a, int logr, int logc, int kind) {
+// features a launch carries (see FEAT_* above)
+inline int tile_features(const TileArgs& a) {
+  return (a.in_valid != ~(u64)0 || a.in_valid1 != ~(u64)0 ? FEAT_IN_VALID : 0) | (a.in2 ? FEAT_IN2 : 0) |
+         (a.out_valid != ~(u64)0 ? FEAT_OUT_VALID : 0);
+}
+
+inline bool tile_cfg_matches(const TileArgs& a, int logr, int logc, int kind, int feat = 0) {
   const u64 C = (u64)1 << a.logc, R = (u64)1 << logr;
   if (logc >= 0 && a.logc != (u32)logc) return false;
   if (kind == 0) return true;
-  const bool common = !a.stage_io && !a.in2 && a.in_valid == ~(u64)0 && a.out_valid == ~(u64)0 && a.scale == 1 &&
-                      a.nb2 == 1 && a.ncols % C == 0 && a.tiles == a.ncols / C;
+  if (tile_features(a) != feat) return false;
+  const bool common = !a.stage_io && a.scale == 1 && a.ncols % C == 0 && a.tiles == a.ncols / C && !a.xb1 && !a.yb1 &&
+                      (kind == 4 || (!a.xb2 && !a.yb2));
   if (!common) return false;
-  // largest lane offset (elements) on either side must stay below 2^29
-  const u64 span = R * a.ncols;
-  if (span >= ((u64)1 << 29)) return false;
+  // NARROW addressing: the largest lane offset on either side (elements, relative to the tile's base) stays below 2^29
+  const auto mag = [](i64 v) { return (u64)(v < 0 ? -v : v); };
+  const u64 in_span = a.js_log < 31 ? (R >> a.js_log) * mag(a.in_sj_hi) + (((u64)1 << a.js_log) - 1) * mag(a.in_sj) + (C - 1) * mag(a.in_sc)
+                                    : (R - 1) * mag(a.in_sj) + (C - 1) * mag(a.in_sc);
+  const u64 out_span = (R - 1) * mag(a.out_sk) + (C - 1) * mag(a.out_sc);
+  const u64 lim = (u64)1 << 29;
+  if (in_span >= lim || out_span >= lim) return false;
+  // the padding / truncation limits are compared in bytes against 64-bit sums: any size; (b2, tile) bases are 64-bit scalars
   const bool colpass = a.js_log == 31 && a.in_sc == 1 && a.out_sc == 1 && a.tw_log > 0 && a.tw_log <= 29 && a.xc == 1 &&
-                       a.yk == 1 && !a.xb1 && !a.xb2 && !a.x0 && !a.yb1 && !a.yb2 && !a.y0 && a.in_sj > 0 && a.out_sk > 0;
+                       a.yk == 1 && !a.x0 && !a.y0 && a.in_sj > 0 && a.out_sk > 0;
+  if (kind == 4)
+    return !a.tw_full && a.in_sc == 1 && a.out_sc == 1 && a.tw_log > 0 && a.tw_log <= 29 && a.in_sj > 0 && a.out_sk > 0 &&
+           (a.js_log == 31 || a.in_sj_hi > 0);
   if (kind == 1) return colpass && !a.tw_full;
-  if (kind == 3) return colpass && a.tw_full && a.tf_sc == 1 && a.tf_sb2 == 0 && a.tf_sk == a.ncols;
+  if (kind == 3) return colpass && a.tw_full && a.tf_sc == 1 && a.tf_sb2 == 0 && a.tf_sk == a.ncols && R * a.ncols < lim;
   if (kind == 2)
-    return !a.tw_full && a.js_log < 31 && (R / 16) >= ((u64)1 << a.js_log) && a.in_sj == 1 && a.out_sc == 1 &&
+    return !a.tw_full && (a.js_log == 31 || (R / 16) >= ((u64)1 << a.js_log)) && a.in_sj == 1 && a.out_sc == 1 &&
            a.tw_log == 0 && a.in_sc > 0 && a.out_sk > 0;
   return false;
 }
@@ -274,13 +299,18 @@ RONK_HD TileCtx tile_ctx(const TileArgs& a_in, u32 tid, u32 bid) {
   a = a_in;                                      // what the instantiation knows replaces what the launch says
   if constexpr (CFG::LOGC >= 0) a.logc = CFG::LOGC;
   if constexpr (KIND != 0) {
-    a.stage_io = 0; a.in2 = nullptr; a.in_valid = a.out_valid = a.in_valid1 = ~(u64)0; a.scale = 1;
+    a.stage_io = 0; a.scale = 1;
+    if constexpr (!(CFG::FEAT & FEAT_IN2)) a.in2 = nullptr;
+    if constexpr (!(CFG::FEAT & FEAT_IN_VALID)) a.in_valid = a.in_valid1 = ~(u64)0;
+    if constexpr (!(CFG::FEAT & FEAT_OUT_VALID)) a.out_valid = ~(u64)0;
     if constexpr (KIND != 3) a.tw_full = nullptr;
-    a.nb2 = 1; a.in_sb2 = a.out_sb2 = 0; a.out_sc = 1;
-    a.xb1 = a.xb2 = a.x0 = a.yb1 = a.yb2 = a.y0 = 0;
+    a.out_sc = 1;                                // (nb2 / in_sb2 / out_sb2 stay run-time: the middle and last pass of a three-pass plan)
+    a.xb1 = a.yb1 = 0;
+    if constexpr (KIND != 4) a.xb2 = a.x0 = a.yb2 = a.y0 = 0;
     a.ncols = (u64)a.tiles << a.logc;
   }
   if constexpr (KIND == 1 || KIND == 3) { a.js_log = 31; a.in_sc = 1; a.xc = 1; a.yk = 1; }
+  if constexpr (KIND == 4) a.in_sc = 1;
   if constexpr (KIND == 3) { a.tf_sc = 1; a.tf_sb2 = 0; a.tf_sk = (u32)a.ncols; }
   if constexpr (KIND == 2) { a.in_sj = 1; a.tw_log = 0; }
 
@@ -367,9 +397,11 @@ RONK_HD void tile_load(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barri
   } else if (ABL & 16) {
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = (u64)(tid * 16 + i);
-  } else if (live && a.in_valid != ~(u64)0) {
-    const u64 lin0 = (u64)b2 * (u64)a.in_sb2 + (u64)t * (u64)a.in_st;
-    const u64 valid = (b1 && a.in_valid1 != ~(u64)0) ? a.in_valid1 : a.in_valid;
+  } else if (live && (a.in_valid != ~(u64)0 || a.in_valid1 != ~(u64)0)) {
+    // joff is in bytes when NARROW: compare in that unit (an unlimited polynomial -- ~0 -- stays unlimited)
+    const u64 lin0 = ((u64)b2 * (u64)a.in_sb2 + (u64)t * (u64)a.in_st) << SH;
+    const u64 valid_e = (b1 && a.in_valid1 != ~(u64)0) ? a.in_valid1 : a.in_valid;
+    const u64 valid = valid_e >= ((u64)1 << 60) ? ~(u64)0 : valid_e << SH;
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = (lin0 + joff[i] < valid) ? ld_g<NARROW>(in, joff[i]) : 0;
   } else if (live) {
@@ -549,7 +581,8 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
   const u32 lmask = (1u << a.tw_lo_bits) - 1;
   const u64* const tf = (KIND == 3 || a.tw_full) ? a.tw_full : nullptr;
   const u32 tf_lane = (col * a.tf_sc + b2 * a.tf_sb2) << SH, tf_sk = a.tf_sk << SH;
-  const u64 lin_out0 = (u64)b2 * (u64)a.out_sb2 + (u64)t * (u64)a.out_st;
+  const u64 lin_out0 = ((u64)b2 * (u64)a.out_sb2 + (u64)t * (u64)a.out_st) << SH;   // in the unit of the lane offsets
+  const u64 out_valid = a.out_valid >= ((u64)1 << 60) ? ~(u64)0 : a.out_valid << SH;
   u64 keep = 0;
   if (a.stage_io && Q > 1) barrier();                      // every lane has read its last-round rows: LDS is free
 #pragma unroll
@@ -636,7 +669,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
       for (int i = 0; i < GSZ; i++) {
         const u32 ci = (Q == 1) ? (u32)brev(i, 4) : (u32)((R / RLAST) * brev(i, LOGLAST));
         const u32 off = obase + ci * out_sk;
-        if (a.out_valid == ~(u64)0 || lin_out0 + off < a.out_valid) st_g<NARROW>(outp, off, xg[i]);
+        if (out_valid == ~(u64)0 || lin_out0 + off < out_valid) st_g<NARROW>(outp, off, xg[i]);
       }
     }
   }

@@ -231,7 +231,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     // contiguous 512-byte runs.  Only the two passes see this layout.
     // Measured tile preference, applied when the tile width is left to the planner: when a pass has
     // many tiles per CU (>= 4 of the largest size), tiles of 8192 coefficients -- two resident workgroups per CU, in
-    // different phases -- beat 16384 (2^20 x 64: 0.961 -> 0.826 ms, 2^22 x 16: 1.04 -> 0.925); with one tile per CU
+    // different phases -- beat 16384 for 2^10-row passes (2^20 x 64: 0.961 -> 0.826 ms); with one tile per CU
     // (a single 2^22 transform) the large tile stays better, and for 2^8 / 2^9-row passes C = 16 stays best.
     const bool many_tiles = auto_tiles && (double)batch * (double)n / 16384.0 >= 1024.0;
     // Latency regime (ntt_small.h): the whole batch is at most 2^19 coefficients -- with 16 coefficients per work-item that
@@ -242,8 +242,12 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     bool small = auto_tiles && batch * n <= ((u64)1 << 19) && ka <= 10 && kb <= 10;
     if (const char* e = getenv("RONK_SMALL")) small = atoi(e) != 0 && ka <= 10 && kb <= 10;
     int lc1 = max_logc, lc2 = max_logc;
-    if (many_tiles && ka >= 10 && ka <= 11 && lc1 > 13 - ka) lc1 = 13 - ka;
-    if (many_tiles && kb >= 10 && kb <= 11 && lc2 > 13 - kb) lc2 = 13 - kb;
+    // Round 3, re-measured with the specialised kernels and HBM-cold buffers (bench.py --mode batch --rotate 8, same box,
+    // profiles/r03_planner_sweep.txt): 2^10-row passes keep the 8192-coefficient tiles (2^20 x 64: 92.3 k NTT/s against
+    // 78.4 k with 16 columns), but 2^11-row passes are better off with the full 16384-coefficient tile (2^22 x 16: 20.9 k
+    // against 19.2 k with 4 columns; 2^21 x 32: 47.5 k / 47.3 k) -- a 4-column tile reads 32-byte row segments.
+    if (many_tiles && ka == 10 && lc1 > 3) lc1 = 3;
+    if (many_tiles && kb == 10 && lc2 > 3) lc2 = 3;
     // Few tiles (one transform of 2^20 / 2^21, small batches of them): narrower tiles until every CU has one -- a pass of 64
     // workgroups leaves three quarters of the chip idle (2^20: 47.1 -> 29.8 us, 2^21: 50.5 -> 41.1 us with 4-column tiles).
     if (auto_tiles && !small) {

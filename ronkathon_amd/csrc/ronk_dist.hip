@@ -293,9 +293,15 @@ static int sharded_enqueue(ronk_sharded_plan* pl, const uint64_t* const* d_in, u
     if (rccl) { for (int h = 0; h < W; h++) HIPCHK(hipStreamWaitEvent(k.copy[0], pl->r[h].done, 0)); }   // a group writes every recv buffer
     else for (int h = 0; h < W; h++) HIPCHK(hipStreamWaitEvent(k.copy[h], pl->r[h].done, 0));           // recv of h: its phase 2 has read it
   }
-  // phase 1 + exchange, chunk by chunk (chunk-major so that an RCCL group sees every rank's chunk j at once)
-  for (int j = 0; j < chunks; j++) {
-    for (int g = 0; g < W; g++) {
+  // phase 1 + exchange.  Chunk-major (every device gets its chunk 0 before any device gets chunk 1: the host's enqueue
+  // time is spread over the devices, and an RCCL group sees every rank's chunk j at once); rank-major only when all the
+  // ranks are logical ranks on ONE device, where interleaving them just multiplies the cross-stream waits.
+  bool one_device = !rccl;
+  for (int g = 1; g < W; g++) one_device = one_device && pl->r[g].device == pl->r[0].device;
+  const int outer = one_device ? W : chunks, inner = one_device ? chunks : W;
+  for (int o = 0; o < outer; o++) {
+    for (int i = 0; i < inner; i++) {
+      const int j = one_device ? i : o, g = one_device ? o : i;
       ShardRank& k = pl->r[g];
       RCHK(on_device(k.device));
       u64* piece = k.send + (u64)j * sh.R * Cwc;
@@ -312,6 +318,7 @@ static int sharded_enqueue(ronk_sharded_plan* pl, const uint64_t* const* d_in, u
       }
     }
     if (rccl) {
+      const int j = o;
       // one group: rank g sends block h of its chunk to rank h and receives block (h, j) from rank h
       RCCLCHK(g_rccl.GroupStart());
       int r_ = 0;

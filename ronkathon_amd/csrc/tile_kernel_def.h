@@ -10,7 +10,7 @@ namespace ronk {
 
 // Workgroup = 2^LOGR * C / 16 work-items (<= 1024), dynamic LDS = (2^LOGR + 2^LOGR/16) * C * 8 bytes (<= 136 KiB of the
 // CU's 160 KiB).
-template <int LOGR, bool INV, int LOGC, int KIND, bool HALF>
+template <int LOGR, bool INV, int LOGC, int KIND, bool HALF, int FEAT = 0>
 __device__ __forceinline__ void tile_kernel_main(const TileArgs& a, u64* lds) {
   // The dispatcher hands workgroup b to XCD b % 8 (observed, for speed only): renumber so that
   // each XCD works on a contiguous run of tiles -- neighbouring tiles share 128-byte lines and
@@ -18,7 +18,31 @@ __device__ __forceinline__ void tile_kernel_main(const TileArgs& a, u64* lds) {
   const u32 nb = gridDim.x, b = blockIdx.x;
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND, !HALF && cfg_ldstw(LOGR, LOGC, KIND), HALF>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+  tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND, !HALF && !FEAT && cfg_ldstw(LOGR, LOGC, KIND), HALF, FEAT>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+}
+
+// the shapes with features (tile_cfg_table.h RONK_CFG_TABLE_FEAT; tile_kernels_feat.hip)
+template <int LOGR, bool INV, int LOGC, int KIND, int FEAT>
+__global__ void __launch_bounds__(1024) ntt_tile_kernel_feat(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  tile_kernel_main<LOGR, INV, LOGC, KIND, false, FEAT>(a, lds);
+}
+template <int LOGR, bool INV, int LOGC, int KIND, int FEAT>
+static hipError_t launch_one_feat(const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s) {
+  static bool attr_done[64] = {};
+  if (lds > 48 * 1024) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      e = hipFuncSetAttribute((const void*)ntt_tile_kernel_feat<LOGR, INV, LOGC, KIND, FEAT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((ntt_tile_kernel_feat<LOGR, INV, LOGC, KIND, FEAT>), dim3(grid), dim3(block), lds, s, a);
+  return hipGetLastError();
 }
 
 template <int LOGR, bool INV, int LOGC, int KIND>
@@ -66,6 +90,9 @@ static hipError_t launch_one(const TileArgs& a, u32 grid, u32 block, size_t lds,
 // tile_kernels_cfg.hip: launches the specialised instantiation for (logr, a.logc, kind) if there is one; *found says so
 hipError_t launch_tile_cfg(int logr, bool inverse, int kind, const TileArgs& a, u32 grid, u32 block, size_t lds,
                            hipStream_t s, bool* found);
+// tile_kernels_feat.hip: the shapes with features (zero-padded input, fused second operand, truncated output)
+hipError_t launch_tile_cfg_feat(int logr, bool inverse, int kind, int feat, const TileArgs& a, u32 grid, u32 block, size_t lds,
+                                hipStream_t s, bool* found);
 // tile_kernels_half.hip: the same shapes with two-phase 32-bit LDS exchanges (TileCfg::HALF; `lds` is the full-size
 // image, the launcher halves it)
 hipError_t launch_tile_cfg_half(int logr, bool inverse, int kind, const TileArgs& a, u32 grid, u32 block, size_t lds,

@@ -42,10 +42,16 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
                        hipStream_t s) {
   static const bool no_cfg = getenv("RONK_NO_CFG_KERNELS") != nullptr;   // experiments: force the generic kernels
   if (!no_cfg) {
-    for (int kind : {1, 2, 3}) {
-      if (!tile_cfg_matches(a, logr, (int)a.logc, kind)) continue;
+    const int feat = tile_features(a);
+    for (int kind : {1, 2, 3, 4}) {
+      if (!tile_cfg_matches(a, logr, (int)a.logc, kind, feat)) continue;
       bool found = false;
-      if (use_half(a, logr, grid, block, kind)) {
+      if (feat) {
+        hipError_t e = launch_tile_cfg_feat(logr, inverse, kind, feat, a, grid, block, lds, s, &found);
+        if (found) return e;
+        continue;
+      }
+      if (kind != 4 && use_half(a, logr, grid, block, kind)) {
         hipError_t e = launch_tile_cfg_half(logr, inverse, kind, a, grid, block, lds, s, &found);
         if (found) return e;
       }

@@ -18,6 +18,7 @@ namespace ronk {
 hipError_t launch_tile_cfg(int logr, bool inverse, int kind, const TileArgs& a, u32 grid, u32 block, size_t lds,
                            hipStream_t s, bool* found) {
   RONK_CFG_TABLE(RONK_CFG_CASE)
+  RONK_CFG_TABLE_DIST(RONK_CFG_CASE)
   *found = false;
   return hipSuccess;
 }

@@ -55,6 +55,18 @@ static bool dispatch_cfg(int logr, u32 tid) {
     RONK_CFG_TABLE(EMU_HALF_CASE)
 #undef EMU_HALF_CASE
   }
+  {
+    const int feat = tile_features(a);
+#define EMU_FEAT_CASE(LR, LC, KD, FT)                                                            \
+  if (logr == LR && (int)a.logc == LC && feat == FT && tile_cfg_matches(a, LR, LC, KD, FT)) {    \
+    tile_body<LR, INV, 0, TileCfg<LC, KD, false, false, FT>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
+    g_cfg_used = KD + 100 * FT;                                                                  \
+    return true;                                                                                 \
+  }
+    RONK_CFG_TABLE_FEAT(EMU_FEAT_CASE)
+#undef EMU_FEAT_CASE
+    if (feat) return false;
+  }
 #define EMU_CFG_CASE(LR, LC, KD)                                                                 \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
     tile_body<LR, INV, 0, TileCfg<LC, KD, cfg_ldstw(LR, LC, KD)>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
@@ -62,6 +74,7 @@ static bool dispatch_cfg(int logr, u32 tid) {
     return true;                                                                                 \
   }
   RONK_CFG_TABLE(EMU_CFG_CASE)
+  RONK_CFG_TABLE_DIST(EMU_CFG_CASE)
 #undef EMU_CFG_CASE
   return false;
 }
@@ -131,6 +144,7 @@ static u64 splitmix(u64& s) {
   return z ^ (z >> 31);
 }
 
+static int g_dist_cfg = 0, g_dist_generic = 0;   // passes of the dist mode that ran a specialised / the generic body
 static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64* tmp) {
   std::vector<u64> lds;
   for (auto& p : pd.passes) {
@@ -143,10 +157,12 @@ static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64*
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
     lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);   // + room for the LDS-staged round twiddles
+    g_cfg_used = 0;
     for (u32 bid = 0; bid < p.grid; bid++) {
       g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = inv; g_fa.small = p.small;
       run_block(p.block);
     }
+    (g_cfg_used ? g_dist_cfg : g_dist_generic)++;
   }
 }
 
@@ -187,6 +203,7 @@ static int dist_main(int log2n, int world, bool inv, int chunks) {
   if (rc) return 1;
   for (u64 i = 0; i < n; i++)
     if (got[i] != ref[i]) { printf("DIST MISMATCH at %llu\n", (unsigned long long)i); return 1; }
+  printf("passes: specialised=%d generic=%d\n", g_dist_cfg, g_dist_generic);
   printf("OK dist log2n=%d world=%d inv=%d chunks=%d\n", log2n, world, (int)inv, chunks);
   return 0;
 }
@@ -206,6 +223,7 @@ int main(int argc, char** argv) {
   u64 in_valid = argc > 7 ? strtoull(argv[7], 0, 10) : 0, out_valid = argc > 8 ? strtoull(argv[8], 0, 10) : 0;
   bool auto_tiles = argc > 9 && atoi(argv[9]) != 0;   // the planner's own per-pass tile rules (ronk_plan_create's default)
   u64 in_valid1 = argc > 10 ? strtoull(argv[10], 0, 10) : 0;   // TileArgs::in_valid1: the limit of batch entries >= 1 (paired multiply operands)
+  const bool with_in2 = argc > 11 && atoi(argv[11]) != 0;      // TileArgs::in2: a second operand multiplied in on load (fused pointwise product)
   PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
@@ -214,6 +232,12 @@ int main(int argc, char** argv) {
   // adversarial corners
   in[0] = gl64::P - 1; if (n > 1) in[n - 1] = gl64::P - 1; if (n > 2) in[1] = 0;
 
+  std::vector<u64> in2;
+  if (with_in2) {
+    in2.resize(n * batch);
+    for (auto& v : in2) { do v = splitmix(s); while (v >= gl64::P); }
+    in2[0] = gl64::P - 1; in2[n - 1] = 0;
+  }
   std::vector<u64> lds;
   for (auto& p : pd.passes) {
     TileArgs a = p.args;
@@ -224,6 +248,7 @@ int main(int argc, char** argv) {
     a.wr = pd.wr[p.wr_id].data();
     if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
     if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
+    if (with_in2 && p.in_buf == BUF_IN) a.in2 = in2.data();
     if (in_valid && p.in_buf == BUF_IN) a.in_valid = in_valid;
     if (in_valid1 && p.in_buf == BUF_IN) a.in_valid1 = in_valid1;
     if (out_valid && p.out_buf == BUF_OUT) a.out_valid = out_valid;
@@ -236,9 +261,11 @@ int main(int argc, char** argv) {
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
            g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
-           g_cfg_used == 12 ? "half:row" : p.small ? "small" : "generic");
+           g_cfg_used == 12 ? "half:row" : g_cfg_used >= 100 ? (g_cfg_used % 100 == 2 ? "feat:row" : g_cfg_used % 100 == 3 ? "feat:column/matrix" : "feat:column/two-level") :
+           p.small ? "small" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = (b && in_valid1) ? in_valid1 : in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
+  if (with_in2) for (u64 i = 0; i < n * batch; i++) in[i] = gl64::mul(in[i], in2[i]);
   for (u64 b = 0; b < batch; b++) {
     int rc = inv ? orc_ifft(gl64::P, 7, &in[b * n], &ref[b * n], n) : orc_fft(gl64::P, 7, &in[b * n], &ref[b * n], n);
     if (rc) { printf("oracle rc %d\n", rc); return 1; }

@@ -163,3 +163,32 @@ def test_paired_multiply_operands(emu, args):
     """TileArgs::in_valid1: a batch of two whose entries have different zero-padding limits (the two operands of a
     polynomial multiply transformed by one pair of launches) -- small kernel, tile kernel with 4-column tiles, tile kernel"""
     run(emu, *args)
+
+
+@pytest.mark.parametrize("k", [23, 24, 25])
+def test_three_pass_plans_run_the_specialised_bodies(emu, k):
+    """2^23 .. : column pass (two-level twiddle) / middle pass (full matrix, one transform per row of the first split) /
+    last pass (flat rows) all match a TileCfg shape now that nb2 is a run-time value there"""
+    for inv in (0, 1):
+        out = subprocess.run([emu, str(k), "1", str(inv), "4", "18", "23"], capture_output=True, text=True, timeout=1800)
+        lines = out.stdout.strip().splitlines()
+        assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+        kinds = [l.split("kernel=")[1] for l in lines if l.startswith("pass")]
+        assert kinds == ["cfg:column/two-level", "cfg:column/matrix", "cfg:row"], out.stdout
+
+
+@pytest.mark.parametrize("args,kinds", [
+    ((20, 2, 0, 2, 18, 25, 300000, 0, 0, 700001), ("feat:column/two-level", "cfg:row")),          # multiply: both operands, zero padded
+    ((22, 2, 0, 2, 18, 25, 2097152, 0, 0, 2097152), ("feat:column/two-level", "cfg:row")),
+    ((20, 1, 1, 4, 18, 25, 0, 1000001, 1, 0, 1), ("feat:column/two-level", "feat:row")),            # its inverse: fused product in, truncated out
+    ((21, 1, 1, 4, 18, 25, 0, 2097151, 1, 0, 1), ("feat:column/two-level", "feat:row")),
+    ((22, 1, 1, 4, 18, 25, 0, 4194303, 1, 0, 1), ("feat:column/two-level", "feat:row")),
+    ((16, 16, 0, 4, 18, 25, 32768, 0, 1), ("feat:column/matrix", "cfg:row")),                       # batched Reed-Solomon encode
+])
+def test_feature_kernels(emu, args, kinds):
+    """TileCfg::FEAT: the passes of a polynomial multiply and of a batched encode on compile-time-specialised bodies (byte-scaled
+    padding / truncation limits, second operand through the narrow addressing)"""
+    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=1800)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-600:]
+    assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == list(kinds), out.stdout
