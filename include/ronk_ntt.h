@@ -100,7 +100,8 @@ int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, ui
 /* Same with planner tuning (-1 = default): tile_log2_columns = log2 of the widest tile (columns per workgroup;
  * default 4 -> one 128 KiB-LDS workgroup per CU at 2^11 rows, best for one transform at a time; 2 -> two
  * workgroups per CU, better when several transforms are in flight on different streams);
- * twiddle_matrix_log2_max = largest full inter-pass twiddle matrix (default 18 = L2-resident only). */
+ * twiddle_matrix_log2_max = largest full inter-pass twiddle matrix (default: 18 = L2-resident only, and the whole matrix
+ * at 2^21 / 2^22 points, where it pays for its extra read). */
 int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                            int tile_log2_columns, int twiddle_matrix_log2_max);
 /* Same through an options block (start from RONK_PLAN_OPTS_DEFAULT, then set what you need; -1 = default everywhere).

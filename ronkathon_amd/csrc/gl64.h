@@ -54,7 +54,11 @@ RONK_HD u64 canon(u64 x) { return x + ((x >= P) ? EPS : 0); }
 // prime/arithmetic.rs:3-7.  a, b < p: a wrapped sum (s < a) or s >= p both mean "subtract p"
 RONK_HD u64 add(u64 a, u64 b) {
   u64 s = a + b;
+#ifdef RONK_GL64_ALL_LAZY   // tools/census.hip only: instruction-count upper bound for deferred canonicalisation (WRONG values)
+  return s + ((s < a) ? EPS : 0);
+#else
   return s + ((s < a || s >= P) ? EPS : 0);
+#endif
 }
 
 // h*EPS + t for a 32-bit h and ANY 64-bit t, canonical.  The sum wraps at most once (h*EPS <= 2^64 - 2^33 + 1) and

@@ -600,7 +600,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
-    if (tf && !(ABL & 1)) {
+    if ((KIND == 3 || tf) && !(ABL & 1)) {   // KIND 3: the matrix is there by construction (tile_cfg_matches): no second variant in the binary
       if (live) {  // dead columns of a ragged tile hold zeros anyway
         // HALF kernels are built for 64 VGPRs: at most 8 table entries in flight at a time
         constexpr int WCH = (CFG::HALF && GSZ > 8) ? 8 : GSZ;

@@ -101,7 +101,12 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // Full inter-pass twiddle matrix (one coalesced load + one multiply instead of two gathers + two
     // multiplies) while it stays L2-resident: up to 2^18 entries = 2 MiB.  Larger matrices would add an
     // n-element HBM read per transform (measured +4 % speed at 2^22 for +25 % traffic): left to RONK_TWF_MAX_LOG.
-    int twf_max_log = 18;
+    // Round 3 (specialised kernels, HBM-cold buffers, same-box A/B/A/B: profiles/r03_twf_ab.txt): at 2^21 and 2^22 the
+    // matrix is worth its n-element read after all -- pass 1 executes 139 instead of 158 VALU per coefficient and drops two
+    // table gathers per coefficient: one 2^21 transform 42.3 -> 36.8 us, one 2^22 transform 56.5 -> 52.9 us, 2^22 with two
+    // lanes 23.1 k -> 23.8 k NTT/s (2^20: 27.9 -> 28.7 us, slower: left alone).  64 MiB of tables per 2^22 plan (both
+    // directions) out of 288 GB.
+    int twf_max_log = (log2n == 21 || log2n == 22) ? (int)log2n : 18;
     if (const char* e = getenv("RONK_TWF_MAX_LOG")) { int v = atoi(e); if (v >= 0 && v <= 26) twf_max_log = v; }
     if (twiddle_matrix_log2_max >= 0 && twiddle_matrix_log2_max <= 26) twf_max_log = twiddle_matrix_log2_max;
     // Two passes up to 2^22; from 2^23 three passes are faster although they move 1.5x the bytes: a two-pass plan
@@ -477,6 +482,7 @@ extern "C" int ronk_plan_time_passes(ronk_plan* pl, const uint64_t* d_in, uint64
 // buffers for the multiply; an event orders successive uses of an entry across streams.
 
 struct CacheEntry {
+  ronk_plan* pli = nullptr;          // the multiply's own inverse plan when it wants other planner options than `pl` (lazy)
   ronk_plan* pl = nullptr;
   u64 *fa = nullptr, *fb = nullptr;  // poly_mul operands, n elements each (lazy)
   ronk_plan* pl2 = nullptr;          // the same size with batch 2: both operands of a multiply in ONE pair of launches (lazy)
@@ -494,6 +500,7 @@ static void cache_entry_free(CacheEntry* e) {
   if (e->fa) (void)hipFree(e->fa);
   if (e->fb) (void)hipFree(e->fb);
   if (e->pl2) ronk_plan_destroy(e->pl2);
+  if (e->pli) ronk_plan_destroy(e->pli);
   if (e->fab) (void)hipFree(e->fab);
   if (e->done) (void)hipEventDestroy(e->done);
   delete e;
@@ -685,13 +692,24 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     // tiles run under the arithmetic of the other's -- what two streams do for independent transforms.
     // (from 2^20 on with 4-column tiles, two workgroups per CU: the configuration that lets two transforms overlap)
     // (2^19 .. 2^22: that plan runs its two polynomials on two streams, ronk_plan::in_flight)
-    if (!e->pl2) RCHK(k >= 20 ? ronk_plan_create_tuned(&e->pl2, p, g, (u32)k, 2, pl->device, 2, -1)
+    // Inter-pass twiddles of the multiply's plans: A/B knobs RONK_MUL_FWD_TWF / RONK_MUL_INV_TWF (log2 of the largest full
+    // matrix; default: see below)
+    static const int fwd_twf = [] { const char* e_ = getenv("RONK_MUL_FWD_TWF"); return e_ ? atoi(e_) : -2; }();
+    static const int inv_twf = [] { const char* e_ = getenv("RONK_MUL_INV_TWF"); return e_ ? atoi(e_) : -2; }();
+    // measured (round 3, 2^22, same box: profiles/r03_mul_twf_ab.txt): matrix for both the forward pair and the inverse 167 us,
+    // for either one alone or for neither 152 us (two 32 MiB matrices plus the operands do not stay cached together); at
+    // 2^21 all four within 1 %.  Default: the forward pair keeps the two-level tables at 2^22, the inverse runs the cached
+    // plan as it is.
+    const int ftw = fwd_twf != -2 ? fwd_twf : (k == 22 ? 18 : -1), itw = inv_twf != -2 ? inv_twf : -1;
+    if (!e->pl2) RCHK(k >= 20 ? ronk_plan_create_tuned(&e->pl2, p, g, (u32)k, 2, pl->device, 2, ftw)
                               : ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
+    if (itw >= 0 && !e->pli) RCHK(ronk_plan_create_tuned(&e->pli, p, g, (u32)k, 1, pl->device, -1, itw));
+    ronk_plan* const plinv = e->pli ? e->pli : pl;
     if (!e->fab) HIPCHK(hipMalloc((void**)&e->fab, 2 * N * 8));
     HIPCHK(hipStreamWaitEvent(s, e->done, 0));
     const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
     RCHK(transform_dev(e->pl2, false, d_a, nullptr, e->fab, s, (u64)d, ~(u64)0, stride, (u64)d2));
-    RCHK(transform_dev(pl, true, e->fab, e->fab + N, d_out, s, ~(u64)0, (u64)m));
+    RCHK(transform_dev(plinv, true, e->fab, e->fab + N, d_out, s, ~(u64)0, (u64)m));
     HIPCHK(hipEventRecord(e->done, s));
     return RONK_OK;
   }

@@ -20,6 +20,6 @@
 // transform of a multiply, first pass), 4 = truncated output (its last pass).  NTT sizes 2^20 .. 2^22 of the multiply; the
 // 1024 x 2^16 encode.
 #define RONK_CFG_TABLE_FEAT(X)                                                                \
-  X(10, 2, 1, 1) X(11, 2, 1, 1) X(8, 4, 3, 1)                                                 \
-  X(10, 2, 1, 2) X(11, 2, 1, 2) X(11, 3, 1, 2)                                                \
+  X(10, 2, 1, 1) X(11, 2, 1, 1) X(11, 2, 3, 1) X(8, 4, 3, 1)                                  \
+  X(10, 2, 1, 2) X(11, 2, 1, 2) X(11, 3, 1, 2) X(11, 2, 3, 2) X(11, 3, 3, 2)                  \
   X(10, 2, 2, 4) X(10, 3, 2, 4) X(11, 3, 2, 4)

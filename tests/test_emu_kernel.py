@@ -192,3 +192,19 @@ def test_feature_kernels(emu, args, kinds):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-600:]
     assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == list(kinds), out.stdout
+
+
+@pytest.mark.parametrize("args,kinds", [
+    ((22, 1, 0, 4, 22, 25, 0, 0, 1), ("cfg:column/matrix", "cfg:row")),                        # the library default at 2^22 / 2^21
+    ((21, 1, 1, 4, 21, 25, 0, 0, 1), ("cfg:column/matrix", "cfg:row")),
+    ((22, 2, 0, 2, 22, 25, 2097152, 0, 0, 2097152), ("feat:column/matrix", "cfg:row")),        # ... and the multiply on it
+    ((22, 1, 1, 4, 22, 25, 0, 4194303, 1, 0, 1), ("feat:column/matrix", "feat:row")),
+    ((21, 1, 1, 4, 21, 25, 0, 2097151, 1, 0, 1), ("feat:column/matrix", "feat:row")),
+])
+def test_full_twiddle_matrix_at_2_21_and_2_22(emu, args, kinds):
+    """ronk_plan_create's default from round 3: the whole inter-pass twiddle matrix at 2^21 / 2^22 (KIND 3 shapes), also under
+    the multiply's features"""
+    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=1800)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-600:]
+    assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == list(kinds), out.stdout

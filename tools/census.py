@@ -9,15 +9,16 @@ FAST = {'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_and_b32', 'v_or_b32', 'v_xo
         'v_lshrrev_b32', 'v_accvgpr_write_b32', 'v_accvgpr_read_b32'}
 def main():
     out = '/tmp/census.s'
-    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
-                           '-I' + os.path.join(ROOT, 'include'), '-o', out, os.path.join(ROOT, 'tools/census.hip')],
+    extra = (['-DRONK_CENSUS_BREAKDOWN'] if '--breakdown' in sys.argv else []) + (['-DRONK_CENSUS_ALL_LAZY'] if '--all-lazy' in sys.argv else [])
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only'] + extra +
+                          ['-I' + os.path.join(ROOT, 'include'), '-o', out, os.path.join(ROOT, 'tools/census.hip')],
                           stderr=subprocess.DEVNULL)
     s = open(out).read()
     tot = {}
     for m in re.finditer(r'^(_Z\w*census_kernel\w+):.*?s_endpgm(.*?)\.end_amdhsa_kernel', s, re.S | re.M):
         name = m.group(1)
         body = m.group(0)
-        tag = re.search(r'ILi(\d+)ELb(\d)ELi(\d)', name).groups()
+        tag = re.search(r'ILi(\d+)ELb(\d)ELi(\d)ELi(\d+)', name).groups()
         ins = [l.split() for l in body.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
         c = Counter(i[0] for i in ins)
         valu = sum(n for k, n in c.items() if k.startswith('v_'))
@@ -25,21 +26,28 @@ def main():
         nops = sum(int(i[1]) + 1 for i in ins if i[0] == 's_nop')
         vg = re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)
         sp = re.search(r'; ScratchSize: (\d+)', s[m.end():m.end() + 3000])
-        print('R=2^%s mode %s: VALU %5d (%.1f/coef)  slots %7.1f (%.1f/coef)  s_nop states %4d  mov %d  vgpr %s scratch %s' % (
-            tag[0], tag[2], valu, valu / 16, slots, slots / 16, nops, c.get('v_mov_b32_e32', 0), vg, sp.group(1) if sp else '?'))
-        tot.setdefault(tag[0], [0, 0.0])
-        tot[tag[0]][0] += valu; tot[tag[0]][1] += slots
+        print('R=2^%s mode %s abl %s: VALU %5d (%.1f/coef)  slots %7.1f (%.1f/coef)  s_nop states %4d  mov %d  vgpr %s scratch %s' % (
+            tag[0], tag[2], tag[3], valu, valu / 16, slots, slots / 16, nops, c.get('v_mov_b32_e32', 0), vg, sp.group(1) if sp else '?'))
+        if tag[3] != '0':
+            continue                       # breakdown instantiations: listed, not summed
+        # a transform = one column pass + one row pass: 'two-level' sums modes 0 + 1, 'matrix' sums modes 3 + 1
+        for variant, modes in (('two-level', '01'), ('matrix', '31')):
+            if tag[2] in modes:
+                t_ = tot.setdefault((tag[0], variant), [0, 0.0])
+                t_[0] += valu; t_[1] += slots
         if '-v' in sys.argv:
             print('   ', dict(c.most_common(25)))
-    for k, (v, sl) in tot.items():
-        print('transform with 2^%s passes: VALU/coef %.1f  slots/coef %.1f' % (k, v / 16, sl / 16))
+    for (k, variant), (v, sl) in sorted(tot.items()):
+        print('transform with 2^%s passes, inter-pass twiddle %-9s: VALU/coef %.1f  slots/coef %.1f' % (k, variant, v / 16, sl / 16))
     if '--write' in sys.argv:   # profiles/latest_census.json: bench.py's roofline.valu (secondary, VALU-issue ceiling)
         import json
         sys.path.insert(0, ROOT)
         import bench
-        v, sl = tot['11']
+        v, sl = tot[('11', 'matrix')]
         with open(os.path.join(ROOT, 'profiles', 'latest_census.json'), 'w') as f:
-            json.dump({'kernel_source_hash': bench.kernel_source_hash(), 'workload': 'ntt22 (two 2^11-row passes, C = 8)',
+            json.dump({'kernel_source_hash': bench.kernel_source_hash(),
+                       'workload': 'ntt22 (two 2^11-row passes, C = 8, full inter-pass twiddle matrix: the library default at 2^22)',
+                       'two_level_variant': {'valu_per_coeff': tot[('11', 'two-level')][0] / 16, 'slots_per_coeff': tot[('11', 'two-level')][1] / 16},
                        'valu_per_coeff': v / 16, 'slots_per_coeff': sl / 16,
                        'how': 'tools/census.py: static count of the executed path of tools/census.hip (plan flags fixed at '
                               'compile time), weights 1.0 (simple 32-bit VALU) / 1.6 (everything else) from tools/instr_rate.hip'},
