@@ -31,11 +31,14 @@ static hipError_t launch_dir(int logr, const TileArgs& a, u32 grid, u32 block, s
 //   default  column passes (KIND 1, 3) of any size and row passes (KIND 2) up to 2^9 rows, when the grid has at least
 //            twice the threads the chip holds at four waves per SIMD (2 * 256 CUs * 1024)
 //   RONK_HALF_LDS = 0 never, 1 always, 2 row passes only (experiments)
-static bool use_half(const TileArgs&, int logr, u32 grid, u32 block, int kind) {
+//   round 3 (planner: big batches keep 16384-coefficient tiles for 2^11-row passes; HBM-cold sweep, profiles/r03_half_rule_sweep.txt):
+//            a 2^11-row x 8-column row pass owns a whole CU (136 KiB) -- there the half image pays as well (2^22 x 16: 21.5 k ->
+//            22.5 k NTT/s); 2^10-row row passes stay on the full image (2^21 x 32: 49.9 k with the rule, 48.4 k all-half)
+static bool use_half(const TileArgs& a, int logr, u32 grid, u32 block, int kind) {
   static const int mode = [] { const char* e = getenv("RONK_HALF_LDS"); return e ? atoi(e) : -1; }();
   if (mode >= 0) return mode == 1 || (mode == 2 && kind == 2);
   if ((unsigned long long)grid * block < 2ull * 256 * 1024) return false;
-  return kind != 2 || logr <= 9;
+  return kind != 2 || logr <= 9 || (logr == 11 && a.logc == 3);
 }
 
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds,
