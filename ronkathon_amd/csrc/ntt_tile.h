@@ -181,6 +181,8 @@ RONK_HD void st_out(u64* p, u64 v) {
 //           twiddle, no scale, full tiles only
 //   KIND 3  column pass whose inter-pass twiddle is the full matrix [k][col] (plan.h maybe_full_table; it stays
 //           L2-resident up to 2^18 entries: the batched 2^16 shape)
+//   KIND 5  whole-polynomial pass (single-pass plans, n = R <= 2^12: the batch is the column axis): rows contiguous, column
+//           stride R on both sides (compile-time), no twiddle; the scale of the inverse and a ragged last tile stay run-time
 //   KIND 4  general twiddled pass (the phases of the multi-GPU four-step, plan.h build_dist_phase1/2): unit column strides
 //           and a two-level output twiddle omega_N^{X*Y} whose X / Y coefficients (column, b2, offsets) stay run-time scalars;
 //           rows flat or blocked (the receive buffer of the exchange)
@@ -234,6 +236,9 @@ inline bool tile_cfg_matches(const TileArgs& a, int logr, int logc, int kind, in
   if (logc >= 0 && a.logc != (u32)logc) return false;
   if (kind == 0) return true;
   if (tile_features(a) != feat) return false;
+  if (kind == 5)   // whole polynomials side by side; any scale, ragged last tile allowed
+    return !a.stage_io && !a.tw_log && !a.tw_full && a.js_log == 31 && a.in_sj == 1 && a.out_sk == 1 && a.in_sc == (i64)R &&
+           a.out_sc == (i64)R && a.nb1 == 1 && a.nb2 == 1 && a.tiles == (a.ncols + C - 1) / C && R * C < ((u64)1 << 28);
   const bool common = !a.stage_io && a.scale == 1 && a.ncols % C == 0 && a.tiles == a.ncols / C && !a.xb1 && !a.yb1 &&
                       (kind == 4 || (!a.xb2 && !a.yb2));
   if (!common) return false;
@@ -247,6 +252,7 @@ inline bool tile_cfg_matches(const TileArgs& a, int logr, int logc, int kind, in
   // the padding / truncation limits are compared in bytes against 64-bit sums: any size; (b2, tile) bases are 64-bit scalars
   const bool colpass = a.js_log == 31 && a.in_sc == 1 && a.out_sc == 1 && a.tw_log > 0 && a.tw_log <= 29 && a.xc == 1 &&
                        a.yk == 1 && !a.x0 && !a.y0 && a.in_sj > 0 && a.out_sk > 0;
+  if (kind == 5) return false;   // (matched before `common`: see tile_cfg_matches_whole)
   if (kind == 4)
     return !a.tw_full && a.in_sc == 1 && a.out_sc == 1 && a.tw_log > 0 && a.tw_log <= 29 && a.in_sj > 0 && a.out_sk > 0 &&
            (a.js_log == 31 || a.in_sj_hi > 0);
@@ -299,15 +305,21 @@ RONK_HD TileCtx tile_ctx(const TileArgs& a_in, u32 tid, u32 bid) {
   a = a_in;                                      // what the instantiation knows replaces what the launch says
   if constexpr (CFG::LOGC >= 0) a.logc = CFG::LOGC;
   if constexpr (KIND != 0) {
-    a.stage_io = 0; a.scale = 1;
+    a.stage_io = 0;
+    if constexpr (KIND != 5) a.scale = 1;
     if constexpr (!(CFG::FEAT & FEAT_IN2)) a.in2 = nullptr;
     if constexpr (!(CFG::FEAT & FEAT_IN_VALID)) a.in_valid = a.in_valid1 = ~(u64)0;
     if constexpr (!(CFG::FEAT & FEAT_OUT_VALID)) a.out_valid = ~(u64)0;
     if constexpr (KIND != 3) a.tw_full = nullptr;
-    a.out_sc = 1;                                // (nb2 / in_sb2 / out_sb2 stay run-time: the middle and last pass of a three-pass plan)
+    if constexpr (KIND != 5) a.out_sc = 1;       // (nb2 / in_sb2 / out_sb2 stay run-time: the middle and last pass of a three-pass plan)
     a.xb1 = a.yb1 = 0;
     if constexpr (KIND != 4) a.xb2 = a.x0 = a.yb2 = a.y0 = 0;
-    a.ncols = (u64)a.tiles << a.logc;
+    if constexpr (KIND != 5) a.ncols = (u64)a.tiles << a.logc;
+  }
+  if constexpr (KIND == 5) {
+    a.js_log = 31; a.in_sj = 1; a.out_sk = 1; a.in_sc = a.out_sc = (i64)1 << LOGR; a.tw_log = 0; a.tw_full = nullptr;
+    a.nb1 = a.nb2 = 1; a.in_sb1 = a.in_sb2 = a.out_sb1 = a.out_sb2 = 0;
+    a.in_st = a.out_st = ((i64)1 << LOGR) << a.logc;
   }
   if constexpr (KIND == 1 || KIND == 3) { a.js_log = 31; a.in_sc = 1; a.xc = 1; a.yk = 1; }
   if constexpr (KIND == 4) a.in_sc = 1;
@@ -330,7 +342,7 @@ RONK_HD TileCtx tile_ctx(const TileArgs& a_in, u32 tid, u32 bid) {
   x.out = a.out + (i64)x.b1 * a.out_sb1 + (i64)x.b2 * a.out_sb2 + (i64)x.t * a.out_st;
   x.in_sj = (u32)a.in_sj << SH; x.out_sk = (u32)a.out_sk << SH;
   x.in_lane = x.c * ((u32)a.in_sc << SH); x.out_lane = x.c * ((u32)a.out_sc << SH);
-  x.live = KIND != 0 ? true : x.col < a.ncols;  // ragged last tile: dead columns compute on zeros
+  x.live = (KIND != 0 && KIND != 5) ? true : x.col < a.ncols;  // ragged last tile: dead columns compute on zeros
   return x;
 }
 

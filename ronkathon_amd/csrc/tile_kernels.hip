@@ -46,7 +46,7 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
   static const bool no_cfg = getenv("RONK_NO_CFG_KERNELS") != nullptr;   // experiments: force the generic kernels
   if (!no_cfg) {
     const int feat = tile_features(a);
-    for (int kind : {1, 2, 3, 4}) {
+    for (int kind : {1, 2, 3, 4, 5}) {
       if (!tile_cfg_matches(a, logr, (int)a.logc, kind, feat)) continue;
       bool found = false;
       if (feat) {
@@ -54,7 +54,7 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
         if (found) return e;
         continue;
       }
-      if (kind != 4 && use_half(a, logr, grid, block, kind)) {
+      if (kind < 4 && use_half(a, logr, grid, block, kind)) {
         hipError_t e = launch_tile_cfg_half(logr, inverse, kind, a, grid, block, lds, s, &found);
         if (found) return e;
       }

@@ -260,7 +260,7 @@ int main(int argc, char** argv) {
     }
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
-           g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
+           g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 5 ? "cfg:whole" : g_cfg_used == 4 ? "cfg:general" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
            g_cfg_used == 12 ? "half:row" : g_cfg_used >= 100 ? (g_cfg_used % 100 == 2 ? "feat:row" : g_cfg_used % 100 == 3 ? "feat:column/matrix" : "feat:column/two-level") :
            p.small ? "small" : "generic");
   }

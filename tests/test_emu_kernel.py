@@ -209,3 +209,13 @@ def test_full_twiddle_matrix_at_2_21_and_2_22(emu, args, kinds):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-600:]
     assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == list(kinds), out.stdout
+
+
+@pytest.mark.parametrize("args", [(12, 3, 0, 0), (12, 2, 1, 0), (11, 5, 1, 0), (10, 7, 0, 0), (9, 3, 1, 0), (8, 13, 0, 0), (7, 9, 1, 0), (6, 33, 0, 0)])
+def test_single_pass_plans_run_the_whole_polynomial_body(emu, args):
+    """n = 2^6 .. 2^12 at the planner's own tile widths (max_logc = 0, as ronk_plan_create passes it): KIND 5, forward and
+    inverse (run-time scale), ragged last tiles"""
+    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+    assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == ["cfg:whole"], out.stdout
