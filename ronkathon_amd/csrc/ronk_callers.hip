@@ -22,16 +22,21 @@ struct WsSlot {
   hipStream_t last = nullptr;
   bool used = false;   // ever had work queued
   bool busy = false;   // leased right now
+  bool ev_valid = false;   // `done` was recorded behind the slot's last work
 };
 static std::mutex g_ws_mu;
 static std::vector<WsSlot*> g_ws;
+// Completion events are recorded only once the pool has been seen from a second stream: while every call comes from ONE
+// stream, stream order protects a reused slot and the hipEventRecord per call (~1.5 us of the 12.5 us an evaluate of 2^22
+// coefficients takes end to end) buys nothing.  The stream that triggers the switch simply gets a fresh slot.
+static bool g_ws_multi = false;
 struct WsLease {
   WsSlot* slot = nullptr;
   hipStream_t s = nullptr;
   ~WsLease() {
     if (!slot) return;
-    (void)hipEventRecord(slot->done, s);
     std::lock_guard<std::mutex> lk(g_ws_mu);
+    slot->ev_valid = g_ws_multi && hipEventRecord(slot->done, s) == hipSuccess;
     slot->last = s; slot->used = true; slot->busy = false;
   }
   int acquire(size_t bytes, hipStream_t st) {
@@ -47,11 +52,13 @@ struct WsLease {
       if (w->device != dev) continue;
       on_dev++;
       if (w->busy || w->bytes < need) continue;
-      if (!w->used || w->last == st || hipEventQuery(w->done) == hipSuccess) { slot = w; break; }
+      if (!w->used || w->last == st || (w->ev_valid && hipEventQuery(w->done) == hipSuccess)) { slot = w; break; }
+      g_ws_multi = true;                        // a slot last used by ANOTHER stream: from now on every release leaves an event
       if (!waitable) waitable = w;
     }
     if (!slot && waitable && on_dev >= 32) {  // bound the pool: wait for an old slot instead of growing
-      (void)hipEventSynchronize(waitable->done);
+      if (waitable->ev_valid) (void)hipEventSynchronize(waitable->done);
+      else (void)hipDeviceSynchronize();        // released before the switch to events: nothing to wait on but the device
       slot = waitable;
     }
     if (!slot) {
