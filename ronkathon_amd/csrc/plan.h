@@ -289,6 +289,10 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     b.d.needs_tmp = true;
   } else {
     int ka = (log2n + 2) / 3, kb = (log2n - ka + 1) / 2;
+    // 2^24: (9, 8, 7) instead of the balanced (8, 8, 8) -- the first pass (row stride B*C elements on both sides) is the slow
+    // one of every three-pass plan, and 2^9-row tiles make it 109 instead of 125 us (0.226 -> 0.210 ms; round 3 sweep with the
+    // specialised kernels, profiles/r03_three_pass_splits.txt; 2^25 / 2^26: the balanced split stays best)
+    if (log2n == 24) { ka = 9; kb = 8; }
     if (const char* e = getenv("RONK_SPLIT3")) {   // "ka,kb" (planner experiments)
       int va = 0, vb = 0;
       if (sscanf(e, "%d,%d", &va, &vb) == 2 && va >= 4 && va <= 12 && vb >= 4 && vb <= 12 && log2n - va - vb >= 4 &&

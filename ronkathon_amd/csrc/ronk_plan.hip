@@ -112,7 +112,9 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // Two passes up to 2^22; from 2^23 three passes are faster although they move 1.5x the bytes: a two-pass plan
     // would need 2^12-row tiles of only 4 columns (32-byte row segments) -- 2^24: 0.331 -> 0.291 ms, 2^23 x 8: 1.135 ->
     // 1.027 ms; at 2^22 two passes win (58.9 vs 66.6 us).  RONK_THREE_PASS_FROM overrides.
-    int three_from = 23;
+    // Round 3: with the specialised kernels two passes (2^12 x 2^11) win again at 2^23 for ONE transform (117.7 -> 114.7 us with a
+    // generic first pass, 110 with the (12, 2, 1) shape); batches of 2^23 keep three passes (measured in round 2).
+    int three_from = (log2n == 23 && batch == 1) ? 24 : 23;
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
     rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles));
     if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles));

@@ -12,9 +12,10 @@
   X(7, 5, 2) X(8, 4, 2) X(9, 4, 2) X(10, 4, 2) X(10, 3, 2) X(10, 2, 2) X(11, 3, 2) X(11, 2, 2)
 // Shapes of the multi-GPU four-step phases (plan.h build_dist_phase1 / 2; KIND 4 = general twiddled pass), for the sizes
 // BASELINE config 5 and its neighbours use: 2^26 (R = C = 2^13: passes of 2^7 and 2^6 rows) and 2^24 (R = C = 2^12, one pass per
-// phase).  No HALF variants (tile_kernels_half.hip walks RONK_CFG_TABLE only).
+// phase); (12, 2, 1): the first pass of the single 2^23 transform (2^12 x 2^11).  No HALF variants (tile_kernels_half.hip walks
+// RONK_CFG_TABLE only).
 #define RONK_CFG_TABLE_DIST(X)                                                                \
-  X(7, 5, 4) X(6, 6, 4) X(6, 6, 2) X(12, 2, 4) X(12, 2, 2)                                    \
+  X(7, 5, 4) X(6, 6, 4) X(6, 6, 2) X(12, 2, 4) X(12, 2, 2) X(12, 2, 1)                        \
   X(12, 0, 5) X(11, 0, 5) X(10, 0, 5) X(9, 1, 5) X(8, 2, 5) X(7, 3, 5) X(6, 4, 5)
 // (the last row: KIND 5 = whole-polynomial passes, the single-pass plans n = 2^6 .. 2^12 at the tile widths plan.h picks)
 // The same shapes with FEATURES (TileCfg::FEAT, ntt_tile.h): X(LOGR, LOGC, KIND, FEAT).  1 = zero-padded input (the forward
