@@ -17,6 +17,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ronk_ntt.h"
@@ -257,5 +258,121 @@ inline G1Affine commit(const std::vector<Limbs>& coeffs, const std::vector<G1Aff
   return out;
 }
 }  // namespace bn254
+
+// ---- heap- / device-resident polynomials, plans, the sharded transform ------------------------------------------------
+// The counterpart of rust/ronk-goldilocks/src/device.rs: the reference's Polynomial<B, F, D> stores [F; D] inline
+// (src/polynomial/mod.rs:34-44), which the stack cannot hold at D = 2^22; these carry the same data without a template
+// length and keep it in HBM between operations.  Goldilocks (p = 2^64 - 2^32 + 1, generator 7) only.  Same values and
+// panics as fft (mod.rs:273-323), ifft (:430-484), Mul (arithmetic.rs:97-119), evaluate (mod.rs:133-139), Div by a linear
+// divisor (kzg::open, src/kzg/setup.rs:63-78).
+namespace device {
+constexpr uint64_t P = RONK_GOLDILOCKS_P, G = RONK_GOLDILOCKS_G;
+
+class DevicePoly {
+ public:
+  explicit DevicePoly(size_t len) : len_(len) {
+    void* p = nullptr;
+    check(ronk_dev_alloc(&p, len * 8));
+    ptr_ = static_cast<uint64_t*>(p);
+  }
+  explicit DevicePoly(const std::vector<uint64_t>& coefficients) : DevicePoly(coefficients.size()) {
+    check(ronk_memcpy_h2d(ptr_, coefficients.data(), len_ * 8));
+  }
+  DevicePoly(DevicePoly&& o) noexcept : ptr_(o.ptr_), len_(o.len_) { o.ptr_ = nullptr; }
+  DevicePoly(const DevicePoly&) = delete;
+  DevicePoly& operator=(const DevicePoly&) = delete;
+  ~DevicePoly() { if (ptr_) { ronk_dev_sync(); ronk_dev_free(ptr_); } }
+  size_t size() const { return len_; }
+  uint64_t* data() { return ptr_; }
+  const uint64_t* data() const { return ptr_; }
+  std::vector<uint64_t> to_host() const {
+    std::vector<uint64_t> v(len_);
+    check(ronk_dev_sync());
+    check(ronk_memcpy_d2h(v.data(), ptr_, len_ * 8));
+    return v;
+  }
+  DevicePoly mul(const DevicePoly& rhs) const {            // impl Mul: len + rhs.len - 1 coefficients
+    DevicePoly out(len_ + rhs.len_ - 1);
+    check(ronk_poly_mul_dev(P, G, ptr_, len_, rhs.ptr_, rhs.len_, out.ptr_, nullptr));
+    return out;
+  }
+  uint64_t evaluate(uint64_t x) const {                    // Polynomial::<Monomial>::evaluate
+    DevicePoly y(1);
+    check(ronk_poly_eval_dev(P, ptr_, len_, x, y.ptr_, nullptr));
+    return y.to_host()[0];
+  }
+  // self / [b0, b1] and the remainder's constant term: kzg::open's poly.div([-z, 1])
+  std::pair<DevicePoly, uint64_t> div_linear(uint64_t b0, uint64_t b1) const {
+    DevicePoly q(len_), r(1);
+    check(ronk_poly_div_linear_dev(P, ptr_, len_, b0, b1, q.ptr_, r.ptr_, nullptr));
+    const uint64_t rem = r.to_host()[0];
+    return {std::move(q), rem};
+  }
+
+ private:
+  uint64_t* ptr_ = nullptr;
+  size_t len_ = 0;
+};
+
+// ronk_plan: twiddles + scratch for one (n = 2^log2n, batch); two_lanes = ronk_plan_opts::in_flight = 2
+class Plan {
+ public:
+  Plan(uint32_t log2n, uint64_t batch = 1, bool two_lanes = false) : log2n_(log2n), batch_(batch) {
+    ronk_plan_opts o = RONK_PLAN_OPTS_DEFAULT;
+    if (two_lanes) o.in_flight = 2;
+    check(ronk_plan_create_opts(&h_, P, G, log2n, batch, -1, &o));
+  }
+  Plan(const Plan&) = delete;
+  Plan& operator=(const Plan&) = delete;
+  ~Plan() { if (h_) ronk_plan_destroy(h_); }
+  size_t n() const { return (size_t)1 << log2n_; }
+  int in_flight() const { return ronk_plan_in_flight(h_); }
+  void forward(const DevicePoly& src, DevicePoly& dst) const { check(ronk_ntt_forward_dev(h_, src.data(), dst.data(), nullptr)); }
+  void inverse(const DevicePoly& src, DevicePoly& dst) const { check(ronk_ntt_inverse_dev(h_, src.data(), dst.data(), nullptr)); }
+  // K unrelated polynomials per call: the library keeps two transforms in flight
+  void forward_many(const std::vector<const DevicePoly*>& src, const std::vector<DevicePoly*>& dst) const {
+    std::vector<const uint64_t*> in;
+    std::vector<uint64_t*> out;
+    for (auto* p : src) in.push_back(p->data());
+    for (auto* p : dst) out.push_back(p->data());
+    if (in.size() != out.size()) throw Panic(RONK_ERR_INVALID);
+    check(ronk_ntt_forward_many_dev(h_, in.data(), out.data(), in.size(), nullptr));
+  }
+  // host vectors through the plan (a batch is pipelined over its polynomials: upload | transform | download)
+  std::vector<uint64_t> forward_host(const std::vector<uint64_t>& x) const {
+    if (x.size() != n() * batch_) throw Panic(RONK_ERR_INVALID);
+    std::vector<uint64_t> y(x.size());
+    check(ronk_ntt_forward(h_, x.data(), y.data(), nullptr));
+    return y;
+  }
+
+ private:
+  ronk_plan* h_ = nullptr;
+  uint32_t log2n_;
+  uint64_t batch_;
+};
+
+// ronk_sharded_plan: one transform over `devices` (four-step; exchange = peer-copy mesh or RCCL)
+class ShardedPlan {
+ public:
+  ShardedPlan(uint32_t log2n, const std::vector<int>& devices, bool inverse = false, int chunks = 0, int exchange = RONK_EXCHANGE_MESH)
+      : n_((size_t)1 << log2n) {
+    check(ronk_sharded_plan_create_ex(&h_, log2n, inverse ? 1 : 0, devices.data(), (int)devices.size(), chunks, exchange));
+  }
+  ShardedPlan(const ShardedPlan&) = delete;
+  ShardedPlan& operator=(const ShardedPlan&) = delete;
+  ~ShardedPlan() { if (h_) ronk_sharded_plan_destroy(h_); }
+  std::vector<uint64_t> transform(const std::vector<uint64_t>& x) const {   // natural order in and out
+    if (x.size() != n_) throw Panic(RONK_ERR_INVALID);
+    std::vector<uint64_t> y(n_);
+    check(ronk_ntt_sharded(h_, x.data(), y.data()));
+    return y;
+  }
+
+ private:
+  ronk_sharded_plan* h_ = nullptr;
+  size_t n_;
+};
+}  // namespace device
 
 }  // namespace ronkathon

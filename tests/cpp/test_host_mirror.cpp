@@ -101,6 +101,41 @@ int main() {
     const G1Affine two = commit({Limbs{2, 0, 0, 0}}, {g});
     CHECK(two.x == (Limbs{0xd3c208c16d87cfd3ull, 0xd97816a916871ca8ull, 0x9b85045b68181585ull, 0x030644e72e131a02ull}));
   }
+  // device-resident polynomials, plans with two lanes, the sharded transform (ronkathon::device, the C++ twin of
+  // rust/ronk-goldilocks/src/device.rs): properties only -- this test has no oracle; tests/test_gpu_parity.py and the FFI
+  // replay compare the same entry points against the oracle element by element
+  {
+    using namespace device;
+    const size_t n = (size_t)1 << 16;
+    std::vector<uint64_t> x(n), y2(n);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    for (auto& v : x) { do { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = st; } while (v >= P); }
+    DevicePoly dx(x), dy(n), dz(n);
+    Plan plan(16), lanes(16, 1, true);
+    CHECK(plan.in_flight() == 1 && lanes.in_flight() == 2);
+    plan.forward(dx, dy);
+    plan.inverse(dy, dz);
+    CHECK(dz.to_host() == x);                                       // ifft(fft(x)) == x
+    CHECK(plan.forward_host(x) == dy.to_host());                    // host-pointer and device forms agree
+    DevicePoly da(n), db(n);
+    lanes.forward_many({&dx, &dz}, {&da, &db});                     // two arrays in one call, both equal to fft(x)
+    CHECK(da.to_host() == dy.to_host() && db.to_host() == dy.to_host());
+    // kzg::open: p = q (x - z) + r with r = p(z)
+    const uint64_t z = 0x123456789ABCDEF1ull % P, t = 0xFEEDFACE12345ull;
+    auto qr = dx.div_linear(P - z, 1);
+    CHECK(qr.second == dx.evaluate(z));
+    using F = PrimeField<RONK_GOLDILOCKS_P>;
+    CHECK(F::new_(dx.evaluate(t)) == F::new_(qr.first.evaluate(t)) * (F::new_(t) - F::new_(z)) + F::new_(qr.second));
+    // Mul: evaluation homomorphism
+    std::vector<uint64_t> bsmall(x.begin(), x.begin() + 1000);
+    DevicePoly dbs(bsmall);
+    DevicePoly prod = dx.mul(dbs);
+    CHECK(prod.size() == n + 999);
+    CHECK(F::new_(prod.evaluate(t)) == F::new_(dx.evaluate(t)) * F::new_(dbs.evaluate(t)));
+    // sharded over two logical ranks on device 0 == the single-GPU transform
+    ShardedPlan sp(16, {0, 0});
+    CHECK(sp.transform(x) == dy.to_host());
+  }
   printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }
