@@ -117,3 +117,23 @@ def test_minor_trait_surface_of_the_mirror():
     lag.nodes = np.array([1, 84, 16], dtype=np.uint64)
     p.basis = lag
     assert str(p) == "1*l_1(x) + 2*l_84(x) + 3*l_16(x)"                                    # polynomial/mod.rs:487-501
+
+
+def test_argument_errors_of_the_round_3_entry_points_need_no_device():
+    """ronk_plan_opts / the many-arrays entry points / the exchange selector: invalid arguments are refused before any device
+    work (so this runs in the CPU-only container), and the new error code has a text"""
+    from ronkathon_amd import _lib as L
+    h = C.c_void_p()
+    for bad in (0, 3, -2):
+        opts = L.PlanOpts(-1, -1, bad)
+        assert L.lib.ronk_plan_create_opts(C.byref(h), L.GOLDILOCKS_P, 7, 10, 1, -1, C.byref(opts)) == L.ERR_INVALID
+    assert L.lib.ronk_plan_create_opts(C.byref(h), 101, 2, 3, 1, -1, None) == L.ERR_NO_ROOT          # NULL options = defaults
+    assert L.lib.ronk_plan_in_flight(None) == L.ERR_INVALID
+    assert L.lib.ronk_ntt_forward_many_dev(None, None, None, 2, None) == L.ERR_INVALID
+    devs = (C.c_int * 2)(0, 1)
+    assert L.lib.ronk_sharded_plan_create_ex(C.byref(h), 20, 0, devs, 2, 0, 7) == L.ERR_INVALID       # unknown exchange
+    assert L.lib.ronk_sharded_plan_exchange(None) == L.ERR_INVALID
+    assert L.ERR_RCCL == -12 and L.lib.ronk_strerror(L.ERR_RCCL) == b"RCCL error"
+    opts = L.PlanOpts()
+    assert (opts.tile_log2_columns, opts.twiddle_matrix_log2_max, opts.in_flight, list(opts.reserved)) == (-1, -1, -1, [0] * 5)
+    assert C.sizeof(L.PlanOpts) == 32                                                                  # 8 ints, as in the header
