@@ -597,6 +597,37 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
   const u64 out_valid = a.out_valid >= ((u64)1 << 60) ? ~(u64)0 : a.out_valid << SH;
   u64 keep = 0;
   if (a.stage_io && Q > 1) barrier();                      // every lane has read its last-round rows: LDS is free
+  // Twiddles one group ahead (specialised twiddled passes with more than one group: KIND 1 / 3 / 4).  gfx950 counts vector
+  // loads AND stores on one in-order counter (vmcnt): a twiddle load issued after a group's stores can only be waited for
+  // together with those stores, i.e. with their full trip to memory -- seven times per tile for a 2^9-row pass (eight groups
+  // of two: 105 us for the first pass of a 2^24 transform whose arithmetic takes 65).  So the twiddles of group g+1 are
+  // fetched (matrix: loaded; two-level tables: gathered and multiplied together) BEFORE the stores of group g are issued.
+  constexpr int NG = 16 / GSZ;
+  // (the half-image kernels are built for 64 VGPRs: there only the two-element groups of the 2^9-row passes can afford it)
+  constexpr bool TWPIPE = (KIND == 1 || KIND == 3 || KIND == 4) && NG > 1 && !(ABL & 1) && (!CFG::HALF || GSZ <= 2);
+  auto fetch_w = [&](int g, u64* w) {   // inter-pass twiddles of group g, in register order (TWPIPE only)
+    const u32 kl = m + (u32)g * M;
+    if constexpr (KIND == 3) {
+      const u32 tbase = tf_lane + kl * tf_sk;
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) w[i] = ld_g<NARROW>(tf, tbase + (u32)((R / RLAST) * brev(i, LOGLAST)) * tf_sk);
+    } else {
+      constexpr int ES = NARROW ? 3 : 0;
+      u32 ej[GSZ];
+      ej[0] = (twX * (twyk * kl + twYb)) << ES;
+      const u32 estep = (twX * (twyk * (u32)(R / RLAST))) << ES;
+#pragma unroll
+      for (int j = 1; j < GSZ; j++) ej[j] = ej[j - 1] + estep;
+      const u32 lmask8 = lmask << 3, hmask8 = (nmask >> a.tw_lo_bits) << 3;
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) {
+        const u32 ee = ej[brev(i, LOGLAST)];
+        w[i] = gl64::mul(ld_tabb(a.tw_lo, ee & lmask8), ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8));
+      }
+    }
+  };
+  u64 wq[2][GSZ];   // twiddles of the current / the next group (TWPIPE)
+  if constexpr (TWPIPE) fetch_w(0, wq[0]);
 #pragma unroll
   for (int g = 0; g < 16 / GSZ; g++) {
     u64* xg = x + g * GSZ;
@@ -612,7 +643,11 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
-    if ((KIND == 3 || tf) && !(ABL & 1)) {   // KIND 3: the matrix is there by construction (tile_cfg_matches): no second variant in the binary
+    if constexpr (TWPIPE) {
+      if (g + 1 < NG) fetch_w(g + 1, wq[(g + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], wq[g & 1][i]);
+    } else if ((KIND == 3 || tf) && !(ABL & 1)) {   // KIND 3: the matrix is there by construction (tile_cfg_matches): no second variant in the binary
       if (live) {  // dead columns of a ragged tile hold zeros anyway
         // HALF kernels are built for 64 VGPRs: at most 8 table entries in flight at a time
         constexpr int WCH = (CFG::HALF && GSZ > 8) ? 8 : GSZ;
