@@ -29,6 +29,7 @@ sanitize:
 	g++ $(SAN) -std=c++17 -fsanitize=address,undefined -o build/san/test_gl64_host tests/emu/test_gl64_host.cpp
 	gcc -O1 -c -o build/san/orc.o oracle/ronk_oracle.c
 	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_tile tests/emu/emu_tile.cpp build/san/orc.o
+	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_scan tests/emu/emu_scan.cpp build/san/orc.o
 	g++ $(SAN) -std=c++17 -fsanitize=address,undefined -o build/san/bn254_san tests/emu/bn254_san.cpp
 	./build/san/oracle_san
 	./build/san/bn254_san
@@ -38,4 +39,6 @@ sanitize:
 	./build/san/emu_tile 15 2 0 4 18 25 0 0 1 | tail -1
 	./build/san/emu_tile 20 1 0 3 | tail -1
 	./build/san/emu_tile dist 16 4 0 0 2 | tail -1
+	./build/san/emu_scan 18446744069414584321 70001 123456789 3 1 | tail -1
+	./build/san/emu_scan 101 5000 7 3 0 | tail -1
 .PHONY: sanitize

@@ -33,7 +33,7 @@ WORKLOADS = {
     "batch16":     (16, 1024, 16.0 * 1024,   "NTT/s", None),   # config 4: 1024 x 2^16 in one launch pair
     "mul22":       (22, 1,    48.0,          "op/s",  None),   # config 3: 3 transforms of size 2^22, pad/pointwise/truncate fused
     "roundtrip16": (16, 1,    32.0,          "op/s",  None),   # config 2: forward + inverse
-    "open22":      (22, 1,    16.0,          "op/s",  "chunk_sum8_kernel + lindiv_fused_kernel (csrc/scan_kernels.h)"),
+    "open22":      (22, 1,    16.0,          "op/s",  "lindiv_scan_kernel + lindiv_apply_kernel2 (csrc/lindiv_kernels.h)"),
     "eval22":      (22, 1,    8.0,           "op/s",  "eval_onepass_kernel (csrc/scan_kernels.h)"),
     "rs16":        (16, 1024, 12.0 * 1024,   "op/s",  None),   # reads n/2, writes n coefficients per codeword
     "vecmul24":    (24, 1,    24.0,          "op/s",  "vec_binary2_kernel<GlOps, VEC_MUL>"),
@@ -60,9 +60,10 @@ KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", 
 VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
 
 
-# the scan workloads run kernels of scan_kernels.h only: their counters stay valid while THAT file is unchanged
+# the scan workloads run kernels of scan_kernels.h / lindiv_kernels.h only: their counters stay valid while THOSE files
+# are unchanged
 SCAN_SOURCES = ("ronkathon_amd/csrc/scan_kernels.h",)
-SOURCES_BY_WORKLOAD = {"open22": SCAN_SOURCES, "eval22": SCAN_SOURCES}
+SOURCES_BY_WORKLOAD = {"open22": ("ronkathon_amd/csrc/lindiv_kernels.h", "ronkathon_amd/csrc/gl64.h"), "eval22": SCAN_SOURCES}
 
 
 def kernel_source_hash(files=KERNEL_SOURCES):

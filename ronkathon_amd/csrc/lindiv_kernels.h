@@ -1,0 +1,251 @@
+// lindiv_kernels.h -- division by a linear divisor (kzg::open), the two-launch form with per-lane partial scans.
+//
+// Reference semantics restated: poly / (b0 + b1 x), src/polynomial/mod.rs:170-225 via src/kzg/setup.rs:63-78 (divisor
+// [-z, 1]).  With z = -b0/b1 and S(x) = sum_{i >= x} c_i z^(i-x) (the value of the coefficient suffix that starts at x),
+//   quot[j] = S(j+1) / b1,   remainder = S(0) = c(z).
+// scan_kernels.h (lindiv_fused_kernel) pays three field products per coefficient: one for the chunk sums of the first
+// launch, two in the second launch (a Horner pass up every lane's run for the lane sums, then the recurrence down the same
+// run) plus a 256-lane scan of the lane sums -- 108 VALU instructions per coefficient in the second launch (PMC), which
+// made it issue-bound (16.7 us for 2^22 coefficients, the memory floor of its 64 MiB is ~10 us).  Here the FIRST launch
+// does the Horner pass in the lanes' own runs and the scan, and leaves both results in HBM:
+//   1  lindiv_scan_body    lane t of chunk b owns PL contiguous coefficients; U_t = their value at z; suffix scan over
+//                          the chunk's 256 lanes (6 doubling steps inside a wavefront through the cross-lane network,
+//                          then the four wavefront sums through LDS): W[256 b + t] = S restricted to chunk b, from lane t's first coefficient;  H[b] = W[256 b]
+//   2  lindiv_apply_body   carry of the chunk from the H array (as lindiv_fused_kernel did), then per lane
+//                          S(first coefficient of lane t+1) = W[256 b + t + 1] + z^(PL (255 - t)) * carry and the
+//                          recurrence down the lane's run: ONE product per coefficient.
+// Two products per coefficient in total; HBM traffic 8 B read + 8/PL B written, then 8 + 8/PL read + 8 written.
+// MODE LINDIV_DLOAD: a lane READS its run with 16-byte accesses straight from global memory (needs a 16-byte aligned
+// dividend); otherwise, and for the quotient always, the chunk goes through a padded LDS image with coalesced 8-byte
+// accesses (any alignment).  Measured forms -- 16 coefficients per lane, 16-byte stores of the runs, fewer resident
+// workgroups -- and the split of the 22.8 us per 2^22 coefficients over the two launches: profiles/r03_lindiv_forms.txt.
+//
+// The bodies are written against a small context (work-item ids, barrier, cross-lane shift, 16-byte access) so that the
+// CPU suite runs the very same code on fibers (tests/emu/emu_scan.cpp); the kernels are at the end of the file.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gl64.h"
+
+namespace ronk {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+constexpr int LINDIV_PL = 8;                   // coefficients per lane
+constexpr int LINDIV_CHUNK = 256 * LINDIV_PL;  // coefficients per workgroup
+
+struct LinDivTab {
+  u64 z;
+  u64 scale;      // 1/b1 (1 for monic divisors)
+  u64 zs[7];      // z^(PL 2^s): multipliers of the lane scan inside a wavefront (s < 6); zs[6] = z^(64 PL): one wavefront
+  u64 zp[256];    // z^(PL k)
+  u64 Y;          // z^(256 PL): one chunk
+  u64 Y256;       // Y^256
+  u64 YA[16];     // Y^i
+  u64 YB[16];     // Y^(16 i):      Y^t = YA[t & 15] * YB[t >> 4], t < 256
+};
+
+// host: the table for divisor root z, modulus p (canonical z < p), PL coefficients per lane
+inline void lindiv_build_tab(u64 p, u64 z, u64 scale, LinDivTab* t) {
+  const int pl = LINDIV_PL;
+  auto mulm = [p](u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % p); };
+  auto powm = [&](u64 a, u64 e) { u64 r = 1 % p; while (e) { if (e & 1) r = mulm(r, a); a = mulm(a, a); e >>= 1; } return r; };
+  t->z = z % p;
+  t->scale = scale;
+  const u64 zpl = powm(t->z, (u64)pl);
+  u64 y = 1 % p;
+  for (int k = 0; k < 256; k++) { t->zp[k] = y; y = mulm(y, zpl); }
+  t->Y = y;                                               // z^(256 pl)
+  for (int s = 0; s < 7; s++) t->zs[s] = t->zp[1 << s];
+  const u64 Y16 = powm(t->Y, 16);
+  t->Y256 = powm(Y16, 16);
+  u64 cc = 1 % p, dd = 1 % p;
+  for (int i = 0; i < 16; i++) {
+    t->YA[i] = cc; t->YB[i] = dd;
+    cc = mulm(cc, t->Y); dd = mulm(dd, Y16);
+  }
+}
+
+// LDS words (u64) a workgroup of the two bodies needs
+constexpr int LINDIV_DLOAD = 1;
+template <int MODE, bool APPLY>
+constexpr int lindiv_lds_words() { return 8 + ((MODE & LINDIV_DLOAD) && !APPLY ? 0 : LINDIV_CHUNK + 256); }
+
+// the lane's run e[m] = c[base + PL tid + m] (ZERO beyond d)
+template <int MODE, class Ctx>
+RONK_HD void lindiv_load_run(const u64* __restrict__ c, size_t d, size_t base, u32 tid, u64* buf, u64 (&e)[LINDIV_PL], Ctx& cx) {
+  constexpr int PL = LINDIV_PL;
+  const bool full = base + 256 * PL <= d;
+  if constexpr ((MODE & LINDIV_DLOAD) != 0) {
+    const size_t i0 = base + (size_t)PL * tid;
+    if (full) {
+#pragma unroll
+      for (int m = 0; m < PL; m += 2) cx.ld2(c + i0 + m, e[m], e[m + 1]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < PL; m++) e[m] = i0 + m < d ? c[i0 + m] : 0;
+    }
+  } else {
+    // coalesced, lane-strided fill; one pad word per run so that the PL-contiguous reads are conflict free
+#pragma unroll
+    for (int r = 0; r < PL; r++) {
+      const u32 k = tid + 256 * r;
+      const size_t i = base + k;
+      buf[k + k / PL] = (full || i < d) ? c[i] : 0;
+    }
+    cx.barrier();
+#pragma unroll
+    for (int m = 0; m < PL; m++) e[m] = buf[(PL + 1) * tid + m];
+  }
+}
+
+// launch 1: W[256 b + t] and H[b]
+template <int MODE, class Ops, class Ctx>
+RONK_HD void lindiv_scan_body(const Ops& ops, const u64* __restrict__ c, size_t d, const LinDivTab& tab, u64* __restrict__ W,
+                              u64* __restrict__ H, Ctx& cx) {
+  const u32 tid = cx.tid();
+  const size_t b = cx.bid();
+  u64* sc = cx.lds();
+  constexpr int PL = LINDIV_PL;
+  u64 e[PL];
+  lindiv_load_run<MODE>(c, d, b * (256 * PL), tid, sc + 8, e, cx);
+  const u64 z = tab.z;
+  u64 U = e[PL - 1];
+#pragma unroll
+  for (int m = PL - 2; m >= 0; m--) U = ops.add(ops.mul(U, z), e[m]);
+  // W_t = U_t + z^PL W_(t+1): doubling steps, inside the wavefront first
+  const u32 lane = tid & 63;
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    const u32 off = 1u << s;
+    const u64 up = cx.shfl_down(U, off);
+    if (lane + off < 64) U = ops.add(U, ops.mul(tab.zs[s], up));
+  }
+  // across the four wavefronts: C = value of the chunk's suffix that starts at the end of this wavefront (wavefront sums
+  // T_w = lane 0's U; Horner in z^(64 PL) from the top: 0..3 products, the same number for every lane of a wavefront)
+  const u32 w = cx.wave();
+  if (lane == 0) sc[w] = U;
+  cx.barrier();
+  if (w < 3) {
+    u64 C = sc[3];
+    for (u32 ww = 2; ww > w; ww--) C = ops.add(ops.mul(C, tab.zs[6]), sc[ww]);
+    U = ops.add(U, ops.mul(tab.zp[64 - lane], C));
+  }
+  W[b * 256 + tid] = U;
+  if (tid == 0) H[b] = U;
+}
+
+// launch 2: quot[base + k] = scale * S(base + k + 1); chunk 0 also writes the remainder c(z) = H_0 + Y G_1
+template <int MODE, class Ops, class Ctx>
+RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t d, const LinDivTab& tab,
+                               const u64* __restrict__ W, const u64* __restrict__ H, u32 nchunks, u64* __restrict__ quot,
+                               u64* __restrict__ rem, Ctx& cx) {
+  const u32 tid = cx.tid();
+  const u32 b = cx.bid();
+  u64* sc = cx.lds();
+  u64* buf = sc + 8;
+  constexpr int PL = LINDIV_PL;
+  const size_t base = (size_t)b * (256 * PL);
+  const bool full = base + 256 * PL <= d;
+  u64 e[PL];
+  lindiv_load_run<MODE>(c, d, base, tid, buf, e, cx);
+  const u64 wn = tid < 255 ? W[(size_t)b * 256 + tid + 1] : 0;
+  // incoming carry G_(b+1) = sum_{j > b} H_j Y^(j-b-1): lane t takes j = b+1+t+256q (Horner in Y^256 over q), times Y^t
+  u64 cpart = 0;
+  {
+    const u32 first = b + 1 + tid;
+    if (first < nchunks) {
+      // (eight sums are fetched at once, then folded: a load inside the dependent Horner chain would cost one memory
+      // round trip per term; the counts of a workgroup's lanes differ by at most one, so skipped terms cost a branch)
+      const u32 cnt = (nchunks - first + 255) / 256;
+      for (u32 qb = (cnt + 7) & ~7u; qb > 0; qb -= 8) {
+        u64 h[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) h[i] = qb - 8 + i < cnt ? H[first + 256 * (qb - 8 + i)] : 0;
+#pragma unroll
+        for (int i = 7; i >= 0; i--)
+          if (qb - 8 + i < cnt) cpart = ops.add(ops.mul(cpart, tab.Y256), h[i]);
+      }
+      cpart = ops.mul(cpart, ops.mul(tab.YA[tid & 15], tab.YB[tid >> 4]));
+    }
+  }
+  // sum over the workgroup: inside the wavefront through the cross-lane network, the four wavefront sums through LDS
+#pragma unroll
+  for (int s = 0; s < 6; s++) cpart = ops.add(cpart, cx.shfl_xor(cpart, 1u << s));
+  if ((tid & 63) == 0) sc[tid >> 6] = cpart;
+  cx.barrier();
+  const u64 cin = ops.add(ops.add(sc[0], sc[1]), ops.add(sc[2], sc[3]));
+  if (b == 0 && tid == 0 && rem) *rem = ops.add(H[0], ops.mul(tab.Y, cin));
+  // S(first coefficient of the next lane), then down the run
+  const u32 k = 255 - tid;
+  u64 r = ops.add(wn, ops.mul(tab.zp[k], cin));
+  const u64 z = tab.z;
+  u64 o[PL];
+#pragma unroll
+  for (int m = PL - 1; m >= 0; m--) { o[m] = r; r = ops.add(ops.mul(r, z), e[m]); }
+  if (tab.scale != 1) {
+#pragma unroll
+    for (int m = 0; m < PL; m++) o[m] = ops.mul(o[m], tab.scale);
+  }
+  {
+    // (the image is free: with LDS loads a lane has read nothing but its own run's words since the fill's barrier)
+#pragma unroll
+    for (int m = 0; m < PL; m++) buf[(PL + 1) * tid + m] = o[m];
+    cx.barrier();
+#pragma unroll
+    for (int rr = 0; rr < PL; rr++) {
+      const u32 kk = tid + 256 * rr;
+      const size_t i = base + kk;
+      if (full || i < d) quot[i] = buf[kk + kk / PL];
+    }
+  }
+}
+
+}  // namespace ronk
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+
+namespace ronk {
+
+struct LinDivDevCtx {
+  u64* lds_;
+  __device__ __forceinline__ u32 tid() const { return threadIdx.x; }
+  __device__ __forceinline__ u32 bid() const { return blockIdx.x; }
+  __device__ __forceinline__ u32 wave() const { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+  __device__ __forceinline__ u64* lds() const { return lds_; }
+  __device__ __forceinline__ void barrier() const { __syncthreads(); }
+  __device__ __forceinline__ u64 shfl_down(u64 v, u32 off) const { return __shfl_down((unsigned long long)v, off, 64); }
+  __device__ __forceinline__ u64 shfl_xor(u64 v, u32 mask) const { return __shfl_xor((unsigned long long)v, (int)mask, 64); }
+  typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ void ld2(const u64* p, u64& a, u64& b) const {
+    const v2 v = *reinterpret_cast<const v2*>(p);
+    a = v.x; b = v.y;
+  }
+  __device__ __forceinline__ void st2(u64* p, u64 a, u64 b) const {
+    v2 v; v.x = a; v.y = b;
+    *reinterpret_cast<v2*>(p) = v;
+  }
+};
+
+template <int MODE, class Ops>
+__global__ void __launch_bounds__(256) lindiv_scan_kernel(Ops ops, const u64* __restrict__ c, size_t d, LinDivTab tab,
+                                                           u64* __restrict__ W, u64* __restrict__ H) {
+  __shared__ __attribute__((aligned(16))) u64 lds[lindiv_lds_words<MODE, false>()];
+  LinDivDevCtx cx{lds};
+  lindiv_scan_body<MODE>(ops, c, d, tab, W, H, cx);
+}
+
+template <int MODE, class Ops>
+__global__ void __launch_bounds__(256) lindiv_apply_kernel2(Ops ops, const u64* __restrict__ c, size_t d, LinDivTab tab,
+                                                             const u64* __restrict__ W, const u64* __restrict__ H,
+                                                             u64* __restrict__ quot, u64* __restrict__ rem) {
+  __shared__ __attribute__((aligned(16))) u64 lds[lindiv_lds_words<MODE, true>()];
+  LinDivDevCtx cx{lds};
+  lindiv_apply_body<MODE>(ops, c, d, tab, W, H, gridDim.x, quot, rem, cx);
+}
+
+}  // namespace ronk
+#endif

@@ -2,6 +2,7 @@
 // evaluate, division (kzg::open), Lagrange evaluate, Reed-Solomon encode / decode, KZG commit (curve MSM).
 #include "runtime.h"
 #include "scan_kernels.h"
+#include "lindiv_kernels.h"
 #include "interp_kernels.h"
 #include "curve_kernels.h"
 
@@ -129,6 +130,32 @@ static const size_t FUSED_EVAL_MAX = (size_t)FCH << 20, FUSED_DIV_MAX = (size_t)
 static const bool g_no_fused_scans = getenv("RONK_NO_FUSED_SCANS") != nullptr;   // experiments / A-B
 static const bool g_no_onepass_scans = getenv("RONK_NO_ONEPASS_SCANS") != nullptr;
 static const bool g_onepass_div = getenv("RONK_ONEPASS_DIV") != nullptr;   // one-launch division: built, parity-tested, slower (scan_kernels.h)
+// ---- division by a linear divisor, lindiv_kernels.h: the default up to 4096 chunks ---------------------------------------
+// RONK_LINDIV = "0": scan_kernels.h forms only; "l": the chunk goes through the LDS image both ways even when the operands
+// are 16-byte aligned (A-B runs; profiles/r03_lindiv_forms.txt)
+static const int g_lindiv = [] {
+  const char* e = getenv("RONK_LINDIV");
+  if (!e || !*e) return 2;
+  return e[0] == '0' ? 0 : e[strlen(e) - 1] == 'l' ? 1 : 2;
+}();
+static void make_lindiv_tab(u64 p, u64 z, u64 scale, LinDivTab* t) {   // (kept for the next call: see make_horner_tab2)
+  static std::mutex mu;
+  static LinDivTab last;
+  static u64 lp = 0, lz = 0, lscale = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (lp != p || lz != z || lscale != scale) { lindiv_build_tab(p, z, scale, &last); lp = p; lz = z; lscale = scale; }
+  *t = last;
+}
+template <int MODE>
+static int lindiv2_launch(const FieldCtx& f, const u64* d_c, size_t d, const LinDivTab& tab, u64* W, u64* H, u32 nch, u64* d_quot,
+                          u64* d_rem, hipStream_t s) {
+  FIELD_DISPATCH(f, {
+    hipLaunchKernelGGL((lindiv_scan_kernel<MODE, decltype(ops)>), dim3(nch), dim3(256), 0, s, ops, d_c, d, tab, W, H);
+    hipLaunchKernelGGL((lindiv_apply_kernel2<MODE, decltype(ops)>), dim3(nch), dim3(256), 0, s, ops, d_c, d, tab, W, H, d_quot, d_rem);
+  });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
 static void make_horner_tab(u64 p, u64 z, u64 scale, HornerTab* t) {
   u64 x = 1 % p;
   for (int i = 0; i < 256; i++) { t->zt[i] = x; x = h_mulmod(x, z, p); }
@@ -221,13 +248,28 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
   hipStream_t s = (hipStream_t)stream;
   const u64 b1inv = h_powmod(b1, p - 2, p);
   const u64 z = h_mulmod((p - b0) % p, b1inv, p);        // -b0 / b1
+  if (g_lindiv && d <= (size_t)LINDIV_CHUNK * 4096 && !g_no_fused_scans && !g_onepass_div) {   // lindiv_kernels.h
+    const size_t nch = (d + LINDIV_CHUNK - 1) / LINDIV_CHUNK;
+    const bool direct = g_lindiv == 2 && ((uintptr_t)d_c & 15) == 0;
+    LinDivTab tab;
+    make_lindiv_tab(p, z, b1inv, &tab);
+    WsLease ws;
+    RCHK(ws.acquire(nch * 257 * 8, s));
+    u64* H = ws.u();
+    u64* W = ws.u() + nch;
+    return direct ? lindiv2_launch<LINDIV_DLOAD>(f, d_c, d, tab, W, H, (u32)nch, d_quot, d_rem, s)
+                  : lindiv2_launch<0>(f, d_c, d, tab, W, H, (u32)nch, d_quot, d_rem, s);
+  }
   if (d <= FUSED_DIV_MAX && !g_no_fused_scans) {   // two launches: chunk sums, then carry + recurrence per chunk
     const size_t nch = (d + FCH - 1) / FCH;
     HornerTab2 tab2;
     make_horner_tab2(p, z, b1inv, &tab2);
     WsLease ws;
     RCHK(ws.acquire(nch * 8, s));
-    if (g_onepass_div && nch <= LB_DIV_MAX && !g_no_onepass_scans && !stream_is_capturing(s)) {   // one launch (scan_kernels.h)
+    // one launch (scan_kernels.h); not for a quotient written over the dividend: a workgroup whose wait runs out recomputes
+    // the chunk sums above it from the coefficients, which other workgroups may have overwritten by then
+    const bool overlap = d_quot < d_c + d && d_c < d_quot + d;
+    if (g_onepass_div && !overlap && nch <= LB_DIV_MAX && !g_no_onepass_scans && !stream_is_capturing(s)) {
       u64 *cur, *next;
       ws.lb_arrays(&cur, &next);
       FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_onepass_kernel<decltype(ops)>), dim3((u32)nch), dim3(256), 0, s, ops, d_c, d,

@@ -43,10 +43,24 @@ def main():
             assert orc.poly_eval(p, a, t) == orc.add(p, orc.mul(p, orc.poly_eval(p, q, t), orc.sub(p, t, z)), val), (p, d)
             if d <= 5000:
                 assert np.array_equal(q, orc.kzg_open_quotient(p, a, z)), (p, d)
-            # spot-check the recurrence q[j-1] = c[j] + z q[j] at chunk edges of the big sizes
-            for j in (d - 1, d // 2, 2048, 2049, 4096, 1):
-                if 1 <= j < d:
-                    assert int(q[j - 1]) == orc.add(p, int(a[j]), orc.mul(p, z, int(q[j]))), (p, d, j)
+            # the recurrence q[j-1] = c[j] + z q[j] at EVERY j (with q[d-1] = 0 above it pins the whole quotient)
+            if d > 1:
+                assert np.array_equal(q[:-1], orc.vec_add(p, a[1:], orc.vec_mul(p, q[1:], np.full(d - 1, z, dtype=np.uint64)))), (p, d)
+            # a non-monic divisor b0 + b1 x (quotient scaled by 1/b1), operands 8 bytes off a 16-byte boundary (the
+            # 16-byte access form must not be chosen), and the quotient written over the dividend
+            if rep < 6:
+                b1 = 5 % p or 1
+                b0 = orc.mul(p, orc.neg(p, z), b1)
+                db = torch.zeros(d + 3, dtype=torch.int64, device="cuda")
+                off = 1 if (db.data_ptr() % 16 == 0) else 0                      # -> address = 8 mod 16
+                db[off:off + d] = da
+                torch.cuda.synchronize()
+                L.check(L.lib.ronk_poly_div_linear_dev(p, db.data_ptr() + 8 * off, d, b0, b1, db.data_ptr() + 8 * off, dr.data_ptr(), st))
+                torch.cuda.synchronize()
+                q2 = db.cpu().numpy().view(np.uint64)[off:off + d]
+                assert np.array_equal(q2, orc.vec_mul(p, q, np.full(d, orc.inverse(p, b1), dtype=np.uint64))), (p, d, "scaled, unaligned, in place")
+                assert int(dr.cpu().numpy().view(np.uint64)[0]) == val
+                assert not db.cpu().numpy()[off + d:].any() and (off == 0 or int(db[0]) == 0), "wrote outside the operand"
     print("scan check ok")
 
 

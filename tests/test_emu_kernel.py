@@ -219,3 +219,37 @@ def test_single_pass_plans_run_the_whole_polynomial_body(emu, args):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
     assert [l.split("kernel=")[1] for l in lines if l.startswith("pass")] == ["cfg:whole"], out.stdout
+
+
+# ---- the linear-division kernels (ronkathon_amd/csrc/lindiv_kernels.h) on fibers: tests/emu/emu_scan.cpp
+SCAN_EXE = os.path.join(ROOT, "build", "emu_scan")
+
+
+@pytest.fixture(scope="module")
+def emu_scan():
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "emu", "emu_scan.cpp")
+    deps = [src] + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("lindiv_kernels.h", "gl64.h")]
+    if not os.path.exists(SCAN_EXE) or any(os.path.getmtime(d) > os.path.getmtime(SCAN_EXE) for d in deps):
+        obj = os.path.join(ROOT, "build", "orc_emu.o")
+        subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SCAN_EXE, src, obj])
+    return SCAN_EXE
+
+
+@pytest.mark.parametrize("direct", [0, 1])
+def test_linear_division_kernels_on_fibers(emu_scan, direct):
+    """both launches of ronk_poly_div_linear_dev's default path, the code the GPU runs, against the oracle's recurrence (and
+    orc_poly_divrem up to 4096 coefficients): one coefficient .. several hundred chunks (more than one sum per lane in the
+    carry), chunk and wavefront edges, z = 0 / 1 / p - 1, non-monic divisors, F_101 and F_2; with 16-byte reads of the
+    lanes' runs and through the LDS image"""
+    GP = 0xFFFFFFFF00000001
+    for d in (1, 2, 7, 511, 512, 513, 2047, 2048, 2049, 4096, 4097, 20000, 70001):
+        run(emu_scan, GP, d, 123456789, 1, direct)
+    run(emu_scan, GP, 9000, GP - 1, 77, direct)
+    run(emu_scan, GP, 9000, 1, 1, direct)
+    run(emu_scan, GP, 9000, 0, 5, direct)
+    run(emu_scan, 101, 5000, 7, 3, direct)
+    run(emu_scan, 101, 300, 0, 1, direct)
+    run(emu_scan, 2, 3000, 1, 1, direct)
+    run(emu_scan, GP, 700001, 987654321987, 3, direct, 5)       # 342 chunks: two sums per lane for the low chunks

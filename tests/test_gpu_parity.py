@@ -683,11 +683,14 @@ def test_scan_paths_fused_and_three_kernel(R, orc):
 
 
 @pytest.mark.parametrize("env", [{}, {"RONK_ONEPASS_DIV": "1"}, {"RONK_ONEPASS_DIV": "1", "RONK_LB_TEST_FLAGS": "1"},
-                                 {"RONK_NO_ONEPASS_SCANS": "1"}, {"RONK_NO_FUSED_SCANS": "1"}])
+                                 {"RONK_NO_ONEPASS_SCANS": "1"}, {"RONK_NO_FUSED_SCANS": "1"},
+                                 {"RONK_LINDIV": "l"}, {"RONK_LINDIV": "0"}])
 def test_scan_onepass_variants(R, env):
     """the one-launch evaluate / linear division (look-back through an agent-coherent array), the same with every wait
-    forced to give up (the recompute-from-coefficients path that makes the waits bounded), and the two- and three-launch
-    forms: each in its own process, since the library reads its knobs once"""
+    forced to give up (the recompute-from-coefficients path that makes the waits bounded), the two- and three-launch
+    forms; the lane-scan division (lindiv_kernels.h, the default) with 16-byte reads of the lanes' runs ({}) and with the
+    LDS image both ways ("l"; what unaligned dividends get anyway), "0" = the scan_kernels.h division: each in its own
+    process, since the library reads its knobs once"""
     import subprocess, sys
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "scan_subprocess_check.py")],

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs into a small text/JSON report.
 
-usage: rocprof_summary.py <dir with trace/ fetch/ write/ sq/ sub-runs> <out prefix> [source label]
+usage: rocprof_summary.py <dir with trace/ fetch/ write/ sq/ sub-runs> <out prefix> [source label [workload]]
 The JSON records the sha256 of the tile-kernel sources (bench.kernel_source_hash): bench.py refuses counters taken on
 other sources.
   trace/  rocprofv3 --kernel-trace --stats      -> per-kernel calls / average duration
@@ -30,6 +30,10 @@ def main():
     import bench
     rep = {"kernel_source_hash": bench.kernel_source_hash(), "source": sys.argv[3] if len(sys.argv) > 3 else os.path.basename(out) + ".txt",
            "kernels": [], "counters": {}}
+    wl = sys.argv[4] if len(sys.argv) > 4 else None
+    if wl in bench.SOURCES_BY_WORKLOAD:      # a workload with its own kernel sources (the scans): validated against those
+        rep["workload_source_hash"] = bench.kernel_source_hash(bench.SOURCES_BY_WORKLOAD[wl])
+        rep["workload_source_note"] = "sha256 of " + ", ".join(bench.SOURCES_BY_WORKLOAD[wl])
     db = db_of(os.path.join(root, "trace"))
     if db:
         for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
