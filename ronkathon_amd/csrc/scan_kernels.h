@@ -31,17 +31,16 @@ struct HornerTab {
   u64 scale;      // 1/b1 (1 for evaluate and for monic divisors)
 };
 
+// sum over the 256 work-items of a workgroup, valid in every lane: inside a wavefront through the cross-lane network, the
+// four wavefront sums through red[0..3] (ONE barrier; round 2 had an eight-step LDS tree with nine).  A caller that uses
+// `red` again synchronises first.
 template <class Ops>
 __device__ __forceinline__ u64 block_sum_256(const Ops& ops, u64 v, u64* red) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
-  __syncthreads();
 #pragma unroll
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] = ops.add(red[tid], red[tid + s]);
-    __syncthreads();
-  }
-  return red[0];
+  for (int s = 0; s < 6; s++) v = ops.add(v, (u64)__shfl_xor((unsigned long long)v, 1 << s, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ops.add(ops.add(red[0], red[1]), ops.add(red[2], red[3]));
 }
 
 // A: H[b] = sum_{k < 4096} c[base + k] z^k  (entries beyond d read as ZERO)
@@ -205,13 +204,16 @@ struct HornerTab2 {
   u64 test_flags;        // bit 0: every wait of the one-launch forms gives up at once (tests of the recompute path)
 };
 
-// Y^e from the binary expansion of e (wave-uniform or per lane)
+// Y^e, e < 2^20 (wave-uniform or per lane): the low twelve bits from the three 16-entry tables (two products; round 2 spent
+// up to twelve predicated products here, on every lane of every workgroup of an evaluate), the rest from the binary expansion
 template <class Ops>
 __device__ __forceinline__ u64 ypow(const Ops& ops, const HornerTab2& tab, u32 e) {
-  u64 r = ops.one();
+  u64 r = ops.mul(ops.mul(tab.YA[e & 15], tab.YB[(e >> 4) & 15]), tab.YC[(e >> 8) & 15]);
+  if (e >> 12) {
 #pragma unroll
-  for (int s = 0; s < 20; s++)
-    if (e & (1u << s)) r = ops.mul(r, tab.Yp[s]);
+    for (int s = 12; s < 20; s++)
+      if (e & (1u << s)) r = ops.mul(r, tab.Yp[s]);
+  }
   return r;
 }
 
