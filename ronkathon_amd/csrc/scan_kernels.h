@@ -231,9 +231,12 @@ __device__ __forceinline__ u64 chunk_sum8_at(const Ops& ops, const u64* __restri
 #pragma unroll
     for (int r = 7; r >= 0; r--) { const size_t i = base + tid + 256 * r; e[r] = i < d ? c[i] : 0; }
   }
-  u64 acc = e[7];
+  // sum_r e[r] z^(256 r) as two Horner chains in z^512 (even and odd r): the same seven products, four deep instead of seven
+  const u64 z512 = ops.mul(tab.z256, tab.z256);
+  u64 ae = e[6], ao = e[7];
 #pragma unroll
-  for (int r = 6; r >= 0; r--) acc = ops.add(ops.mul(acc, tab.z256), e[r]);
+  for (int r = 4; r >= 0; r -= 2) { ae = ops.add(ops.mul(ae, z512), e[r]); ao = ops.add(ops.mul(ao, z512), e[r + 1]); }
+  u64 acc = ops.add(ops.mul(ao, tab.z256), ae);
   acc = ops.mul(acc, tab.zt[tid]);
   return block_sum_256(ops, acc, red);
 }
