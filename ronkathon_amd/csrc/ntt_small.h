@@ -7,7 +7,7 @@
 // R*C/4 work-items doing log4(R) rounds of one radix-4 butterfly each (omega_4 = 2^48: a shift), i.e. a quarter of the
 // instructions per lane and four times the waves; more barriers and one table twiddle per coefficient and round do not
 // matter when nothing else competes for the VALU.  Selected by the planner (plan.h) for two-pass plans whose whole batch
-// is at most 2^17 coefficients.
+// is at most 2^19 coefficients.
 //
 // Same TileArgs contract as tile_body (strides, blocked rows, inter-pass twiddle by two-level table or full matrix, scale,
 // second operand and implicit padding / truncation of the fused polynomial multiply; no staged I/O), same results: X[k] = sum_j x[j] omega^{jk}, natural order in and out
@@ -24,6 +24,15 @@
 namespace ronk {
 
 RONK_HD u32 small_row(u32 p) { return p + (p >> 2); }
+
+// the value is materialised here (device: an empty asm that reads and writes its register)
+RONK_HD void small_keep(u64& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
 
 // omega_4^{+-1} * x: omega_4 = omega_64^16 = 2^(39*16 mod 192) = 2^48; the inverse is 2^144 = -2^48
 template <bool INV>
@@ -49,37 +58,94 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
   };
   auto cell = [&](u32 p) -> u32 { return (small_row(p) << logc) + c; };
 
-  u64 x[4];
+  // natural output index of position p: reverse the base-4 digits (and the last binary digit when LOGR is odd)
+  auto natural = [&](u32 p) -> u32 {
+    u32 k = 0;
+    if (ODD) {
+      k = (p & 1) << (2 * S4);
+      p >>= 1;
+    }
+#pragma unroll
+    for (int s = S4 - 1; s >= 0; s--) { k |= (p & 3) << (2 * s); p >>= 2; }
+    return k;
+  };
+  // ---- EVERY global load of the pass is issued here, before anything waits for one: the four inputs (and the second
+  // operand's), the table twiddles of all rounds, the inter-pass twiddles of the four outputs.  None of the addresses
+  // depends on data, and a launch of this kernel is a handful of memory round trips long: taken one after the other -- a
+  // load behind every `if`, as the first version compiled -- they were most of its 6.3 us (profiles/r03_small_kernel_loads.txt).
+  // Loads that a lane must not make (padding, dead columns) go to a safe address and are discarded; round twiddles with
+  // exponent 0 read omega^0 = 1 from the table instead of being skipped.
+  u64 x[4], x2[4];
+  bool ok[4];
+  {
+    constexpr u32 q = R / 4;   // round 0: one block, j = u
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const i64 off = in_row(u + i * q);
+      // lin = offset inside the polynomial (everything but the b1 term): >= in_valid reads as ZERO (From<[F;N]> padding)
+      const u64 lin = (u64)((i64)b2 * a.in_sb2 + (i64)t * a.in_st + (i64)c * a.in_sc + off);
+      const u64 valid = (b1 && a.in_valid1 != ~(u64)0) ? a.in_valid1 : a.in_valid;
+      ok[i] = live && (valid == ~(u64)0 || lin < valid);
+      x[i] = *(ok[i] ? in + off : a.in);
+    }
+    if (a.in2) {                                             // fused pointwise product
+#pragma unroll
+      for (int i = 0; i < 4; i++) x2[i] = *(ok[i] ? a.in2 + (in - a.in) + in_row(u + i * q) : a.in2);
+    }
+  }
+  constexpr int TWR = ODD ? S4 : S4 - 1;                     // rounds followed by table twiddles (none after L == 4, j == 0)
+  u64 twr[TWR > 0 ? TWR : 1][3];
+#pragma unroll
+  for (int s = 0; s < TWR; s++) {
+    const u32 L = R >> (2 * s), q = L / 4;
+    const u32 step = (u % q) * (R / L);
+#pragma unroll
+    for (int r = 1; r < 4; r++) twr[s][r - 1] = ld_tab(a.wr, (step * r) & (R - 1));
+  }
+  u32 pos[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) pos[i] = ODD ? 4 * u + i : u * 4 + i;   // (odd sizes: positions 2v, 2v+1 of v = 2u, 2u+1)
+  const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
+  const u32 lmask = (1u << a.tw_lo_bits) - 1;
+  const u32 twX = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
+  u64 two[4], two_hi[4];
+  if (a.tw_full) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      two[i] = a.tw_full[live ? (size_t)natural(pos[i]) * a.tf_sk + (size_t)col * a.tf_sc + (size_t)b2 * a.tf_sb2 : (size_t)0];
+  } else if (a.tw_log) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u32 e = (twX * ((u32)a.yk * natural(pos[i]) + (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0)) & nmask;
+      two[i] = ld_tab(a.tw_lo, e & lmask);
+      two_hi[i] = ld_tab(a.tw_hi, e >> a.tw_lo_bits);
+    }
+    // (the compiler would sink these eight loads to their use behind the last barrier -- one more exposed round trip)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { small_keep(two[i]); small_keep(two_hi[i]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (!ok[i]) x[i] = 0;
+    else if (a.in2) x[i] = gl64::mul(x[i], x2[i]);
+  }
   // ---- radix-4 rounds
 #pragma unroll
   for (int s = 0; s < S4; s++) {
     const u32 L = R >> (2 * s), q = L / 4;
     const u32 Bk = u / q, j = u % q;
     const u32 p0 = Bk * L + j;
-    if (s == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const i64 off = in_row(p0 + i * q);
-        // lin = offset inside the polynomial (everything but the b1 term): >= in_valid reads as ZERO (From<[F;N]> padding)
-        const u64 lin = (u64)((i64)b2 * a.in_sb2 + (i64)t * a.in_st + (i64)c * a.in_sc + off);
-        const u64 valid = (b1 && a.in_valid1 != ~(u64)0) ? a.in_valid1 : a.in_valid;
-        const bool ok = live && (valid == ~(u64)0 || lin < valid);
-        x[i] = ok ? in[off] : 0;
-        if (a.in2 && ok) x[i] = gl64::mul(x[i], (a.in2 + (in - a.in))[off]);   // fused pointwise product
-      }
-    } else {
+    if (s > 0) {
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = lds[cell(p0 + i * q)];
     }
     const u64 t0 = gl64::add(x[0], x[2]), t1 = gl64::sub(x[0], x[2]);
     const u64 t2 = gl64::add(x[1], x[3]), t3 = mul_w4_of_diff<INV>(x[1], x[3]);
     x[0] = gl64::add(t0, t2); x[1] = gl64::add(t1, t3); x[2] = gl64::sub(t0, t2); x[3] = gl64::sub(t1, t3);
-    // twiddles omega_L^{j r} = omega_R^{j r R/L}; none in the last radix-4 round of an even size (L == 4, j == 0)
-    if (q > 1 || ODD) {
-      const u32 step = j * (R / L);
+    // twiddles omega_L^{j r} = omega_R^{j r R/L} (fetched above)
+    if (s < TWR) {
 #pragma unroll
-      for (int r = 1; r < 4; r++)
-        if (j) x[r] = gl64::mul(x[r], ld_tab(a.wr, (step * r) & (R - 1)));
+      for (int r = 1; r < 4; r++) x[r] = gl64::mul(x[r], twr[s < TWR ? s : 0][r - 1]);
     }
     if (s == S4 - 1 && !ODD) break;   // results stay in registers: output below
     // in place: the four positions belong to this work-item alone in this round, so no barrier between its reads and writes
@@ -87,21 +153,6 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
     for (int i = 0; i < 4; i++) lds[cell(p0 + i * q)] = x[i];
     barrier();
   }
-  // natural output index of position p: reverse the base-4 digits (and the last binary digit when LOGR is odd)
-  auto natural = [&](u32 p) -> u32 {
-    u32 k = 0;
-    if (ODD) {
-      k = (p & 1) << (2 * S4);
-      p >>= 1;
-#pragma unroll
-      for (int s = S4 - 1; s >= 0; s--) { k |= (p & 3) << (2 * s); p >>= 2; }
-    } else {
-#pragma unroll
-      for (int s = S4 - 1; s >= 0; s--) { k |= (p & 3) << (2 * s); p >>= 2; }
-    }
-    return k;
-  };
-  u32 pos[4];
   if (ODD) {
     // last round: radix 2 on positions 2v, 2v+1; each work-item does two butterflies (v = 2u, 2u + 1)
 #pragma unroll
@@ -110,28 +161,16 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
       const u64 e0 = lds[cell(2 * v)], e1 = lds[cell(2 * v + 1)];
       x[2 * h] = gl64::add(e0, e1);
       x[2 * h + 1] = gl64::sub(e0, e1);
-      pos[2 * h] = 2 * v; pos[2 * h + 1] = 2 * v + 1;
     }
-  } else {
-    const u32 p0 = u * 4;   // last radix-4 round: L = 4, q = 1, block u
-#pragma unroll
-    for (int i = 0; i < 4; i++) pos[i] = p0 + i;
   }
   // ---- output: inter-pass twiddle / scale, natural order
   if (!live) return;
-  const u32 nmask = a.tw_log >= 32 ? 0xFFFFFFFFu : ((1u << a.tw_log) - 1);
-  const u32 lmask = (1u << a.tw_lo_bits) - 1;
-  const u32 twX = (u32)a.xc * col + (u32)a.xb1 * b1 + (u32)a.xb2 * b2 + (u32)a.x0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const u32 k = natural(pos[i]);
     u64 v = x[i];
-    if (a.tw_full) {
-      v = gl64::mul(v, a.tw_full[(size_t)k * a.tf_sk + (size_t)col * a.tf_sc + (size_t)b2 * a.tf_sb2]);
-    } else if (a.tw_log) {
-      const u32 e = (twX * ((u32)a.yk * k + (u32)a.yb1 * b1 + (u32)a.yb2 * b2 + (u32)a.y0)) & nmask;
-      v = gl64::mul(v, gl64::mul(ld_tab(a.tw_lo, e & lmask), ld_tab(a.tw_hi, e >> a.tw_lo_bits)));
-    }
+    if (a.tw_full) v = gl64::mul(v, two[i]);
+    else if (a.tw_log) v = gl64::mul(v, gl64::mul(two[i], two_hi[i]));
     if (a.scale != 1) v = gl64::mul(v, a.scale);
     const u64 lin = (u64)((i64)b2 * a.out_sb2 + (i64)t * a.out_st + (i64)c * a.out_sc + (i64)k * a.out_sk);
     if (a.out_valid == ~(u64)0 || lin < a.out_valid) out[(i64)k * a.out_sk] = v;
