@@ -111,12 +111,13 @@ RONK_HD void lindiv_scan_body(const Ops& ops, const u64* __restrict__ c, size_t 
   constexpr int PL = LINDIV_PL;
   u64 e[PL];
   lindiv_load_run<MODE>(c, d, b * (256 * PL), tid, sc + 8, e, cx);
+  const u32 lane = tid & 63;
+  const u64 zup = tab.zp[64 - lane];   // (a per-lane table load: issued with the coefficients, not behind the barrier below)
   const u64 z = tab.z;
   u64 U = e[PL - 1];
 #pragma unroll
   for (int m = PL - 2; m >= 0; m--) U = ops.add(ops.mul(U, z), e[m]);
   // W_t = U_t + z^PL W_(t+1): doubling steps, inside the wavefront first
-  const u32 lane = tid & 63;
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     const u32 off = 1u << s;
@@ -131,7 +132,7 @@ RONK_HD void lindiv_scan_body(const Ops& ops, const u64* __restrict__ c, size_t 
   if (w < 3) {
     u64 C = sc[3];
     for (u32 ww = 2; ww > w; ww--) C = ops.add(ops.mul(C, tab.zs[6]), sc[ww]);
-    U = ops.add(U, ops.mul(tab.zp[64 - lane], C));
+    U = ops.add(U, ops.mul(zup, C));
   }
   W[b * 256 + tid] = U;
   if (tid == 0) H[b] = U;
@@ -151,26 +152,28 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
   const bool full = base + 256 * PL <= d;
   u64 e[PL];
   lindiv_load_run<MODE>(c, d, base, tid, buf, e, cx);
-  const u64 wn = tid < 255 ? W[(size_t)b * 256 + tid + 1] : 0;
+  // Every other load of the launch is issued here too, unconditionally (a lane that has no use for one reads a safe entry
+  // and discards it): taken where they are used -- behind `tid < 255`, inside the carry loop, after the barrier -- they were
+  // five dependent memory round trips in a launch of 14 us.
+  const u64 wn_raw = W[(size_t)b * 256 + (tid < 255 ? tid + 1 : 255)];
+  const u64 zpk = tab.zp[255 - tid];
+  const u64 ya = tab.YA[tid & 15], yb = tab.YB[tid >> 4];
   // incoming carry G_(b+1) = sum_{j > b} H_j Y^(j-b-1): lane t takes j = b+1+t+256q (Horner in Y^256 over q), times Y^t
+  // (eight sums are fetched at once, then folded; the counts of a workgroup's lanes differ by at most one, so skipped terms
+  // cost a branch)
+  const u32 first = b + 1 + tid;
+  const u32 cnt = first < nchunks ? (nchunks - first + 255) / 256 : 0;
   u64 cpart = 0;
-  {
-    const u32 first = b + 1 + tid;
-    if (first < nchunks) {
-      // (eight sums are fetched at once, then folded: a load inside the dependent Horner chain would cost one memory
-      // round trip per term; the counts of a workgroup's lanes differ by at most one, so skipped terms cost a branch)
-      const u32 cnt = (nchunks - first + 255) / 256;
-      for (u32 qb = (cnt + 7) & ~7u; qb > 0; qb -= 8) {
-        u64 h[8];
+  for (u32 qb = (((nchunks - b + 254) / 256) + 7) & ~7u; qb > 0; qb -= 8) {   // (workgroup-uniform trip count: lane 0's)
+    u64 h[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) h[i] = qb - 8 + i < cnt ? H[first + 256 * (qb - 8 + i)] : 0;
+    for (int i = 0; i < 8; i++) h[i] = H[qb - 8 + i < cnt ? first + 256 * (qb - 8 + i) : 0];
 #pragma unroll
-        for (int i = 7; i >= 0; i--)
-          if (qb - 8 + i < cnt) cpart = ops.add(ops.mul(cpart, tab.Y256), h[i]);
-      }
-      cpart = ops.mul(cpart, ops.mul(tab.YA[tid & 15], tab.YB[tid >> 4]));
-    }
+    for (int i = 7; i >= 0; i--)
+      if (qb - 8 + i < cnt) cpart = ops.add(ops.mul(cpart, tab.Y256), h[i]);
   }
+  if (cnt) cpart = ops.mul(cpart, ops.mul(ya, yb));
+  const u64 wn = tid < 255 ? wn_raw : 0;
   // sum over the workgroup: inside the wavefront through the cross-lane network, the four wavefront sums through LDS
 #pragma unroll
   for (int s = 0; s < 6; s++) cpart = ops.add(cpart, cx.shfl_xor(cpart, 1u << s));
@@ -179,8 +182,7 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
   const u64 cin = ops.add(ops.add(sc[0], sc[1]), ops.add(sc[2], sc[3]));
   if (b == 0 && tid == 0 && rem) *rem = ops.add(H[0], ops.mul(tab.Y, cin));
   // S(first coefficient of the next lane), then down the run
-  const u32 k = 255 - tid;
-  u64 r = ops.add(wn, ops.mul(tab.zp[k], cin));
+  u64 r = ops.add(wn, ops.mul(zpk, cin));
   const u64 z = tab.z;
   u64 o[PL];
 #pragma unroll
