@@ -142,6 +142,18 @@ def test_small_kernel_fused_multiply_arguments(emu):
         run(emu, *args)
 
 
+def test_small_kernel_every_load_up_front(emu):
+    """the latency kernel issues all of a pass's global loads before it waits for any (ntt_small.h): the paths whose loads used to
+    sit behind branches -- two-level inter-pass twiddles (matrix limit below the size), the fused multiply's second operand,
+    a second operand together with padding limits that differ per batch entry, odd pass sizes -- against the oracle"""
+    for args in ((16, 1, 0, 4, 12, 25, 0, 0, 1), (15, 2, 1, 4, 10, 25, 0, 0, 1), (14, 2, 0, 4, 18, 25, 9000, 0, 1, 5000, 1),
+                 (16, 1, 1, 4, 18, 25, 0, 0, 1, 0, 1), (13, 2, 0, 4, 10, 25, 3000, 0, 1, 0, 1)):
+        out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+        lines = out.stdout.strip().splitlines()
+        assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+        assert all("kernel=small" in l for l in lines if l.startswith("pass")), out.stdout
+
+
 @pytest.mark.parametrize("k,batch,want_tiles", [(20, 1, 256), (21, 1, 256), (21, 2, 128), (22, 1, 256)])
 def test_planner_narrows_tiles_until_every_cu_has_one(emu, k, batch, want_tiles):
     """auto_tiles: a pass of fewer than 256 workgroups gets narrower tiles (not below 4 columns); the specialised kernels
