@@ -717,8 +717,9 @@ def main():
     if pmc and log2n == wl_log2n and batch == wl_batch:
         # every kernel of the step that moved data (the passes of a transform; the two scan kernels of a division): the
         # step's traffic and VALU count are SUMS over them, each counted once per step
-        kerns = [kname for kname, c in pmc.get("counters", {}).items()
-                 if "_hbm_bytes_per_launch" in c and "copyBuffer" not in kname and "fillBuffer" not in kname]
+        # (the library's kernels only: under the profiler the same process also runs torch's roll / fill kernels while it sets
+        # its buffers up, once, not per step)
+        kerns = [kname for kname, c in pmc.get("counters", {}).items() if "_hbm_bytes_per_launch" in c and "ronk::" in kname]
         kerns.sort(key=lambda kname: -pmc["counters"][kname].get("_avg_us", 0))
         if kerns:
             cs = [pmc["counters"][kname] for kname in kerns]

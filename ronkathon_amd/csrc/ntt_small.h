@@ -7,7 +7,7 @@
 // R*C/4 work-items doing log4(R) rounds of one radix-4 butterfly each (omega_4 = 2^48: a shift), i.e. a quarter of the
 // instructions per lane and four times the waves; more barriers and one table twiddle per coefficient and round do not
 // matter when nothing else competes for the VALU.  Selected by the planner (plan.h) for two-pass plans whose whole batch
-// is at most 2^19 coefficients.
+// is small (plan.h: at most 2^18 coefficients, 2^19 for n <= 2^17, 2^20 for n <= 2^14).
 //
 // Same TileArgs contract as tile_body (strides, blocked rows, inter-pass twiddle by two-level table or full matrix, scale,
 // second operand and implicit padding / truncation of the fused polynomial multiply; no staged I/O), same results: X[k] = sum_j x[j] omega^{jk}, natural order in and out

@@ -234,12 +234,19 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     // different phases -- beat 16384 for 2^10-row passes (2^20 x 64: 0.961 -> 0.826 ms); with one tile per CU
     // (a single 2^22 transform) the large tile stays better, and for 2^8 / 2^9-row passes C = 16 stays best.
     const bool many_tiles = auto_tiles && (double)batch * (double)n / 16384.0 >= 1024.0;
-    // Latency regime (ntt_small.h): the whole batch is at most 2^19 coefficients -- with 16 coefficients per work-item that
+    // Latency regime (ntt_small.h): the whole batch is at most 2^19 .. 2^20 coefficients -- with 16 coefficients per work-item that
     // is at most 512 waves on 1024 SIMDs and the time is one wave's instruction stream.  Measured (forward + inverse, same
     // box): 2^13 34.9 -> 23.3 us, 2^16 35.1 -> 25.9, 2^17 43.8 -> 32.0, 2^18 56.6 -> 38.2, 4 x 2^16 forward 18.1 -> 13.3;
     // one forward 2^19 37.3 -> 26.7, 64 x 2^13 19.1 -> 13.7; at 2^20 coefficients it is a draw or worse (single 47.2 -> 49.3,
     // 16 x 2^16 19.4 -> 22.7).  RONK_SMALL = 0 / 1 forces it.
-    bool small = auto_tiles && batch * n <= ((u64)1 << 19) && ka <= 10 && kb <= 10;
+    // Round 3 (late), both forms as they are now (the latency kernel issues all its loads up front, the tile kernels are
+    // specialised; profiles/r03_small_kernel_loads.txt, one transform / batch at a time): up to 2^18 coefficients always
+    // (2^18: 15.7 us against 20.8); at 2^19 for n <= 2^17 (4 x 2^17: 20.0 against 22.6; but 2 x 2^18: 23.8 against 22.7, one
+    // 2^19: 27.1 against 24.5); at 2^20 for n <= 2^14 (128 x 2^13: 18.6 against 20.9, 64 x 2^14: 19.4 against 21.0; 32 x 2^15 a
+    // draw, 16 x 2^16: 21.2 against 19.8).
+    const u64 total = (u64)batch * n;
+    bool small = auto_tiles && ka <= 10 && kb <= 10 &&
+                 (total <= ((u64)1 << 18) || (total <= ((u64)1 << 19) && log2n <= 17) || (total <= ((u64)1 << 20) && log2n <= 14));
     if (const char* e = getenv("RONK_SMALL")) small = atoi(e) != 0 && ka <= 10 && kb <= 10;
     int lc1 = max_logc, lc2 = max_logc;
     // Round 3, re-measured with the specialised kernels and HBM-cold buffers (bench.py --mode batch --rotate 8, same box,

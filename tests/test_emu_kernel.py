@@ -125,15 +125,28 @@ def test_half_lds_exchange(emu, args):
     assert all("kernel=half:" in l for l in lines if l.startswith("pass")), out.stdout
 
 
-@pytest.mark.parametrize("args", [(13, 2, 0), (13, 1, 1), (14, 3, 1), (15, 1, 0), (16, 1, 0), (16, 4, 1), (17, 2, 0), (18, 1, 1), (19, 1, 0)])
+@pytest.mark.parametrize("args", [(13, 2, 0), (13, 1, 1), (14, 3, 1), (15, 1, 0), (16, 1, 0), (16, 4, 1), (17, 2, 0), (18, 1, 1), (17, 4, 0),
+                                  (13, 128, 1), (14, 64, 0)])
 def test_small_latency_kernel(emu, args):
     """ntt_small.h (4 coefficients per work-item, radix-4 rounds in place; a radix-2 round for odd pass sizes): the plans
-    the planner builds for at most 2^19 coefficients in all (auto_tiles = 1), forward and inverse, batched"""
+    the planner builds (auto_tiles = 1) for at most 2^18 coefficients in all, for 2^19 when n <= 2^17 and for 2^20 when
+    n <= 2^14; forward and inverse, batched"""
     k, batch, inv = args
     out = subprocess.run([emu, str(k), str(batch), str(inv), "4", "18", "25", "0", "0", "1"], capture_output=True, text=True, timeout=600)
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
     assert all("kernel=small" in l for l in lines if l.startswith("pass")), out.stdout
+
+
+@pytest.mark.parametrize("args", [(19, 1, 0), (18, 2, 1), (16, 16, 0), (17, 8, 0), (15, 32, 1)])
+def test_planner_leaves_the_latency_form_where_the_tile_kernels_are_faster(emu, args):
+    """plan.h's rule, re-measured late in round 3 (profiles/r03_small_kernel_loads.txt): one 2^19 transform, 2 x 2^18 and
+    2^20 coefficients of transforms longer than 2^14 run the tile kernels"""
+    k, batch, inv = args
+    out = subprocess.run([emu, str(k), str(batch), str(inv), "4", "18", "25", "0", "0", "1"], capture_output=True, text=True, timeout=900)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
+    assert not any("kernel=small" in l for l in lines if l.startswith("pass")), out.stdout
 
 
 def test_small_kernel_fused_multiply_arguments(emu):

@@ -6,6 +6,15 @@ TAG=${1:-r03}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
+# counters first: the bench lines below then carry the per-step traffic / VALU sums of THIS library (bench.py refuses counter
+# files taken on other sources)
+timeout 500 bash tools/profile.sh ntt22 ${TAG}_1stream --mode streams --streams 1 > $OUT/prof_1stream.txt 2>&1
+timeout 500 bash tools/profile.sh ntt22 ${TAG}_many > $OUT/prof_many.txt 2>&1
+timeout 500 bash tools/profile.sh batch16 ${TAG}_batch16 > $OUT/prof_batch16.txt 2>&1
+timeout 500 bash tools/profile.sh mul22 ${TAG}_mul22 > $OUT/prof_mul22.txt 2>&1
+for t in 1stream many batch16 mul22; do cp gpurun_out/prof_${TAG}_$t/summary.txt $OUT/summary_$t.txt; cp gpurun_out/prof_${TAG}_$t/summary.json $OUT/summary_$t.json; done
+cp gpurun_out/prof_${TAG}_1stream/summary.json profiles/latest_pmc_ntt22.json; cp gpurun_out/prof_${TAG}_batch16/summary.json profiles/latest_pmc_batch16.json
+for wl in open22 eval22; do timeout 300 bash tools/profile.sh $wl ${TAG}_$wl > $OUT/prof_$wl.txt 2>&1; cp gpurun_out/prof_${TAG}_$wl/summary.json profiles/latest_pmc_$wl.json; cp gpurun_out/prof_${TAG}_$wl/summary.json $OUT/summary_$wl.json; cp gpurun_out/prof_${TAG}_$wl/summary.txt $OUT/summary_$wl.txt; done
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/err
 timeout 300 python bench.py > $OUT/bench_default.json 2>> $OUT/err
 timeout 200 python bench.py --no-cpu --mode streams --streams 2 > $OUT/bench_ntt22_2streams.json 2>> $OUT/err
@@ -19,11 +28,6 @@ timeout 100 python bench.py --no-cpu --workload fourstep --log2n 26 --steps 20 -
 timeout 100 python bench.py --no-cpu --workload sharded --ranks 8 --log2n 26 --steps 20 --warmup 3 > $OUT/bench_sharded_8ranks_1gpu.json 2>> $OUT/err
 # the multi-rank control flow of bench.py (two ranks sharing this GPU over gloo: a smoke test of --gpus N, not a measurement)
 RONK_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu > $OUT/bench_2ranks_gloo_smoke.json 2>> $OUT/err
-timeout 500 bash tools/profile.sh ntt22 ${TAG}_1stream --mode streams --streams 1 > $OUT/prof_1stream.txt 2>&1
-timeout 500 bash tools/profile.sh ntt22 ${TAG}_many > $OUT/prof_many.txt 2>&1
-timeout 500 bash tools/profile.sh batch16 ${TAG}_batch16 > $OUT/prof_batch16.txt 2>&1
-timeout 500 bash tools/profile.sh mul22 ${TAG}_mul22 > $OUT/prof_mul22.txt 2>&1
-for t in 1stream many batch16 mul22; do cp gpurun_out/prof_${TAG}_$t/summary.txt $OUT/summary_$t.txt; cp gpurun_out/prof_${TAG}_$t/summary.json $OUT/summary_$t.json; done
 tail -2 $OUT/err
 python - <<PY
 import json,glob
