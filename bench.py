@@ -192,6 +192,21 @@ def cpu_baseline_batched(log2n, budget_s=10.0):
                       "reference restated in C" % (total, log2n, dt, cores)}
 
 
+def self_launch_command(gpus, environ, argv):
+    """The command line `python bench.py --gpus N ...` re-executes itself under when no launcher set WORLD_SIZE: one rank per
+    GPU through torch.distributed.run on 127.0.0.1 (the contract's own form).  None when nothing is to be launched: N = 1,
+    or the ranks exist already.  The in-library `sharded` workload drives every GPU from ONE process and never re-launches."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    if "--workload" in argv and argv[argv.index("--workload") + 1: argv.index("--workload") + 2] == ["sharded"]:
+        return None
+    if any(a == "--workload=sharded" for a in argv):
+        return None
+    port = environ.get("MASTER_PORT") or str(29500 + os.getpid() % 1000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(argv[0])] + list(argv[1:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,14 +232,28 @@ def main():
     ap.add_argument("--rotate", type=int, default=-1,
                     help="distinct input AND output buffers the steps cycle through (HBM-cold protocol; default 8 for ntt22 "
                          "= 512 MiB touched between two uses of a buffer, else 1 = the same buffers every step)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "mesh", "host"],
+                    help="fourstep / sharded: how the transpose travels -- rccl: torch.distributed all_to_all_single on the nccl "
+                         "backend (fourstep, one process per GPU) or the library's dlopen'ed ncclGroup Send/Recv (sharded, one "
+                         "process); mesh: the library's hipMemcpyPeerAsync mesh (sharded); host: staged through host memory "
+                         "(gloo smoke runs); auto = rccl for fourstep, mesh for sharded")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the contract's
+    # torch.distributed.run command line), then fall through as rank RANK of WORLD_SIZE.  Under a launcher the two must agree.
+    cmd = self_launch_command(args.gpus, os.environ, sys.argv)
+    if cmd:
+        os.execv(cmd[0], cmd)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and args.workload != "sharded":
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or run plain "
+                 "`python bench.py --gpus N`, which starts the ranks itself)" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     # One rank per GPU.  RONK_BENCH_BACKEND=gloo + fewer GPUs than ranks is a control-flow smoke test only (ranks then
     # share devices); the driver's runs use the default: nccl (= RCCL) with local_rank < device_count.
@@ -244,7 +273,20 @@ def main():
     wl = args.workload
     if wl == "fourstep":
         from ronkathon_amd import dist as rdist
-        res = rdist.bench_fourstep(args.log2n or 26, args.steps, args.warmup)
+        # the exchange: RCCL all_to_all_single on the nccl backend (one process per GPU, the product path) or, on a backend
+        # without device collectives (gloo smoke runs on fewer GPUs than ranks), staged through host memory
+        want = args.exchange if args.exchange != "auto" else ("rccl" if backend == "nccl" else "host")
+        if (want == "rccl") != (backend == "nccl") or want == "mesh":
+            sys.exit("bench.py --workload fourstep: --exchange %s needs %s" % (
+                want, {"rccl": "the nccl backend (unset RONK_BENCH_BACKEND)", "host": "RONK_BENCH_BACKEND=gloo",
+                       "mesh": "--workload sharded (the one-process in-library form)"}[want]))
+        res = rdist.bench_fourstep(args.log2n or 26, args.steps, args.warmup, chunks=args.chunks or None)
+        res["config"]["exchange"] = want
+        one_ = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(one_)
+        res["ranks_seen"] = int(one_.item())
+        assert res["ranks_seen"] == args.gpus, "ranks_seen %d != --gpus %d" % (res["ranks_seen"], args.gpus)
         if rank == 0:
             print(json.dumps(res))
         if world > 1:
@@ -392,7 +434,10 @@ def main():
         ndev = torch.cuda.device_count()
         W = args.ranks or ndev
         lg = args.log2n or 26
-        sp = L.ShardedPlan(lg, [g % ndev for g in range(W)], chunks=args.chunks)
+        ex = {"auto": L.EXCHANGE_MESH, "mesh": L.EXCHANGE_MESH, "rccl": L.EXCHANGE_RCCL}.get(args.exchange)
+        if ex is None:
+            sys.exit("bench.py --workload sharded: --exchange mesh or rccl")
+        sp = L.ShardedPlan(lg, [g % ndev for g in range(W)], chunks=args.chunks, exchange=ex)
         per = sp.per_rank
         din, dout = [], []
         for g in range(W):
@@ -416,8 +461,10 @@ def main():
                           "value": args.steps / dt, "unit": "NTT/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": min(dts) / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-                          "config": {"workload": "four-step NTT n = 2^%d over %d rank(s) on %d GPU(s), hipMemcpyPeerAsync mesh, "
-                                                 "%d column chunk(s)" % (lg, W, ndev, sp.chunks), "ranks": W, "chunks": sp.chunks},
+                          "config": {"workload": "four-step NTT n = 2^%d over %d rank(s) on %d GPU(s), %s, "
+                                                 "%d column chunk(s)" % (lg, W, ndev, "ncclGroup Send/Recv (dlopen'ed RCCL)" if ex == L.EXCHANGE_RCCL
+                                                                         else "hipMemcpyPeerAsync mesh", sp.chunks),
+                                     "ranks": W, "chunks": sp.chunks, "exchange": "rccl" if ex == L.EXCHANGE_RCCL else "mesh"},
                           "roofline": {"bound": "hbm", "achieved": 16.0 * nn / ndev / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": 16.0 * nn / ndev / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None}}))
         sp.close()
@@ -806,6 +853,7 @@ def main():
         res["config"].update({"mode": mode, "group": group, "rotate": R_cold, "plan_handles": len(plans),
                               "in_flight": plans[0].in_flight() if hasattr(L.lib, "ronk_plan_in_flight") else None})
         res["ranks_seen"] = ranks_seen
+        assert ranks_seen == args.gpus, "ranks_seen %d != --gpus %d" % (ranks_seen, args.gpus)
         if not args.no_cpu and world == 1 and wl == "ntt22":       # reported at N = 1 only (bench contract)
             res["cpu_baseline"] = cpu_baseline(log2n)
         if not args.no_cpu and world == 1 and wl in ("batch16", "rs16"):

@@ -1,0 +1,37 @@
+"""bench.py's launch contract (no GPU needed): `python bench.py --gpus N` starts its N ranks itself through
+torch.distributed.run on 127.0.0.1; under a launcher --gpus must equal WORLD_SIZE (a mismatch would print a one-GPU line
+under an eight-GPU label)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_self_launch_command_line():
+    cmd = bench.self_launch_command(4, {}, ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert os.path.isabs(cmd[cmd.index("--master-port") + 2]) and cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+    # the port can be pinned from outside
+    cmd = bench.self_launch_command(2, {"MASTER_PORT": "29777"}, ["bench.py", "--gpus", "2"])
+    assert cmd[cmd.index("--master-port") + 1] == "29777"
+
+
+def test_no_self_launch_when_ranks_exist_or_single():
+    assert bench.self_launch_command(1, {}, ["bench.py"]) is None
+    assert bench.self_launch_command(8, {"WORLD_SIZE": "8", "RANK": "0"}, ["bench.py", "--gpus", "8"]) is None
+    # the in-library sharded transform drives all GPUs from ONE process
+    assert bench.self_launch_command(8, {}, ["bench.py", "--gpus", "8", "--workload", "sharded"]) is None
+    assert bench.self_launch_command(8, {}, ["bench.py", "--gpus", "8", "--workload=sharded"]) is None
+
+
+def test_gpus_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
