@@ -506,7 +506,7 @@ def main():
     if mode == "many":      # ONE handle; the library keeps two transforms in flight (ronk_plan_opts::in_flight)
         plans = [L.Plan(P, G, log2n, batch, local_rank, tile_log2_columns=args.tile_logc if args.tile_logc >= -1 else -1,
                         twiddle_matrix_log2_max=args.twf, in_flight=2)]
-    elif mode == "batch":   # ONE handle, `group` polynomials per call; in_flight left to the library (2 at this size)
+    elif mode == "batch":   # ONE handle, `group` polynomials per call; in_flight left to the library (automatic = 1)
         plans = [L.Plan(P, G, log2n, pb, local_rank, tile_log2_columns=args.tile_logc if args.tile_logc >= -1 else -1,
                         twiddle_matrix_log2_max=args.twf)]
     else:

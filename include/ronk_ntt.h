@@ -333,6 +333,15 @@ int ronk_dev_free(void* ptr);
 int ronk_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int ronk_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int ronk_dev_sync(void);
+/* The device the helpers above act on (the calling thread's current HIP device; plans carry their own ordinal).  A host that
+ * places one block per GPU (device::DevicePoly of the Rust shim, the sharded transform's per-rank blocks) selects it around
+ * every alloc / copy / free.  RONK_ERR_INVALID for an ordinal outside [0, ronk_device_count). */
+int ronk_set_device(int device);
+int ronk_get_device(int* device);
+/* Releases the library's cached device workspace (the event-guarded buffer pool behind the Newton division, the fast
+ * Reed-Solomon decode and the scans) once the work that used it has finished; buffers above 256 MiB are never cached.
+ * Safe at any time; the next call that needs workspace allocates again. */
+int ronk_trim_workspace(void);
 
 #ifdef __cplusplus
 }

@@ -24,9 +24,35 @@ struct WsSlot {
   bool used = false;   // ever had work queued
   bool busy = false;   // leased right now
   bool ev_valid = false;   // `done` was recorded behind the slot's last work
+  bool oneoff = false;     // larger than WS_CACHE_MAX: never pooled, freed once its work has completed
 };
 static std::mutex g_ws_mu;
 static std::vector<WsSlot*> g_ws;
+// Retention bound: the pool keeps what the scans, the decode and ordinary divisions need (64 KiB .. 256 MiB per slot, a power
+// of two each).  Anything larger -- the ~10 x Lp x 8 bytes of a 2^27 Newton division, 16 GiB after rounding -- is a ONE-OFF
+// allocation of exactly the requested size: on release it goes to g_ws_grave with an event behind its last work and is freed
+// by the next acquire / ronk_trim_workspace() that finds the event complete (never while queued work still uses it).
+static constexpr size_t WS_CACHE_MAX = (size_t)256 << 20;
+static std::vector<WsSlot*> g_ws_grave;
+static void ws_free_slot(WsSlot* w) {
+  if (w->p) (void)hipFree(w->p);
+  if (w->ctl) (void)hipFree(w->ctl);
+  if (w->lb) (void)hipFree(w->lb);
+  if (w->done) (void)hipEventDestroy(w->done);
+  delete w;
+}
+// g_ws_mu held.  wait = false: free what has completed; true: wait for the rest (ronk_trim_workspace).
+static void ws_reap(bool wait) {
+  for (size_t i = 0; i < g_ws_grave.size();) {
+    WsSlot* w = g_ws_grave[i];
+    bool done = !w->ev_valid || hipEventQuery(w->done) == hipSuccess;
+    if (!done && wait) done = hipEventSynchronize(w->done) == hipSuccess;
+    if (!done) { (void)hipGetLastError(); i++; continue; }
+    ws_free_slot(w);
+    g_ws_grave[i] = g_ws_grave.back();
+    g_ws_grave.pop_back();
+  }
+}
 // Completion events are recorded only once the pool has been seen from a second stream: while every call comes from ONE
 // stream, stream order protects a reused slot and the hipEventRecord per call (~1.5 us of the 12.5 us an evaluate of 2^22
 // coefficients takes end to end) buys nothing.  The stream that triggers the switch simply gets a fresh slot.
@@ -37,6 +63,14 @@ struct WsLease {
   ~WsLease() {
     if (!slot) return;
     std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (slot->oneoff) {   // never pooled: an event behind its work, freed by whoever finds it complete
+      slot->ev_valid = hipEventRecord(slot->done, s) == hipSuccess;
+      if (!slot->ev_valid) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+      slot->busy = false;
+      g_ws_grave.push_back(slot);
+      ws_reap(false);
+      return;
+    }
     slot->ev_valid = g_ws_multi && hipEventRecord(slot->done, s) == hipSuccess;
     slot->last = s; slot->used = true; slot->busy = false;
   }
@@ -44,26 +78,43 @@ struct WsLease {
     s = st;
     size_t need = 65536;
     while (need < bytes) need <<= 1;
+    const bool oneoff = need > WS_CACHE_MAX;
+    if (oneoff) need = (bytes + 255) & ~(size_t)255;   // exactly what was asked for, not the next power of two
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_ws_mu);
+    ws_reap(false);
     size_t on_dev = 0;
     WsSlot* waitable = nullptr;
     for (WsSlot* w : g_ws) {
+      if (oneoff) break;
       if (w->device != dev) continue;
       on_dev++;
       if (w->busy || w->bytes < need) continue;
       if (!w->used || w->last == st || (w->ev_valid && hipEventQuery(w->done) == hipSuccess)) { slot = w; break; }
-      g_ws_multi = true;                        // a slot last used by ANOTHER stream: from now on every release leaves an event
+      if (!g_ws_multi || !w->ev_valid) {
+        // First sight of a slot last used by ANOTHER stream: from now on every release leaves an event.  This slot was
+        // released before the switch, so put its event behind everything queued on that stream so far (which includes the
+        // slot's last work) -- no device-wide wait, and nothing is synchronised while the pool lock is held.
+        g_ws_multi = true;
+        if (!w->ev_valid) {
+          w->ev_valid = hipEventRecord(w->done, w->last) == hipSuccess;
+          if (!w->ev_valid) (void)hipGetLastError();   // the stream is gone: its work has completed or was abandoned with it
+        }
+        if (w->ev_valid && hipEventQuery(w->done) == hipSuccess) { slot = w; break; }
+        (void)hipGetLastError();
+      }
       if (!waitable) waitable = w;
     }
     if (!slot && waitable && on_dev >= 32) {  // bound the pool: wait for an old slot instead of growing
       if (waitable->ev_valid) (void)hipEventSynchronize(waitable->done);
-      else (void)hipDeviceSynchronize();        // released before the switch to events: nothing to wait on but the device
+      else (void)hipDeviceSynchronize();   // its stream was destroyed under queued work (no event could be placed): rare, and
+                                           // the current device IS the slot's device (filter above)
       slot = waitable;
     }
     if (!slot) {
       WsSlot* w = new WsSlot();
+      w->oneoff = oneoff;
       hipError_t e = hipMalloc(&w->p, need);
       if (e == hipSuccess) e = hipMalloc((void**)&w->ctl, 64);
       if (e == hipSuccess) e = hipMemset(w->ctl, 0, 64);
@@ -72,7 +123,7 @@ struct WsLease {
       if (e == hipSuccess) e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
       if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); if (w->ctl) (void)hipFree(w->ctl); if (w->lb) (void)hipFree(w->lb); delete w; return hip_fail(e, "workspace"); }
       w->bytes = need; w->device = dev;
-      g_ws.push_back(w);
+      if (!oneoff) g_ws.push_back(w);
       slot = w;
     }
     slot->busy = true;
@@ -90,6 +141,28 @@ struct WsLease {
   }
   void lb_commit() { slot->lb_calls++; }
 };
+// Releases every idle pool slot and every finished one-off buffer (include/ronk_ntt.h).  Waits for the work behind them
+// (events; a slot released in single-stream mode has none: its stream is synchronised), never for unrelated streams.
+extern "C" int ronk_trim_workspace(void) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  ws_reap(true);
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for (size_t i = 0; i < g_ws.size();) {
+    WsSlot* w = g_ws[i];
+    if (w->busy) { i++; continue; }
+    (void)hipSetDevice(w->device);
+    if (w->used) {
+      hipError_t e = w->ev_valid ? hipEventSynchronize(w->done) : hipStreamSynchronize(w->last);
+      if (e != hipSuccess) (void)hipGetLastError();   // a destroyed stream: nothing of it can still run
+    }
+    ws_free_slot(w);
+    g_ws[i] = g_ws.back();
+    g_ws.pop_back();
+  }
+  if (cur >= 0) (void)hipSetDevice(cur);
+  return RONK_OK;
+}
 // the one-launch scans keep host state per call (which look-back array is clean): not for a capturing stream
 static bool stream_is_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

@@ -244,4 +244,18 @@ extern "C" int ronk_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return RONK_OK;
 }
 extern "C" int ronk_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return RONK_OK; }
+extern "C" int ronk_set_device(int device) {
+  int n = 0;
+  ronk_device_count(&n);
+  if (n <= 0) return RONK_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return RONK_ERR_INVALID;
+  HIPCHK(hipSetDevice(device));
+  return RONK_OK;
+}
+extern "C" int ronk_get_device(int* device) {
+  if (!device) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  HIPCHK(hipGetDevice(device));
+  return RONK_OK;
+}
 

@@ -1,6 +1,8 @@
 // ronk_plan.hip -- C ABI of libronk_ntt.so, part 2: plan construction (plan.h), twiddle upload, transform launches
 // (tile_kernels.hip; generic primes: field_kernels.h), staging for the host-pointer entry points, the plan cache and
 // what is built on it (fft / ifft / dft, polynomial multiply, batched Reed-Solomon encode).
+#include <map>
+
 #include "runtime.h"
 #include "ntt_aux_kernels.h"
 
@@ -184,10 +186,26 @@ static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* ou
 // order `s` behind the previous user of the plan's scratch (see ronk_plan::scratch_ev); caller holds stream_mu
 static void scratch_acquire(ronk_plan* pl, hipStream_t s) {
   if (!pl->scratch_used || pl->scratch_stream == s) return;
-  // first time the plan is seen on a second stream: nothing was recorded behind the previous call (single-stream users
-  // never pay for an event) -- drain the device once, from now on every call leaves an event behind
-  if (!pl->scratch_multi || !pl->scratch_ev_valid || hipStreamWaitEvent(s, pl->scratch_ev, 0) != hipSuccess)
+  // First time the plan is seen on a second stream: nothing was recorded behind the previous call (single-stream users
+  // never pay for an event).  Place the event NOW behind everything queued on the previous stream so far -- that includes
+  // the previous call -- and let `s` wait for it on the device: no host stall, nothing device-wide (legal beside a
+  // capture in global mode).  From now on every call leaves its own event behind (scratch_release).
+  hipError_t e = hipSuccess;
+  if (!pl->scratch_multi || !pl->scratch_ev_valid) {
+    if (!pl->scratch_ev) e = hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(pl->scratch_ev, pl->scratch_stream);
+    pl->scratch_ev_valid = e == hipSuccess;
+  }
+  if (pl->scratch_ev_valid) e = hipStreamWaitEvent(s, pl->scratch_ev, 0);
+  if (!pl->scratch_ev_valid || e != hipSuccess) {
+    // the previous stream no longer exists (or the wait could not be queued): the last resort, on the PLAN's device
+    (void)hipGetLastError();
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != pl->device) (void)hipSetDevice(pl->device);
     (void)hipDeviceSynchronize();
+    if (cur >= 0 && cur != pl->device) (void)hipSetDevice(cur);
+  }
   pl->scratch_multi = true;
 }
 static void scratch_release(ronk_plan* pl, hipStream_t s) {
@@ -269,7 +287,14 @@ static int many_dev(ronk_plan* pl, bool inverse, const uint64_t* const* d_in, ui
     return RONK_OK;
   }
   std::lock_guard<std::mutex> lk(pl->stream_mu);
-  if (!pl->d_tmp2) HIPCHK(hipMalloc((void**)&pl->d_tmp2, pl->n * pl->batch * 8));
+  if (!pl->d_tmp2) {   // the side lane's scratch lives on the PLAN's device, whatever the caller's current device is
+    int cur = -1;
+    HIPCHK(hipGetDevice(&cur));
+    if (cur != pl->device) HIPCHK(hipSetDevice(pl->device));
+    hipError_t em = hipMalloc((void**)&pl->d_tmp2, pl->n * pl->batch * 8);
+    if (cur != pl->device) (void)hipSetDevice(cur);
+    if (em != hipSuccess) return hip_fail(em, "hipMalloc(side scratch)");
+  }
   scratch_acquire(pl, s);
   HIPCHK(hipEventRecord(pl->ev_fork, s));
   HIPCHK(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
@@ -336,6 +361,33 @@ extern "C" int ronk_ntt_inverse_dev(ronk_plan* pl, const uint64_t* in, uint64_t*
   return transform_dev(pl, true, in, nullptr, out, (hipStream_t)st);
 }
 
+// Page-locking of the caller's buffers for the duration of a pipelined host call.  Registrations are shared: two threads that
+// transform from the SAME input buffer (on different plans) hold one registration between them (reference count), memory
+// that is page-locked already -- hipHostMalloc, the caller's own hipHostRegister -- is left alone, and only a range that
+// OVERLAPS a foreign registration partially is refused by the runtime: the copies of that call then run synchronously
+// (correct, un-overlapped).  The lock covers the runtime calls only.
+static std::mutex g_pin_mu;
+static std::map<const void*, std::pair<size_t, int>> g_pins;   // base -> (bytes, users)
+static bool pin_acquire(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pins.find(p);
+  if (it != g_pins.end() && it->second.first >= bytes) { it->second.second++; return true; }
+  if (it != g_pins.end()) return false;                       // ours, but shorter: leave it to its owner
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return false;   // page-locked by the caller
+  (void)hipGetLastError();
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+  g_pins[p] = {bytes, 1};
+  return true;
+}
+static void pin_release(const void* p) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pins.find(p);
+  if (it == g_pins.end() || --it->second.second > 0) return;
+  (void)hipHostUnregister(const_cast<void*>(p));
+  g_pins.erase(it);
+}
+
 static int ensure_stage(ronk_plan* pl) {
   const size_t bytes = pl->n * pl->batch * 8;
   if (!pl->d_stage_in) HIPCHK(hipMalloc((void**)&pl->d_stage_in, bytes));
@@ -370,10 +422,8 @@ static int transform_host_pipelined(ronk_plan* pl, bool inverse, const u64* in, 
   // again; buffers that are already page-locked (hipHostMalloc, an earlier registration) are used as they are, and if a
   // registration is refused the copies simply fall back to their synchronous behaviour.
   const size_t total_bytes = (size_t)(pl->batch * n * 8);
-  const bool reg_in = hipHostRegister(const_cast<u64*>(in), total_bytes, hipHostRegisterDefault) == hipSuccess;
-  if (!reg_in) (void)hipGetLastError();
-  const bool reg_out = hipHostRegister(out, total_bytes, hipHostRegisterDefault) == hipSuccess;
-  if (!reg_out) (void)hipGetLastError();
+  const bool reg_in = pin_acquire(in, total_bytes);
+  const bool reg_out = pin_acquire(out, total_bytes);
   int rc = RONK_OK;
   for (u32 i = 0; i < nsl && !rc; i++) {
     const u64 b0 = (u64)i * per, cnt = pl->batch - b0 < per ? pl->batch - b0 : per;
@@ -394,8 +444,8 @@ static int transform_host_pipelined(ronk_plan* pl, bool inverse, const u64* in, 
   hipError_t e1 = hipStreamSynchronize(pl->st_h2d), e2 = hipStreamSynchronize(pl->st_exec), e3 = hipStreamSynchronize(pl->st_d2h);
   if (!rc && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
     rc = hip_fail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3, "pipeline drain");
-  if (reg_in) (void)hipHostUnregister(const_cast<u64*>(in));
-  if (reg_out) (void)hipHostUnregister(out);
+  if (reg_in) pin_release(in);
+  if (reg_out) pin_release(out);
   return rc;
 }
 

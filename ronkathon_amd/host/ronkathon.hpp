@@ -327,15 +327,18 @@ class Plan {
   ~Plan() { if (h_) ronk_plan_destroy(h_); }
   size_t n() const { return (size_t)1 << log2n_; }
   int in_flight() const { return ronk_plan_in_flight(h_); }
-  void forward(const DevicePoly& src, DevicePoly& dst) const { check(ronk_ntt_forward_dev(h_, src.data(), dst.data(), nullptr)); }
-  void inverse(const DevicePoly& src, DevicePoly& dst) const { check(ronk_ntt_inverse_dev(h_, src.data(), dst.data(), nullptr)); }
+  // every polynomial handed to the plan holds exactly batch * n elements (the library sees bare pointers: a shorter
+  // buffer would be read / written out of bounds) -- the Rust mirror asserts the same (rust/.../device.rs)
+  void need(const DevicePoly& p) const { if (p.size() != n() * batch_) throw Panic(RONK_ERR_INVALID); }
+  void forward(const DevicePoly& src, DevicePoly& dst) const { need(src); need(dst); check(ronk_ntt_forward_dev(h_, src.data(), dst.data(), nullptr)); }
+  void inverse(const DevicePoly& src, DevicePoly& dst) const { need(src); need(dst); check(ronk_ntt_inverse_dev(h_, src.data(), dst.data(), nullptr)); }
   // K unrelated polynomials per call: the library keeps two transforms in flight
   void forward_many(const std::vector<const DevicePoly*>& src, const std::vector<DevicePoly*>& dst) const {
     std::vector<const uint64_t*> in;
     std::vector<uint64_t*> out;
-    for (auto* p : src) in.push_back(p->data());
-    for (auto* p : dst) out.push_back(p->data());
-    if (in.size() != out.size()) throw Panic(RONK_ERR_INVALID);
+    if (src.size() != dst.size()) throw Panic(RONK_ERR_INVALID);
+    for (auto* p : src) { need(*p); in.push_back(p->data()); }
+    for (auto* p : dst) { need(*p); out.push_back(p->data()); }
     check(ronk_ntt_forward_many_dev(h_, in.data(), out.data(), in.size(), nullptr));
   }
   // host vectors through the plan (a batch is pipelined over its polynomials: upload | transform | download)

@@ -59,6 +59,9 @@ impl Plan {
 
   pub fn n(&self) -> usize { 1usize << self.log2n }
 
+  /// the `ronk_plan*` for the crate's other modules (codes.rs)
+  pub(crate) fn raw(&self) -> *mut RonkPlan { self.raw }
+
   pub fn in_flight(&self) -> i32 { unsafe { ffi::ronk_plan_in_flight(self.raw) } }
 
   /// host slices of `batch * n` elements (pinned staging inside the library)
@@ -122,23 +125,54 @@ impl Drop for Plan {
 /// `len` canonical residues resident in HBM (monomial coefficients or values on the roots of unity -- the basis is the
 /// caller's knowledge, exactly like the `B` type parameter of the reference)
 pub struct DevicePoly {
-  ptr: *mut u64,
-  len: usize,
+  ptr:    *mut u64,
+  len:    usize,
+  /// the GPU the memory lives on: alloc / copy / sync / free select it first (`ronk_set_device`)
+  device: i32,
 }
 unsafe impl Send for DevicePoly {}
 
+/// the calling thread's current device (`ronk_get_device`)
+pub fn current_device() -> i32 {
+  let mut d = 0 as c_int;
+  check(unsafe { ffi::ronk_get_device(&mut d) });
+  d
+}
+
+/// selects `device` for the scope, restores the previous one on drop
+struct OnDevice(i32);
+impl OnDevice {
+  fn new(device: i32) -> Self {
+    let prev = current_device();
+    if prev != device {
+      check(unsafe { ffi::ronk_set_device(device) });
+    }
+    Self(prev)
+  }
+}
+impl Drop for OnDevice {
+  fn drop(&mut self) { unsafe { ffi::ronk_set_device(self.0) }; }
+}
+
 impl DevicePoly {
-  /// uninitialised device memory for `len` elements
-  pub fn alloc(len: usize) -> Self {
+  /// uninitialised device memory for `len` elements on the current device
+  pub fn alloc(len: usize) -> Self { Self::alloc_on(current_device(), len) }
+
+  /// ... on GPU `device`: one block per rank of a [`ShardedPlan`] lives on that rank's GPU
+  pub fn alloc_on(device: i32, len: usize) -> Self {
     assert!(len > 0);
+    let _g = OnDevice::new(device);
     let mut p: *mut c_void = ptr::null_mut();
     check(unsafe { ffi::ronk_dev_alloc(&mut p, len * 8) });
-    Self { ptr: p as *mut u64, len }
+    Self { ptr: p as *mut u64, len, device }
   }
 
   /// upload (`Polynomial::new(coefficients)` for a device-resident polynomial)
-  pub fn from_host(coefficients: &[Goldilocks]) -> Self {
-    let d = Self::alloc(coefficients.len());
+  pub fn from_host(coefficients: &[Goldilocks]) -> Self { Self::from_host_on(current_device(), coefficients) }
+
+  pub fn from_host_on(device: i32, coefficients: &[Goldilocks]) -> Self {
+    let d = Self::alloc_on(device, coefficients.len());
+    let _g = OnDevice::new(device);
     check(unsafe { ffi::ronk_memcpy_h2d(d.ptr as *mut c_void, coefficients.as_ptr() as *const c_void, d.len * 8) });
     d
   }
@@ -147,9 +181,17 @@ impl DevicePoly {
 
   pub fn is_empty(&self) -> bool { self.len == 0 }
 
-  /// download (synchronises with the device first)
+  pub fn device(&self) -> i32 { self.device }
+
+  /// raw device pointers for the crate's other modules (codes.rs, bn254.rs) and for callers that bind further entry points
+  pub fn as_ptr(&self) -> *const u64 { self.ptr }
+
+  pub fn as_mut_ptr(&self) -> *mut u64 { self.ptr }
+
+  /// download (synchronises with the polynomial's device first)
   pub fn to_host(&self) -> Vec<Goldilocks> {
     let mut v = vec![Goldilocks(0); self.len];
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_dev_sync() });
     check(unsafe { ffi::ronk_memcpy_d2h(v.as_mut_ptr() as *mut c_void, self.ptr as *const c_void, self.len * 8) });
     v
@@ -157,8 +199,9 @@ impl DevicePoly {
 
   /// `Polynomial::fft` with a cached plan of the library (one-shot: no `Plan` to keep)
   pub fn fft(&self) -> DevicePoly {
+    let _g = OnDevice::new(self.device);
     let plan = Plan::new(log2_exact(self.len), 1);
-    let mut out = DevicePoly::alloc(self.len);
+    let mut out = DevicePoly::alloc_on(self.device, self.len);
     plan.forward(self, &mut out);
     check(unsafe { ffi::ronk_dev_sync() });   // `plan` (its scratch) is dropped on return
     out
@@ -166,8 +209,9 @@ impl DevicePoly {
 
   /// `Polynomial::<Lagrange>::ifft`
   pub fn ifft(&self) -> DevicePoly {
+    let _g = OnDevice::new(self.device);
     let plan = Plan::new(log2_exact(self.len), 1);
-    let mut out = DevicePoly::alloc(self.len);
+    let mut out = DevicePoly::alloc_on(self.device, self.len);
     plan.inverse(self, &mut out);
     check(unsafe { ffi::ronk_dev_sync() });
     out
@@ -175,14 +219,16 @@ impl DevicePoly {
 
   /// `impl Mul` (arithmetic.rs:97-119): `self.len + rhs.len - 1` coefficients; NTT - pointwise - inverse NTT on the device
   pub fn mul(&self, rhs: &DevicePoly) -> DevicePoly {
-    let out = DevicePoly::alloc(self.len + rhs.len - 1);
+    let _g = OnDevice::new(self.device);
+    let out = DevicePoly::alloc_on(self.device, self.len + rhs.len - 1);
     check(unsafe { ffi::ronk_poly_mul_dev(P, G, self.ptr, self.len, rhs.ptr, rhs.len, out.ptr, ptr::null_mut()) });
     out
   }
 
   /// `Polynomial::<Monomial>::evaluate` (mod.rs:133-139); one 8 B/coefficient pass
   pub fn evaluate(&self, x: Goldilocks) -> Goldilocks {
-    let y = DevicePoly::alloc(1);
+    let _g = OnDevice::new(self.device);
+    let y = DevicePoly::alloc_on(self.device, 1);
     check(unsafe { ffi::ronk_poly_eval_dev(P, self.ptr, self.len, x.0, y.ptr, ptr::null_mut()) });
     y.to_host()[0]
   }
@@ -191,8 +237,9 @@ impl DevicePoly {
   /// `[-eval_point, ONE]` (src/kzg/setup.rs:63-78).  The quotient has `len` coefficients, the top one ZERO, like the
   /// reference's D-long quotient.  Panics like the reference for b1 == 0 (`leading_coefficient().inverse().unwrap()`).
   pub fn div_linear(&self, b0: Goldilocks, b1: Goldilocks) -> (DevicePoly, Goldilocks) {
-    let quot = DevicePoly::alloc(self.len);
-    let rem = DevicePoly::alloc(1);
+    let _g = OnDevice::new(self.device);
+    let quot = DevicePoly::alloc_on(self.device, self.len);
+    let rem = DevicePoly::alloc_on(self.device, 1);
     check(unsafe { ffi::ronk_poly_div_linear_dev(P, self.ptr, self.len, b0.0, b1.0, quot.ptr, rem.ptr, ptr::null_mut()) });
     let r = rem.to_host()[0];
     (quot, r)
@@ -200,9 +247,10 @@ impl DevicePoly {
 
   /// `self / rhs`, `self % rhs` for any divisor (quotient_and_remainder, mod.rs:170-225): both with `len` coefficients
   pub fn div_rem(&self, rhs: &DevicePoly) -> (DevicePoly, DevicePoly) {
-    let (quot, rem) = (DevicePoly::alloc(self.len), DevicePoly::alloc(self.len));
+    let _g = OnDevice::new(self.device);
+    let (quot, rem) = (DevicePoly::alloc_on(self.device, self.len), DevicePoly::alloc_on(self.device, self.len));
     let mut status = 0 as c_int;
-    let d_status = DevicePoly::alloc(1);
+    let d_status = DevicePoly::alloc_on(self.device, 1);
     check(unsafe { ffi::ronk_memcpy_h2d(d_status.ptr as *mut c_void, &status as *const c_int as *const c_void, 4) });
     check(unsafe {
       ffi::ronk_poly_divrem_dev(P, self.ptr, self.len, rhs.ptr, rhs.len, quot.ptr, rem.ptr, d_status.ptr as *mut c_int, ptr::null_mut())
@@ -226,8 +274,9 @@ impl DevicePoly {
     rhs: &DevicePoly,
     f: unsafe extern "C" fn(u64, *const u64, *const u64, *mut u64, usize, *mut c_void) -> c_int,
   ) -> DevicePoly {
+    let _g = OnDevice::new(self.device);
     assert!(self.len == rhs.len);
-    let out = DevicePoly::alloc(self.len);
+    let out = DevicePoly::alloc_on(self.device, self.len);
     check(unsafe { f(P, self.ptr, rhs.ptr, out.ptr, self.len, ptr::null_mut()) });
     out
   }
@@ -236,8 +285,9 @@ impl DevicePoly {
 impl Drop for DevicePoly {
   fn drop(&mut self) {
     if !self.ptr.is_null() {
+      let _g = OnDevice::new(self.device);
       unsafe {
-        ffi::ronk_dev_sync();   // nothing enqueued on the null stream may still read or write this buffer
+        ffi::ronk_dev_sync();   // nothing enqueued on ITS device's null stream may still read or write this buffer
         ffi::ronk_dev_free(self.ptr as *mut c_void);
       }
     }
@@ -311,19 +361,52 @@ impl HeapPoly {
 /// `ronk_sharded_plan`: one 2^log2n-point transform over `devices` (a power of two of them) as a four-step NTT whose
 /// exchange the library issues itself.  The reference has no counterpart (a degree this large never exists there).
 pub struct ShardedPlan {
-  raw:      *mut RonkShardedPlan,
-  pub n:    usize,
-  pub ndev: usize,
+  raw:         *mut RonkShardedPlan,
+  pub n:       usize,
+  pub ndev:    usize,
+  pub devices: Vec<i32>,
 }
 unsafe impl Send for ShardedPlan {}
 
+/// how the transpose of the four-step transform travels between the GPUs
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Exchange {
+  /// `hipMemcpyPeerAsync` copies, one copy stream per destination device (`RONK_EXCHANGE_MESH`)
+  Mesh,
+  /// one `ncclGroup` of `ncclSend` / `ncclRecv` pairs per column chunk through RCCL over xGMI (`RONK_EXCHANGE_RCCL`);
+  /// the ranks must sit on distinct GPUs
+  Rccl,
+}
+
 impl ShardedPlan {
+  /// the library's default exchange (the peer-copy mesh)
   pub fn new(log2n: u32, inverse: bool, devices: &[i32], chunks: i32) -> Self {
+    Self::with_exchange(log2n, inverse, devices, chunks, Exchange::Mesh)
+  }
+
+  /// `ronk_sharded_plan_create_ex`: panics (`RONK_ERR_RCCL`) when RCCL is asked for and `librccl.so` cannot be loaded
+  pub fn with_exchange(log2n: u32, inverse: bool, devices: &[i32], chunks: i32, exchange: Exchange) -> Self {
     let mut raw: *mut RonkShardedPlan = ptr::null_mut();
+    let ex = match exchange { Exchange::Mesh => ffi::EXCHANGE_MESH, Exchange::Rccl => ffi::EXCHANGE_RCCL };
     check(unsafe {
-      ffi::ronk_sharded_plan_create(&mut raw, log2n, inverse as c_int, devices.as_ptr(), devices.len() as c_int, chunks)
+      ffi::ronk_sharded_plan_create_ex(&mut raw, log2n, inverse as c_int, devices.as_ptr(), devices.len() as c_int, chunks, ex)
     });
-    Self { raw, n: 1usize << log2n, ndev: devices.len() }
+    Self { raw, n: 1usize << log2n, ndev: devices.len(), devices: devices.to_vec() }
+  }
+
+  /// the exchange this plan runs (`ronk_sharded_plan_exchange`)
+  pub fn exchange(&self) -> Exchange {
+    match unsafe { ffi::ronk_sharded_plan_exchange(self.raw) } {
+      ffi::EXCHANGE_RCCL => Exchange::Rccl,
+      rc if rc < 0 => { check(rc); unreachable!() },
+      _ => Exchange::Mesh,
+    }
+  }
+
+  /// uninitialised per-rank blocks, block g on `devices[g]` (what `transform` takes on both sides)
+  pub fn alloc_blocks(&self) -> Vec<DevicePoly> {
+    let per = self.info().2 as usize;
+    self.devices.iter().map(|&d| DevicePoly::alloc_on(d, per)).collect()
   }
 
   /// (rows R, columns C, elements per rank, column chunks in use)
@@ -342,6 +425,11 @@ impl ShardedPlan {
   /// device-resident blocks, one per rank on that rank's GPU (layouts: include/ronk_ntt.h); asynchronous, see `sync`
   pub fn transform(&self, blocks_in: &[&DevicePoly], blocks_out: &mut [&mut DevicePoly]) {
     assert!(blocks_in.len() == self.ndev && blocks_out.len() == self.ndev);
+    let per = self.info().2 as usize;
+    for (g, &d) in self.devices.iter().enumerate() {
+      assert!(blocks_in[g].device == d && blocks_out[g].device == d, "block {g} must live on GPU {d}");
+      assert!(blocks_in[g].len == per && blocks_out[g].len == per);
+    }
     let ins: Vec<*const u64> = blocks_in.iter().map(|p| p.ptr as *const u64).collect();
     let outs: Vec<*mut u64> = blocks_out.iter().map(|p| p.ptr).collect();
     check(unsafe { ffi::ronk_ntt_sharded_dev(self.raw, ins.as_ptr(), outs.as_ptr()) });

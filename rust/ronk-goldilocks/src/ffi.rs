@@ -11,6 +11,9 @@ use core::ffi::{c_char, c_int, c_void};
 
 pub const P: u64 = 0xFFFF_FFFF_0000_0001;
 pub const G: u64 = 7;
+/// `RONK_EXCHANGE_MESH` / `RONK_EXCHANGE_RCCL` (include/ronk_ntt.h)
+pub const EXCHANGE_MESH: c_int = 0;
+pub const EXCHANGE_RCCL: c_int = 1;
 
 /// `ronk_plan` (opaque)
 #[repr(C)]
@@ -60,8 +63,12 @@ extern "C" {
   pub fn ronk_lagrange_eval(p: u64, c: *const u64, nodes: *const u64, n: usize, x: u64, out: *mut u64) -> c_int;
   /// `Message::decode` (src/codes/reed_solomon.rs:54-106)
   pub fn ronk_rs_decode(p: u64, xs: *const u64, ys: *const u64, k: usize, out: *mut u64) -> c_int;
+  /// `Message::encode::<N>` (src/codes/reed_solomon.rs:42-52): xs[i] = omega_N^i, ys[i] = poly(omega_N^i)
+  pub fn ronk_rs_encode(p: u64, g: u64, msg: *const u64, k: usize, n: usize, xs: *mut u64, ys: *mut u64) -> c_int;
   /// `kzg::commit` (src/kzg/setup.rs:48-60) over BN254 G1: points n x [x: 4 limbs, y: 4 limbs], scalars n x 4 limbs
   pub fn ronk_msm_bn254(points: *const u64, scalars: *const u64, n: usize, out: *mut u64) -> c_int;
+  /// the same with device-resident points and scalars (the result comes back to the host: 8 limbs)
+  pub fn ronk_msm_bn254_dev(d_points: *const u64, d_scalars: *const u64, n: usize, out: *mut u64, stream: *mut c_void) -> c_int;
 
   // ---- plans and device-resident forms (device.rs: `Plan`, `DevicePoly`): coefficients stay in HBM between calls
   pub fn ronk_plan_create(out: *mut *mut RonkPlan, p: u64, g: u64, log2n: u32, batch: u64, device: c_int) -> c_int;
@@ -99,6 +106,17 @@ extern "C" {
     p: u64, d_a: *const u64, d: usize, d_b: *const u64, d2: usize, d_quot: *mut u64, d_rem: *mut u64,
     d_status: *mut c_int, stream: *mut c_void,
   ) -> c_int;
+  /// batched `Message::encode::<N>` (codes/reed_solomon.rs:42-52): `plan.batch` messages of k coefficients -> batch x N y-coordinates
+  pub fn ronk_rs_encode_batch_dev(plan: *mut RonkPlan, d_msgs: *const u64, k: usize, d_ys: *mut u64, stream: *mut c_void) -> c_int;
+  /// low-degree extension of a batch: values on {omega_K^i} -> values on coset_shift * {omega_N^i} (ifft, then encode::<N>)
+  pub fn ronk_lde_batch_dev(
+    plan_k: *mut RonkPlan, plan_n: *mut RonkPlan, d_evals: *const u64, d_coeffs: *mut u64, d_out: *mut u64, coset_shift: u64,
+    stream: *mut c_void,
+  ) -> c_int;
+  /// `Message::decode` (codes/reed_solomon.rs:54-106) on device-resident coordinates; `d_status` may be null
+  pub fn ronk_rs_decode_dev(
+    p: u64, d_xs: *const u64, d_ys: *const u64, k: usize, d_out: *mut u64, d_status: *mut c_int, stream: *mut c_void,
+  ) -> c_int;
   pub fn ronk_vec_add_dev(p: u64, a: *const u64, b: *const u64, out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
   pub fn ronk_vec_sub_dev(p: u64, a: *const u64, b: *const u64, out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
   pub fn ronk_vec_mul_dev(p: u64, a: *const u64, b: *const u64, out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
@@ -107,11 +125,23 @@ extern "C" {
   pub fn ronk_memcpy_h2d(dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
   pub fn ronk_memcpy_d2h(dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
   pub fn ronk_dev_sync() -> c_int;
+  /// the calling thread's current device: what `ronk_dev_alloc` / `ronk_memcpy_*` / `ronk_dev_sync` act on
+  pub fn ronk_set_device(device: c_int) -> c_int;
+  pub fn ronk_get_device(device: *mut c_int) -> c_int;
+  /// releases the library's cached device workspace (buffers above 256 MiB are never cached)
+  pub fn ronk_trim_workspace() -> c_int;
 
   // ---- the sharded four-step transform (BASELINE config 5: 2^26 over the GPUs of one node) as one call
   pub fn ronk_sharded_plan_create(
     out: *mut *mut RonkShardedPlan, log2n: u32, inverse: c_int, devices: *const c_int, ndev: c_int, chunks: c_int,
   ) -> c_int;
+  /// the same with the exchange chosen per plan: [`EXCHANGE_MESH`] (hipMemcpyPeerAsync, one copy stream per peer) or
+  /// [`EXCHANGE_RCCL`] (ncclGroup of Send / Recv pairs through a dlopen'ed librccl: the "RCCL all-to-all over xGMI")
+  pub fn ronk_sharded_plan_create_ex(
+    out: *mut *mut RonkShardedPlan, log2n: u32, inverse: c_int, devices: *const c_int, ndev: c_int, chunks: c_int,
+    exchange: c_int,
+  ) -> c_int;
+  pub fn ronk_sharded_plan_exchange(plan: *const RonkShardedPlan) -> c_int;
   pub fn ronk_sharded_plan_destroy(plan: *mut RonkShardedPlan) -> c_int;
   pub fn ronk_sharded_plan_info(
     plan: *const RonkShardedPlan, rows: *mut u64, cols: *mut u64, per_rank: *mut u64, chunks: *mut c_int,

@@ -1,5 +1,5 @@
 /* test_rust_ffi_replay.c -- replays, in plain C through the real libronk_ntt.so, the FFI call sequence of the Rust shim
- * rust/ronk-goldilocks (src/polynomial.rs): the same entry points, argument order, buffer shapes (`[u64; D]` arrays, a
+ * rust/ronk-goldilocks (src/polynomial.rs, device.rs, codes.rs, bn254.rs): the same entry points, argument order, buffer shapes (`[u64; D]` arrays, a
  * D-element node vector, NULL never passed where the shim passes a pointer) and the same error-code -> panic mapping.
  * Results are checked against the oracle's restatement of the reference (oracle/ronk_oracle.c, the CHECKER).
  * TEST INFRASTRUCTURE; built and run by tests/test_cpp_host_mirror.py (needs a GPU to run). */
@@ -176,6 +176,106 @@ static void replay_sharded(unsigned log2n) {
   free(x); free(got); free(ref);
 }
 
+/* codes.rs: Message::<K>::encode::<N> / decode::<M>, encode_batch, lde, decode_dev -- the same calls, buffers and status word */
+static void replay_codes(void) {
+  /* Message::<3>::new([1, 2, 3]).encode::<8>() and decode::<8> (reed_solomon.rs:42-106) */
+  { uint64_t msg[3] = {1, 2, 3}, xs[8], ys[8], rx[8], ry[8], back[3];
+    EXPECT(ronk_rs_encode(P, G, msg, 3, 8, xs, ys) == 0, "ronk_rs_encode");
+    EXPECT(orc_rs_encode(P, G, msg, 3, 8, rx, ry) == 0 && !memcmp(xs, rx, 64) && !memcmp(ys, ry, 64), "Message::encode values");
+    EXPECT(ronk_rs_decode(P, xs, ys, 3, back) == 0 && !memcmp(back, msg, 24), "Message::decode round trip");
+    EXPECT(ronk_rs_encode(P, G, msg, 3, 2, xs, ys) != 0, "N < K is refused"); }
+  /* encode_batch(plan_n, msgs, k) and lde(plan_k, plan_n, evals, 1): batch 4, k = 2^12, N = 2^13 */
+  { const size_t k = 1u << 12, N = 1u << 13, batch = 4;
+    ronk_plan_opts opts = RONK_PLAN_OPTS_DEFAULT;
+    ronk_plan *pk = NULL, *pn = NULL;
+    EXPECT(ronk_plan_create_opts(&pk, P, G, 12, batch, -1, &opts) == 0 && ronk_plan_create_opts(&pn, P, G, 13, batch, -1, &opts) == 0, "plans");
+    uint64_t *msgs = fresh(batch * k), *dm = dev_from_host(msgs, batch * k), *dys = dev_from_host(NULL, batch * N);
+    EXPECT(ronk_rs_encode_batch_dev(pn, dm, k, dys, NULL) == 0, "ronk_rs_encode_batch_dev");
+    uint64_t *ys = calloc(batch * N, 8), *rx = calloc(N, 8), *ry = calloc(N, 8);
+    dev_to_host(ys, dys, batch * N);
+    for (size_t b = 0; b < batch; b++)
+      EXPECT(orc_rs_encode(P, G, msgs + b * k, k, N, rx, ry) == 0 && !memcmp(ys + b * N, ry, N * 8), "encode_batch values");
+    uint64_t *dsmall = dev_from_host(NULL, batch * k), *dco = dev_from_host(NULL, batch * k), *dext = dev_from_host(NULL, batch * N);
+    EXPECT(ronk_ntt_forward_dev(pk, dm, dsmall, NULL) == 0, "values on the small domain");
+    EXPECT(ronk_lde_batch_dev(pk, pn, dsmall, dco, dext, 1, NULL) == 0, "ronk_lde_batch_dev");
+    uint64_t *co = calloc(batch * k, 8), *ext = calloc(batch * N, 8);
+    dev_to_host(co, dco, batch * k); dev_to_host(ext, dext, batch * N);
+    EXPECT(!memcmp(co, msgs, batch * k * 8), "lde coefficients");
+    EXPECT(!memcmp(ext, ys, batch * N * 8), "lde values == encode values");
+    /* decode_dev on the first k coordinates of codeword 0: xs = omega_N^j (ronk_lagrange_nodes), 8 zeroed status bytes */
+    uint64_t *nodes = calloc(N, 8), *dxs, *dout = dev_from_host(NULL, k), zero = 0, st = 0; void* dst = NULL;
+    EXPECT(ronk_lagrange_nodes(P, G, nodes, N) == 0, "nodes");
+    dxs = dev_from_host(nodes, k);
+    EXPECT(ronk_dev_alloc(&dst, 8) == 0 && ronk_memcpy_h2d(dst, &zero, 8) == 0, "status word");
+    EXPECT(ronk_rs_decode_dev(P, dxs, dys, k, dout, (int*)dst, NULL) == 0, "ronk_rs_decode_dev");
+    dev_to_host(co, dout, k);
+    EXPECT(ronk_memcpy_d2h(&st, dst, 8) == 0 && (uint32_t)st == 0, "decode status");
+    EXPECT(!memcmp(co, msgs, k * 8), "decode_dev recovers message 0");
+    ronk_dev_free(dm); ronk_dev_free(dys); ronk_dev_free(dsmall); ronk_dev_free(dco); ronk_dev_free(dext); ronk_dev_free(dxs);
+    ronk_dev_free(dout); ronk_dev_free(dst);
+    free(msgs); free(ys); free(rx); free(ry); free(co); free(ext); free(nodes);
+    EXPECT(ronk_plan_destroy(pk) == 0 && ronk_plan_destroy(pn) == 0, "destroy"); }
+}
+/* device.rs: current_device / OnDevice (ronk_get_device, ronk_set_device), ShardedPlan::with_exchange + exchange(),
+ * alloc_blocks + transform on device-resident per-rank blocks; bn254::commit_dev; ronk_trim_workspace */
+static void replay_placement(int ndev) {
+  int cur = -1;
+  EXPECT(ronk_get_device(&cur) == 0 && cur >= 0 && cur < ndev, "ronk_get_device");
+  EXPECT(ronk_set_device(cur) == 0, "ronk_set_device(current)");
+  EXPECT(ronk_set_device(ndev) == RONK_ERR_INVALID && ronk_set_device(-1) == RONK_ERR_INVALID, "ordinal out of range");
+  const unsigned log2n = 16; const size_t n = (size_t)1 << log2n;
+  int devices[2] = {0, ndev > 1 ? 1 : 0};
+  ronk_sharded_plan* sp = NULL;
+  EXPECT(ronk_sharded_plan_create_ex(&sp, log2n, 0, devices, 2, 0, RONK_EXCHANGE_MESH) == 0, "ronk_sharded_plan_create_ex(mesh)");
+  EXPECT(ronk_sharded_plan_exchange(sp) == RONK_EXCHANGE_MESH, "ronk_sharded_plan_exchange");
+  uint64_t rows = 0, cols = 0, per = 0; int chunks = 0;
+  EXPECT(ronk_sharded_plan_info(sp, &rows, &cols, &per, &chunks) == 0 && per == n / 2, "info");
+  /* alloc_blocks: block g on devices[g] (OnDevice around every alloc / copy) */
+  uint64_t *x = fresh(n), *ref = calloc(n, 8), *got = calloc(n, 8);
+  const uint64_t* din[2]; uint64_t* dout[2];
+  const size_t Cw = cols / 2;   /* rank g owns columns [g*Cw, (g+1)*Cw): layout [R][C/W] */
+  uint64_t* blk = calloc(per, 8);
+  for (int g = 0; g < 2; g++) {
+    EXPECT(ronk_set_device(devices[g]) == 0, "select the rank's GPU");
+    for (size_t r = 0; r < rows; r++) memcpy(blk + r * Cw, x + r * cols + (size_t)g * Cw, Cw * 8);
+    din[g] = dev_from_host(blk, per); dout[g] = dev_from_host(NULL, per);
+  }
+  EXPECT(ronk_set_device(cur) == 0, "restore");
+  EXPECT(ronk_ntt_sharded_dev(sp, din, dout) == 0 && ronk_sharded_sync(sp) == 0, "ShardedPlan::transform on placed blocks");
+  EXPECT(orc_fft(P, G, x, ref, n) == 0, "oracle");
+  { int ok = 1;   /* rank h ends with X[k1 + R*k2] for k1 in [h*R/W, (h+1)*R/W), laid out [C][R/W] (k2-major): include/ronk_ntt.h */
+    const size_t Rw = rows / 2;
+    for (int h = 0; h < 2; h++) {
+      EXPECT(ronk_set_device(devices[h]) == 0, "select");
+      dev_to_host(blk, dout[h], per);
+      for (size_t k2 = 0; k2 < cols && ok; k2++)
+        for (size_t k1 = 0; k1 < Rw; k1++)
+          if (blk[k2 * Rw + k1] != ref[(h * Rw + k1) + rows * k2]) { ok = 0; break; }
+    }
+    EXPECT(ok, "sharded output blocks == fft"); }
+  for (int g = 0; g < 2; g++) { EXPECT(ronk_set_device(devices[g]) == 0, "select"); ronk_dev_free((void*)din[g]); ronk_dev_free(dout[g]); }
+  EXPECT(ronk_set_device(cur) == 0, "restore");
+  EXPECT(ronk_sharded_plan_destroy(sp) == 0, "destroy");
+  /* Exchange::Rccl: two ranks on ONE device are refused (UNSUPPORTED), a missing librccl is RONK_ERR_RCCL; on two GPUs it must work */
+  { int rc = ronk_sharded_plan_create_ex(&sp, log2n, 0, devices, 2, 0, RONK_EXCHANGE_RCCL);
+    if (devices[0] == devices[1]) EXPECT(rc == RONK_ERR_UNSUPPORTED || rc == RONK_ERR_RCCL, "rccl needs distinct devices");
+    else if (rc == 0) {
+      EXPECT(ronk_sharded_plan_exchange(sp) == RONK_EXCHANGE_RCCL, "exchange == rccl");
+      EXPECT(ronk_ntt_sharded(sp, x, got) == 0 && !memcmp(got, ref, n * 8), "rccl exchange values");
+      ronk_sharded_plan_destroy(sp);
+    } else EXPECT(rc == RONK_ERR_RCCL, "rccl unavailable -> RONK_ERR_RCCL"); }
+  /* bn254::commit_dev: 4 copies of the generator times scalars 1, 2, 3, 4 == commit on host pointers */
+  { uint64_t pts[4 * 8], sc[4 * 4], o1[8], o2[8];
+    memset(pts, 0, sizeof pts); memset(sc, 0, sizeof sc);
+    for (int i = 0; i < 4; i++) { pts[8 * i] = 1; pts[8 * i + 4] = 2; sc[4 * i] = (uint64_t)i + 1; }
+    uint64_t *dp = dev_from_host(pts, 32), *ds = dev_from_host(sc, 16);
+    EXPECT(ronk_msm_bn254(pts, sc, 4, o1) == 0, "ronk_msm_bn254");
+    EXPECT(ronk_msm_bn254_dev(dp, ds, 4, o2, NULL) == 0 && !memcmp(o1, o2, 64), "commit_dev == commit");
+    ronk_dev_free(dp); ronk_dev_free(ds); }
+  EXPECT(ronk_trim_workspace() == 0, "ronk_trim_workspace");
+  free(x); free(ref); free(got); free(blk);
+}
+
 int main(void) {
   int ndev = 0;
   if (ronk_device_count(&ndev) != 0 || ndev < 1) { printf("no device\n"); return 2; }
@@ -190,6 +290,8 @@ int main(void) {
   replay_device(10); replay_device(12); replay_device(16); replay_device(20);
   replay_many(10, 3); replay_many(16, 5); replay_many(20, 4);
   replay_sharded(16); replay_sharded(20);
+  replay_codes();
+  replay_placement(ndev);
   /* rs_decode::<K> */
   { enum { K = 64 };
     uint64_t xs[K], *ys = fresh(K), out[K], ref[K];
