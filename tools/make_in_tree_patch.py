@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""tools/make_in_tree_patch.py -- writes rust/ronk-goldilocks/in_tree/ronkathon.patch: the unified diff that vendors the shim
+INSIDE ronkathon, so that `poly.fft()`, `lagrange.ifft()`, `poly.dft()`, `p.evaluate(x)`, `a * b`, `a / b`, `a % b` on
+`Polynomial<_, Goldilocks, D>` reach the GPU while every other field keeps the reference's own bodies and no call site changes.
+
+How the edit stays small: every public method that gets a GPU twin keeps its body under a new name (`fft` ->
+`fft_reference`, a one-line hunk); the public name becomes a dispatch through a private trait whose blanket impl
+(`default fn`) calls the kept body and whose `Goldilocks` impl calls the GPU (`#![feature(specialization)]` is already
+on: src/lib.rs:23).  `impl Mul` gets `default fn mul` plus a `Goldilocks` specialisation; `impl Div` / `impl Rem` go through
+`quotient_and_remainder`, which dispatches like the methods.  New files: src/polynomial/dispatch.rs (the traits),
+src/algebra/field/goldilocks/{mod,ffi,gpu}.rs (this crate's field.rs / ffi.rs / polynomial.rs with `ronkathon::` -> `crate::`)
+and build.rs (links libronk_ntt.so).
+
+Needs /root/reference (read only) to compute the diff; the result is committed, and tests/test_in_tree_patch.py checks
+`git apply --check` against a scratch copy whenever the reference is present.  Nothing here can be COMPILED in this image
+(no rustc): the patch is checked for applicability, the FFI sequence by tests/cpp/test_rust_ffi_replay.c."""
+import difflib
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+CRATE = os.path.join(ROOT, "rust", "ronk-goldilocks")
+OUT = os.path.join(CRATE, "in_tree", "ronkathon.patch")
+
+
+def read(path):
+    with open(path) as f:
+        return f.read()
+
+
+def replace_once(text, old, new, what):
+    if text.count(old) != 1:
+        sys.exit("make_in_tree_patch: anchor for %s found %d times" % (what, text.count(old)))
+    return text.replace(old, new, 1)
+
+
+# ---------------------------------------------------------------------------------------------- edits of existing files
+def edit_polynomial_mod(t):
+    t = replace_once(t, "pub mod arithmetic;\n", "pub mod arithmetic;\npub(crate) mod dispatch;\n", "mod dispatch")
+    # Monomial: evaluate (mod.rs:133)
+    t = replace_once(
+        t, "  pub fn evaluate(&self, x: F) -> F {\n    let mut result = F::ZERO;",
+        "  pub fn evaluate(&self, x: F) -> F { <Self as dispatch::MonomialDispatch<F, D>>::evaluate_impl(self, x) }\n\n"
+        "  /// The body of [`Polynomial::evaluate`] for every field without an accelerated twin.\n"
+        "  pub(crate) fn evaluate_reference(&self, x: F) -> F {\n    let mut result = F::ZERO;", "Monomial::evaluate")
+    # quotient_and_remainder (mod.rs:170): the public faces are impl Div / impl Rem
+    t = replace_once(
+        t, "  fn quotient_and_remainder<const D2: usize>(\n    self,\n    rhs: Polynomial<Monomial, F, D2>,\n  ) -> (Self, Self) {\n",
+        "  pub(crate) fn quotient_and_remainder<const D2: usize>(\n    self,\n    rhs: Polynomial<Monomial, F, D2>,\n  ) -> (Self, Self) {\n"
+        "    <Self as dispatch::MonomialDispatch<F, D>>::quotient_and_remainder_impl(self, rhs)\n  }\n\n"
+        "  /// The body of [`Polynomial::quotient_and_remainder`] for every field without an accelerated twin.\n"
+        "  pub(crate) fn quotient_and_remainder_reference<const D2: usize>(\n    self,\n    rhs: Polynomial<Monomial, F, D2>,\n  ) -> (Self, Self) {\n",
+        "quotient_and_remainder")
+    # dft (mod.rs:240)
+    t = replace_once(
+        t, "  pub fn dft(&self) -> Polynomial<Lagrange<F>, F, D> {\n",
+        "  pub fn dft(&self) -> Polynomial<Lagrange<F>, F, D> { <Self as dispatch::MonomialDispatch<F, D>>::dft_impl(self) }\n\n"
+        "  /// The body of [`Polynomial::dft`] for every field without an accelerated twin.\n"
+        "  pub(crate) fn dft_reference(&self) -> Polynomial<Lagrange<F>, F, D> {\n", "dft")
+    # fft (mod.rs:273-274): the power-of-two bound stays on the public method
+    t = replace_once(
+        t, "  pub fn fft(&self) -> Polynomial<Lagrange<F>, F, D>\n  where [(); D.is_power_of_two() as usize - 1]: {\n",
+        "  pub fn fft(&self) -> Polynomial<Lagrange<F>, F, D>\n  where [(); D.is_power_of_two() as usize - 1]: {\n"
+        "    <Self as dispatch::MonomialDispatch<F, D>>::fft_impl(self)\n  }\n\n"
+        "  /// The body of [`Polynomial::fft`] for every field without an accelerated twin.\n"
+        "  pub(crate) fn fft_reference(&self) -> Polynomial<Lagrange<F>, F, D> {\n", "fft")
+    # Lagrange: evaluate (mod.rs:382) -- the second `pub fn evaluate` of the file
+    t = replace_once(
+        t, "  pub fn evaluate(&self, x: F) -> F {\n    let n = self.coefficients.len();\n",
+        "  pub fn evaluate(&self, x: F) -> F { <Self as dispatch::LagrangeDispatch<F, D>>::evaluate_impl(self, x) }\n\n"
+        "  /// The body of the barycentric [`Polynomial::evaluate`] for every field without an accelerated twin.\n"
+        "  pub(crate) fn evaluate_reference(&self, x: F) -> F {\n    let n = self.coefficients.len();\n", "Lagrange::evaluate")
+    # ifft (mod.rs:430-431)
+    t = replace_once(
+        t, "  pub fn ifft(&self) -> Polynomial<Monomial, F, D>\n  where [(); D.is_power_of_two() as usize - 1]: {\n",
+        "  pub fn ifft(&self) -> Polynomial<Monomial, F, D>\n  where [(); D.is_power_of_two() as usize - 1]: {\n"
+        "    <Self as dispatch::LagrangeDispatch<F, D>>::ifft_impl(self)\n  }\n\n"
+        "  /// The body of [`Polynomial::ifft`] for every field without an accelerated twin.\n"
+        "  pub(crate) fn ifft_reference(&self) -> Polynomial<Monomial, F, D> {\n", "ifft")
+    return t
+
+
+def edit_polynomial_arithmetic(t):
+    # impl Mul (arithmetic.rs:97-119): the blanket impl becomes specialisable
+    return replace_once(t, "  fn mul(self, rhs: Polynomial<Monomial, F, D2>) -> Self::Output {\n    let mut coefficients = [F::ZERO; D + D2 - 1];",
+                        "  default fn mul(self, rhs: Polynomial<Monomial, F, D2>) -> Self::Output {\n    let mut coefficients = [F::ZERO; D + D2 - 1];",
+                        "impl Mul")
+
+
+def edit_field_mod(t):
+    return replace_once(t, "pub mod extension;\npub mod prime;\n", "pub mod extension;\npub mod goldilocks;\npub mod prime;\n", "pub mod goldilocks")
+
+
+def edit_cargo(t):
+    return replace_once(t, "[dependencies]\n", "[package.metadata.ronk]\n# build.rs links libronk_ntt.so from $RONK_NTT_DIR (the MI355X NTT / polynomial engine)\n\n[dependencies]\n", "Cargo.toml")
+
+
+# ---------------------------------------------------------------------------------------------- new files
+DISPATCH_RS = '''//! Private dispatch between the reference bodies of `Polynomial`'s methods and their accelerated twins.
+//!
+//! Inherent methods cannot be specialised, trait methods can (`#![feature(specialization)]`, src/lib.rs:23): every public
+//! method with a GPU twin forwards to one of the traits below, whose blanket impl (`default fn`) calls the body the method
+//! used to have (`*_reference`, same file as before) and whose `Goldilocks` impl calls libronk_ntt.so through
+//! `crate::algebra::field::goldilocks::gpu`.  No call site changes: `src/kzg/setup.rs:63-78` (`poly.div(..)`),
+//! `src/codes/reed_solomon.rs:42-52` (`polynomial.evaluate(..)`), `src/compiler` keep their source text and, for every
+//! field but `Goldilocks`, their behaviour.
+use super::*;
+use crate::algebra::field::{
+  goldilocks::{
+    gpu::{Accelerated, AcceleratedLagrange},
+    Goldilocks,
+  },
+  FiniteField,
+};
+
+/// [`Monomial`]-basis methods with an accelerated twin
+pub(crate) trait MonomialDispatch<F: FiniteField, const D: usize>: Sized {
+  fn evaluate_impl(&self, x: F) -> F;
+  fn dft_impl(&self) -> Polynomial<Lagrange<F>, F, D>;
+  fn fft_impl(&self) -> Polynomial<Lagrange<F>, F, D>;
+  fn quotient_and_remainder_impl<const D2: usize>(self, rhs: Polynomial<Monomial, F, D2>) -> (Self, Self);
+}
+
+impl<F: FiniteField, const D: usize> MonomialDispatch<F, D> for Polynomial<Monomial, F, D> {
+  default fn evaluate_impl(&self, x: F) -> F { self.evaluate_reference(x) }
+
+  default fn dft_impl(&self) -> Polynomial<Lagrange<F>, F, D> { self.dft_reference() }
+
+  default fn fft_impl(&self) -> Polynomial<Lagrange<F>, F, D> { self.fft_reference() }
+
+  default fn quotient_and_remainder_impl<const D2: usize>(self, rhs: Polynomial<Monomial, F, D2>) -> (Self, Self) {
+    self.quotient_and_remainder_reference(rhs)
+  }
+}
+
+impl<const D: usize> MonomialDispatch<Goldilocks, D> for Polynomial<Monomial, Goldilocks, D> {
+  fn evaluate_impl(&self, x: Goldilocks) -> Goldilocks { Accelerated::evaluate_gpu(self, x) }
+
+  fn dft_impl(&self) -> Polynomial<Lagrange<Goldilocks>, Goldilocks, D> { Accelerated::dft_gpu(self) }
+
+  fn fft_impl(&self) -> Polynomial<Lagrange<Goldilocks>, Goldilocks, D> { Accelerated::fft_gpu(self) }
+
+  fn quotient_and_remainder_impl<const D2: usize>(self, rhs: Polynomial<Monomial, Goldilocks, D2>) -> (Self, Self) {
+    Accelerated::quotient_and_remainder_gpu(&self, &rhs)
+  }
+}
+
+/// [`Lagrange`]-basis methods with an accelerated twin
+pub(crate) trait LagrangeDispatch<F: FiniteField, const D: usize> {
+  fn evaluate_impl(&self, x: F) -> F;
+  fn ifft_impl(&self) -> Polynomial<Monomial, F, D>;
+}
+
+impl<F: FiniteField, const D: usize> LagrangeDispatch<F, D> for Polynomial<Lagrange<F>, F, D> {
+  default fn evaluate_impl(&self, x: F) -> F { self.evaluate_reference(x) }
+
+  default fn ifft_impl(&self) -> Polynomial<Monomial, F, D> { self.ifft_reference() }
+}
+
+impl<const D: usize> LagrangeDispatch<Goldilocks, D> for Polynomial<Lagrange<Goldilocks>, Goldilocks, D> {
+  fn evaluate_impl(&self, x: Goldilocks) -> Goldilocks { AcceleratedLagrange::evaluate_gpu(self, x) }
+
+  fn ifft_impl(&self) -> Polynomial<Monomial, Goldilocks, D> { AcceleratedLagrange::ifft_gpu(self) }
+}
+
+/// `impl Mul` (arithmetic.rs:97-119) for the 64-bit field: NTT - pointwise - inverse NTT on the GPU, `D + D2 - 1` outputs
+impl<const D: usize, const D2: usize> Mul<Polynomial<Monomial, Goldilocks, D2>> for Polynomial<Monomial, Goldilocks, D>
+where [(); D + D2 - 1]:
+{
+  fn mul(self, rhs: Polynomial<Monomial, Goldilocks, D2>) -> Self::Output { Accelerated::mul_gpu(&self, &rhs) }
+}
+
+#[cfg(test)]
+mod tests {
+  //! the accelerated methods against the reference bodies they replace; need a GPU and libronk_ntt.so
+  use super::*;
+
+  fn poly() -> Polynomial<Monomial, Goldilocks, 4> {
+    Polynomial::<Monomial, Goldilocks, 4>::new([1u64, 2, 3, 4].map(Goldilocks))
+  }
+
+  #[test]
+  fn dispatch_reaches_the_same_values() {
+    let p = poly();
+    assert_eq!(p.fft(), p.dft_reference());
+    assert_eq!(p.dft(), p.dft_reference());
+    assert_eq!(p.fft().ifft(), p);
+    assert_eq!(p.evaluate(Goldilocks(2)), p.evaluate_reference(Goldilocks(2)));
+    let b = Polynomial::<Monomial, Goldilocks, 2>::new([Goldilocks(5), Goldilocks(1)]);
+    assert_eq!(p / b, p.quotient_and_remainder_reference(b).0);
+    assert_eq!(p % b, p.quotient_and_remainder_reference(b).1);
+  }
+
+  #[test]
+  fn other_fields_keep_the_reference_bodies() {
+    use crate::algebra::field::prime::PlutoBaseField;
+    let p = Polynomial::<Monomial, PlutoBaseField, 4>::new([1usize, 2, 3, 4].map(PlutoBaseField::new));
+    assert_eq!(p.fft(), p.dft_reference());
+    assert_eq!(p.evaluate(PlutoBaseField::new(2)), PlutoBaseField::new(49));
+  }
+}
+'''
+
+BUILD_RS = '''// Links libronk_ntt.so (the C ABI of the MI355X NTT / polynomial engine behind `algebra::field::goldilocks`).
+// RONK_NTT_DIR = the directory that holds the library; an rpath is added so `cargo test` finds it.
+fn main() {
+  let dir = std::env::var("RONK_NTT_DIR").expect("set RONK_NTT_DIR to the directory containing libronk_ntt.so");
+  println!("cargo:rustc-link-search=native={dir}");
+  println!("cargo:rustc-link-lib=dylib=ronk_ntt");
+  println!("cargo:rustc-link-arg=-Wl,-rpath,{dir}");
+  println!("cargo:rerun-if-env-changed=RONK_NTT_DIR");
+}
+'''
+
+
+def strip_tests(t):
+    i = t.find("#[cfg(test)]\nmod tests {")
+    return t[:i].rstrip() + "\n" if i >= 0 else t
+
+
+def vendor_field(t):
+    t = t.replace("use ronkathon::algebra::{\n  field::{Field, FiniteField},\n  Finite,\n};",
+                  "use crate::algebra::{\n  field::{Field, FiniteField},\n  Finite,\n};")
+    t = replace_once(t, "use crate::ffi::P;\n", "pub mod ffi;\npub mod gpu;\n\nuse self::ffi::P;\n", "field.rs ffi import")
+    assert "ronkathon::" not in strip_tests(t)
+    return strip_tests(t)
+
+
+def vendor_gpu(t):
+    t = replace_once(t, "use ronkathon::{\n  algebra::field::Field,\n  polynomial::{Lagrange, Monomial, Polynomial},\n};",
+                     "use crate::{\n  algebra::field::Field,\n  polynomial::{Lagrange, Monomial, Polynomial},\n};", "gpu.rs imports")
+    t = replace_once(t, "use crate::{\n  ffi::{self, check, G, P},\n  field::Goldilocks,\n};",
+                     "use super::{\n  ffi::{self, check, G, P},\n  Goldilocks,\n};", "gpu.rs crate imports")
+    t = strip_tests(t)
+    assert "ronkathon::" not in t
+    return t
+
+
+def vendor_ffi(t):
+    return t   # no crate-relative paths inside
+
+
+# ---------------------------------------------------------------------------------------------- diff assembly
+def udiff(old, new, path, context=2):
+    a = old.splitlines(keepends=True) if old is not None else []
+    b = new.splitlines(keepends=True)
+    fa = "a/" + path if old is not None else "/dev/null"
+    lines = list(difflib.unified_diff(a, b, fa, "b/" + path, n=context))
+    if not lines:
+        return ""
+    head = "diff --git a/%s b/%s\n" % (path, path)
+    if old is None:
+        head += "new file mode 100644\n"
+    return head + "".join(lines)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("make_in_tree_patch: %s not found (the committed patch stays as it is)" % REF)
+    out = []
+    for rel, edit in (("Cargo.toml", edit_cargo), ("src/algebra/field/mod.rs", edit_field_mod),
+                      ("src/polynomial/arithmetic.rs", edit_polynomial_arithmetic), ("src/polynomial/mod.rs", edit_polynomial_mod)):
+        old = read(os.path.join(REF, rel))
+        out.append(udiff(old, edit(old), rel))
+    assert not os.path.exists(os.path.join(REF, "build.rs")), "the reference grew a build script: merge by hand"
+    out.append(udiff(None, BUILD_RS, "build.rs"))
+    out.append(udiff(None, vendor_ffi(read(os.path.join(CRATE, "src", "ffi.rs"))), "src/algebra/field/goldilocks/ffi.rs"))
+    out.append(udiff(None, vendor_gpu(read(os.path.join(CRATE, "src", "polynomial.rs"))), "src/algebra/field/goldilocks/gpu.rs"))
+    out.append(udiff(None, vendor_field(read(os.path.join(CRATE, "src", "field.rs"))), "src/algebra/field/goldilocks/mod.rs"))
+    out.append(udiff(None, DISPATCH_RS, "src/polynomial/dispatch.rs"))
+    text = "".join(out)
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("wrote %s: %d lines, %d files" % (OUT, text.count("\n"), text.count("diff --git")))
+
+
+if __name__ == "__main__":
+    main()
