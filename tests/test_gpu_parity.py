@@ -99,6 +99,32 @@ def test_polynomial_kats_on_gpu(R, refvec):
     assert e.value.code == -1
 
 
+def test_plonk_lagrange_polys_through_ifft_on_gpu(R, refvec, orc):
+    """row N3: the Lagrange-basis selector / permutation polynomials of src/compiler/program.rs:350-420 (F_17, omega_4 = 13)
+    through `ronk_ifft` / `ronk_fft` on the generic-prime path, against the oracle and against the values the reference holds"""
+    from ronkathon_amd import _lib as L
+    d = refvec["plonk_lagrange_polys"]
+    p, n = d["p"], d["n"]
+    g = int(orc.find_primitive_element(p))
+    nodes = orc.lagrange_nodes(p, g, n)
+    plan = L.Plan(p, g, 2)
+    for name, vals in d["cases"].items():
+        v = np.array(vals, dtype=np.uint64)
+        c = np.zeros(n, dtype=np.uint64)
+        L.check(L.lib.ronk_ifft(p, g, L.ptr(v), L.ptr(c), n))
+        assert np.array_equal(c, orc.ifft(p, g, vals)), name
+        assert np.array_equal(plan.inverse(v), c), name                     # the plan form of the same call
+        back, nd = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        L.check(L.lib.ronk_fft(p, g, L.ptr(c), L.ptr(back), L.ptr(nd), n))
+        assert back.tolist() == vals and nd.tolist() == [int(w) for w in nodes] and int(nd[1]) == 13, name
+        # coefficient form evaluated at the nodes on the GPU = the reference's values
+        for i, w in enumerate(nodes):
+            y = np.zeros(1, dtype=np.uint64)
+            L.check(L.lib.ronk_poly_eval(p, L.ptr(c), n, int(w), L.ptr(y)))
+            assert int(y[0]) == vals[i], name
+    plan.close()
+
+
 def test_callers_on_gpu(R, refvec, orc):
     from ronkathon_amd.callers import Message, kzg_open_quotient
     d = refvec["rs_encode"]
@@ -337,15 +363,23 @@ def test_config3_full_vector_2_22(R, orc):
     assert np.array_equal(prod, want[:2 * d - 1])
 
 
-def test_config4_sixteen_rows_vs_oracle(R, orc):
-    """BASELINE configs[3]: 16 of the 1024 rows (first, last, both sides of every quarter, a few inside) against the oracle"""
+def test_config4_sixty_four_rows_vs_oracle(R, orc):
+    """BASELINE configs[3]: 64 of the 1024 rows against the oracle -- the first and last rows, both sides of every eighth of
+    the batch (the workgroup -> tile renumbering works in eighths: one per XCD), and one row out of every 32 in between; the
+    inverse on the same rows.  (All 1024 rows round-trip in test_config4_batched_1024_x_2_16.)"""
     from ronkathon_amd import _lib as L
     n, batch = 1 << 16, 1024
     x = splitmix_field(0x5EED0044, n * batch)
     plan = L.Plan(GP, GG, 16, batch)
     y = plan.forward(x)
-    for b in (0, 1, 2, 17, 255, 256, 257, 500, 511, 512, 513, 767, 768, 1000, 1022, 1023):
+    rows = sorted(set([0, 1, 2, 1021, 1022, 1023] + [e * 128 + o for e in range(1, 8) for o in (-1, 0, 1)] +
+                      [32 * i + (7 * i) % 32 for i in range(32)] + [17, 500, 777, 1000, 333, 645]))[:64]
+    assert len(rows) == 64
+    for b in rows:
         assert np.array_equal(y[b * n:(b + 1) * n], orc.fft(GP, GG, x[b * n:(b + 1) * n])), b
+    yi = plan.inverse(x)
+    for b in rows[::4]:
+        assert np.array_equal(yi[b * n:(b + 1) * n], orc.ifft(GP, GG, x[b * n:(b + 1) * n])), b
     plan.close()
 
 
@@ -858,6 +892,31 @@ def test_linear_divisor_scan_vs_oracle(R, orc):
                 rhs = orc.add(p, orc.mul(p, orc.poly_eval(p, q.coefficients, x), orc.add(p, b[0], orc.mul(p, b[1], x))),
                               int(r.coefficients[0]))
                 assert lhs == rhs
+            # ... and ELEMENT FOR ELEMENT at the benchmarked size (kzg::open, src/kzg/setup.rs:63-78; the long division of
+            # src/polynomial/mod.rs:170-225 by b0 + b1 x): with z = -b0 / b1 the quotient of the reference satisfies
+            # q[d-1] = 0, q[j-1] = a[j] / b1 + z q[j] for every j, and the remainder is a(z) -- 2^22 - 1 equations that pin
+            # every coefficient (the oracle's own O(d) division would say the same; this form needs no 2^22-step C loop per
+            # case).  Monic (x - z: what kzg::open divides by) and non-monic, out of place and quotient over the dividend.
+            import torch
+            from ronkathon_amd import _lib as L
+            da = torch.from_numpy(a.view(np.int64)).cuda()
+            for b0, b1 in ((orc.neg(p, 0x123456789ABCDEF1 % p), 1), (b[0], b[1]), (0, 5), (GP - 1, GP - 1)):
+                z = orc.mul(p, orc.neg(p, b0), orc.inverse(p, b1))
+                sc = orc.inverse(p, b1)
+                for in_place in (False, True):
+                    src = da.clone()
+                    dq = src if in_place else torch.full((d,), -1, dtype=torch.int64, device="cuda")
+                    dr = torch.zeros(1, dtype=torch.int64, device="cuda")
+                    L.check(L.lib.ronk_poly_div_linear_dev(p, src.data_ptr(), d, b0, b1, dq.data_ptr(), dr.data_ptr(), 0))
+                    torch.cuda.synchronize()
+                    qq = dq.cpu().numpy().view(np.uint64)
+                    assert int(dr.cpu().numpy().view(np.uint64)[0]) == orc.poly_eval(p, a, z), (b0, b1, in_place)
+                    assert int(qq[d - 1]) == 0
+                    rhs = orc.vec_add(p, orc.vec_mul(p, a[1:], np.full(d - 1, sc, dtype=np.uint64)),
+                                      orc.vec_mul(p, qq[1:], np.full(d - 1, z, dtype=np.uint64)))
+                    assert np.array_equal(qq[:-1], rhs), (b0, b1, in_place)
+                    if not in_place:
+                        assert np.array_equal(src.cpu().numpy().view(np.uint64), a)     # the dividend is untouched
         # leading zeros in the dividend, zero dividend, x itself as divisor (generic kernel path)
         for a in ([1, 2, 3, 0, 0], [0, 0, 0, 0], [5, 0, 0, 7]):
             for b in ([3, 1], [0, 1], [4, 0]):

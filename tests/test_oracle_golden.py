@@ -103,6 +103,23 @@ def test_polynomial_kats(refvec):
         assert orc.poly_mul(101, a, b).tolist() == c
 
 
+def test_plonk_lagrange_polys_to_coefficient_form(refvec):
+    """row N3: the compiler's selector / permutation polynomials are Lagrange-basis values on the 4th roots of
+    unity of F_17 (src/compiler/program.rs:350-420); `ifft` (polynomial/mod.rs:430-484) takes them to coefficient form.  The
+    reference holds the VALUES, not the coefficients, so the oracle's ifft is pinned here by the definition it inverts:
+    evaluating the coefficients at omega^i (the O(D^2) `evaluate`, mod.rs:133-139) returns the reference's values."""
+    d = refvec["plonk_lagrange_polys"]
+    p, n = d["p"], d["n"]
+    g = gen(p)
+    nodes = orc.lagrange_nodes(p, g, n)
+    assert int(nodes[1]) == 13                       # omega_4 of F_17 as the compiler uses it (program.rs:59-63)
+    for name, vals in d["cases"].items():
+        c = orc.ifft(p, g, vals)
+        assert [orc.poly_eval(p, c, int(w)) for w in nodes] == vals, name
+        assert orc.fft(p, g, c).tolist() == vals and orc.dft(p, g, c).tolist() == vals, name
+        assert [orc.lagrange_eval(p, vals, nodes, int(w)) for w in (2, 3, 5, 7)] == [orc.poly_eval(p, c, w) for w in (2, 3, 5, 7)], name
+
+
 def test_callers(refvec):
     d = refvec["rs_encode"]
     xs, ys = orc.rs_encode(d["p"], gen(d["p"]), d["msg"], d["n"])
