@@ -127,6 +127,9 @@ _SIG = {
     "ronk_memcpy_h2d": (_int, [_vp, _vp, _sz]),
     "ronk_memcpy_d2h": (_int, [_vp, _vp, _sz]),
     "ronk_dev_sync": (_int, []),
+    "ronk_set_device": (_int, [_int]),
+    "ronk_get_device": (_int, [C.POINTER(_int)]),
+    "ronk_trim_workspace": (_int, []),
 }
 for _name, (_res, _args) in _SIG.items():
     if os.environ.get("RONK_LIB_PATH") and not hasattr(lib, _name):

@@ -140,6 +140,15 @@ struct Dif<1, INV, LAZY> {
   static RONK_HD void run(u64*, bool = true) {}
 };
 
+// FEAT_KEEP: after a three-round pass of 2^logr rows, register r of lane m holds output row m + M * keep_row_digit(logr, r)
+// (M = 2^logr / 16): group g = r / RLAST is the sub-transform kl = m + g*M, register i = r % RLAST of it the output
+// kl + (R / RLAST) * brev(i) = m + M * (g + (16 / RLAST) * brev(i)).  A bijection of 0..15 -- exactly the 16 rows i*M + m that
+// the FIRST round of a column pass over the same index wants in x[i] (tile_load).
+constexpr int keep_row_digit(int logr, int r) {
+  const int loglast = logr - 8, rlast = 1 << loglast;
+  return r / rlast + (16 / rlast) * brev(r % rlast, loglast);
+}
+
 // LDS row of tile row `row`: one dummy row after every 16 (see the header comment)
 RONK_HD u32 swz_row(u32 row) { return row + (row >> 4); }
 
@@ -203,7 +212,10 @@ RONK_HD void st_out(u64* p, u64 v) {
 //   FEAT_IN_VALID   implicit zero padding of the input (in_valid / in_valid1)
 //   FEAT_IN2        second operand, pointwise product fused into the load
 //   FEAT_OUT_VALID  truncated output
-constexpr int FEAT_IN_VALID = 1, FEAT_IN2 = 2, FEAT_OUT_VALID = 4;
+//   FEAT_KEEP       the results stay in the lane's registers -- no output twiddle, no scale, no store (three-round passes
+//                   only): register r = g*RLAST + i ends with output row m + M*keep_row_digit(r) of column c.  Never a launch
+//                   feature (tile_features() does not report it): the fused multiply (ntt_mul.h) instantiates it directly.
+constexpr int FEAT_IN_VALID = 1, FEAT_IN2 = 2, FEAT_OUT_VALID = 4, FEAT_KEEP = 8;
 template <int LOGC_, int KIND_, bool LDSTW_ = false, bool HALF_ = false, int FEAT_ = 0>
 struct TileCfg {
   static constexpr int LOGC = LOGC_;
@@ -631,6 +643,11 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
 #pragma unroll
   for (int g = 0; g < 16 / GSZ; g++) {
     u64* xg = x + g * GSZ;
+    if constexpr ((CFG::FEAT & FEAT_KEEP) != 0) {   // the sub-transform only: results stay in x (keep_row_digit)
+      static_assert(!(CFG::FEAT & FEAT_KEEP) || Q == 3, "FEAT_KEEP: three-round passes");
+      if (!(ABL & 4)) Dif<RLAST, INV, false>::run(xg, false);
+      continue;
+    }
     u32 kg[GSZ];  // natural output row of each register of the group
     // group g of lane m is the sub-transform with natural index kl = m + g*M (see the parking of rounds 1 / 2)
     const u32 kl = (Q == 1) ? 0 : m + (u32)g * M;

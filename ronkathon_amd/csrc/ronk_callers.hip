@@ -92,24 +92,16 @@ struct WsLease {
       on_dev++;
       if (w->busy || w->bytes < need) continue;
       if (!w->used || w->last == st || (w->ev_valid && hipEventQuery(w->done) == hipSuccess)) { slot = w; break; }
-      if (!g_ws_multi || !w->ev_valid) {
-        // First sight of a slot last used by ANOTHER stream: from now on every release leaves an event.  This slot was
-        // released before the switch, so put its event behind everything queued on that stream so far (which includes the
-        // slot's last work) -- no device-wide wait, and nothing is synchronised while the pool lock is held.
-        g_ws_multi = true;
-        if (!w->ev_valid) {
-          w->ev_valid = hipEventRecord(w->done, w->last) == hipSuccess;
-          if (!w->ev_valid) (void)hipGetLastError();   // the stream is gone: its work has completed or was abandoned with it
-        }
-        if (w->ev_valid && hipEventQuery(w->done) == hipSuccess) { slot = w; break; }
-        (void)hipGetLastError();
-      }
+      g_ws_multi = true;                        // a slot last used by ANOTHER stream: from now on every release leaves an event
       if (!waitable) waitable = w;
     }
     if (!slot && waitable && on_dev >= 32) {  // bound the pool: wait for an old slot instead of growing
+      // A slot released before the pool went multi-stream has no event, and its stream handle cannot be trusted any more (a
+      // destroyed hipStream_t crashes hipEventRecord / hipStreamSynchronize -- tests/test_gpu_parity.py destroys one on
+      // purpose), so the one thing left to wait on is the device: the slot's device IS the current one (filter above).
+      // At most once per process and device: from the switch on every release records its event.
       if (waitable->ev_valid) (void)hipEventSynchronize(waitable->done);
-      else (void)hipDeviceSynchronize();   // its stream was destroyed under queued work (no event could be placed): rare, and
-                                           // the current device IS the slot's device (filter above)
+      else (void)hipDeviceSynchronize();
       slot = waitable;
     }
     if (!slot) {
@@ -142,7 +134,7 @@ struct WsLease {
   void lb_commit() { slot->lb_calls++; }
 };
 // Releases every idle pool slot and every finished one-off buffer (include/ronk_ntt.h).  Waits for the work behind them
-// (events; a slot released in single-stream mode has none: its stream is synchronised), never for unrelated streams.
+// (events; a slot released in single-stream mode has none: its device is synchronised).
 extern "C" int ronk_trim_workspace(void) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   ws_reap(true);
@@ -152,9 +144,9 @@ extern "C" int ronk_trim_workspace(void) {
     WsSlot* w = g_ws[i];
     if (w->busy) { i++; continue; }
     (void)hipSetDevice(w->device);
-    if (w->used) {
-      hipError_t e = w->ev_valid ? hipEventSynchronize(w->done) : hipStreamSynchronize(w->last);
-      if (e != hipSuccess) (void)hipGetLastError();   // a destroyed stream: nothing of it can still run
+    if (w->used) {   // (no event = released in single-stream mode; its stream handle may be gone: wait for the device)
+      hipError_t e = w->ev_valid ? hipEventSynchronize(w->done) : hipDeviceSynchronize();
+      if (e != hipSuccess) (void)hipGetLastError();
     }
     ws_free_slot(w);
     g_ws[i] = g_ws.back();

@@ -4,6 +4,7 @@
 #include <map>
 
 #include "runtime.h"
+#include "ntt_mul.h"
 #include "ntt_aux_kernels.h"
 
 // ------------------------------------------------------------------------------------- plans
@@ -183,39 +184,29 @@ static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* ou
   return RONK_OK;
 }
 
-// order `s` behind the previous user of the plan's scratch (see ronk_plan::scratch_ev); caller holds stream_mu
+// order `s` behind the previous user of the plan's scratch (see ronk_plan::scratch_ev); caller holds stream_mu.
+// Every call leaves an event behind its work (scratch_release): a stream handle kept from an earlier call cannot be used for
+// that later -- the caller may have destroyed it (tests/test_gpu_parity.py does so on purpose; hipEventRecord on a dead
+// handle crashes) -- and a device-wide wait here would stall unrelated streams while the plan lock is held and is illegal
+// beside a stream capture in global mode.  ~1 us of host time per call on a multi-pass plan, under 2 % of the enqueue.
 static void scratch_acquire(ronk_plan* pl, hipStream_t s) {
   if (!pl->scratch_used || pl->scratch_stream == s) return;
-  // First time the plan is seen on a second stream: nothing was recorded behind the previous call (single-stream users
-  // never pay for an event).  Place the event NOW behind everything queued on the previous stream so far -- that includes
-  // the previous call -- and let `s` wait for it on the device: no host stall, nothing device-wide (legal beside a
-  // capture in global mode).  From now on every call leaves its own event behind (scratch_release).
-  hipError_t e = hipSuccess;
-  if (!pl->scratch_multi || !pl->scratch_ev_valid) {
-    if (!pl->scratch_ev) e = hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(pl->scratch_ev, pl->scratch_stream);
-    pl->scratch_ev_valid = e == hipSuccess;
-  }
-  if (pl->scratch_ev_valid) e = hipStreamWaitEvent(s, pl->scratch_ev, 0);
-  if (!pl->scratch_ev_valid || e != hipSuccess) {
-    // the previous stream no longer exists (or the wait could not be queued): the last resort, on the PLAN's device
-    (void)hipGetLastError();
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    if (cur != pl->device) (void)hipSetDevice(pl->device);
-    (void)hipDeviceSynchronize();
-    if (cur >= 0 && cur != pl->device) (void)hipSetDevice(cur);
-  }
-  pl->scratch_multi = true;
+  if (pl->scratch_ev_valid && hipStreamWaitEvent(s, pl->scratch_ev, 0) == hipSuccess) return;
+  // no event (the record failed at release time): the last resort, on the PLAN's device
+  (void)hipGetLastError();
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (cur != pl->device) (void)hipSetDevice(pl->device);
+  (void)hipDeviceSynchronize();
+  if (cur >= 0 && cur != pl->device) (void)hipSetDevice(cur);
 }
 static void scratch_release(ronk_plan* pl, hipStream_t s) {
   pl->scratch_stream = s; pl->scratch_used = true;
-  if (!pl->scratch_multi) return;
   hipError_t e = hipSuccess;
   if (!pl->scratch_ev) e = hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventRecord(pl->scratch_ev, s);
   pl->scratch_ev_valid = e == hipSuccess;
-  if (e != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }   // nothing left in flight to guard against
+  if (e != hipSuccess) (void)hipGetLastError();
 }
 
 int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s, u64 in_valid,
@@ -538,6 +529,7 @@ struct CacheEntry {
   ronk_plan* pl = nullptr;
   u64 *fa = nullptr, *fb = nullptr;  // poly_mul operands, n elements each (lazy)
   ronk_plan* pl2 = nullptr;          // the same size with batch 2: both operands of a multiply in ONE pair of launches (lazy)
+  ronk_plan* plf = nullptr;          // the fused multiply's inverse plan: the pair plan's tile width (4 columns) (lazy)
   u64* fab = nullptr;                // its output: [2][n]
   hipEvent_t done = nullptr;
   uint64_t stamp = 0;
@@ -553,6 +545,7 @@ static void cache_entry_free(CacheEntry* e) {
   if (e->fb) (void)hipFree(e->fb);
   if (e->pl2) ronk_plan_destroy(e->pl2);
   if (e->pli) ronk_plan_destroy(e->pli);
+  if (e->plf) ronk_plan_destroy(e->plf);
   if (e->fab) (void)hipFree(e->fab);
   if (e->done) (void)hipEventDestroy(e->done);
   delete e;
@@ -756,10 +749,39 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     if (!e->pl2) RCHK(k >= 20 ? ronk_plan_create_tuned(&e->pl2, p, g, (u32)k, 2, pl->device, 2, ftw)
                               : ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
     if (itw >= 0 && !e->pli) RCHK(ronk_plan_create_tuned(&e->pli, p, g, (u32)k, 1, pl->device, -1, itw));
+    const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
+    // Fused middle (ntt_mul.h): forward row pass of both operands + pointwise product + inverse column pass in ONE launch --
+    // three launches per product, NTT(a) / NTT(b) never written.  Needs the same tile width on both sides (a dedicated
+    // inverse plan with the pair plan's 4-column tiles) and square two-pass plans (2^20, 2^22).  RONK_MUL_FUSED=0: the
+    // four-launch form (A/B); RONK_MUL_INV_TWF picks the inverse's twiddle form as before (default there: two-level tables).
+    static const bool fused_on = [] { const char* e_ = getenv("RONK_MUL_FUSED"); return !e_ || atoi(e_) != 0; }();
+    if (fused_on && (k == 20 || k == 22)) {
+      if (!e->plf) RCHK(ronk_plan_create_tuned(&e->plf, p, g, (u32)k, 1, pl->device, 2, inv_twf != -2 ? inv_twf : 18));
+      const CompiledPlan& F = e->pl2->fwd;
+      const CompiledPlan& I = e->plf->inv;
+      if (F.pd.passes.size() == 2 && I.pd.passes.size() == 2 && !F.pd.passes[1].small && !I.pd.passes[0].small) {
+        TileArgs fa = F.bound(1, nullptr, nullptr, nullptr, e->pl2->d_tmp);
+        TileArgs ia = I.bound(0, nullptr, nullptr, nullptr, e->plf->d_tmp);
+        const PassDesc& fp = F.pd.passes[1];
+        const int kindi = ia.tw_full ? 3 : 1;
+        if (mul_mid_matches(fa, ia, fp.logr, (int)fa.logc, kindi)) {
+          HIPCHK(hipStreamWaitEvent(s, e->done, 0));
+          RCHK(F.launch(0, d_a, nullptr, nullptr, e->pl2->d_tmp, s, (u64)d, ~(u64)0, stride, 0, 0, 0, (u64)d2));
+          bool found = false;
+          hipError_t he = launch_mul_mid(fp.logr, kindi, fa, ia, fa.tiles, fp.block, fp.lds_bytes, s, &found);
+          if (he != hipSuccess) return hip_fail(he, "launch_mul_mid");
+          if (found) {
+            RCHK(I.launch(1, nullptr, nullptr, d_out, e->plf->d_tmp, s, ~(u64)0, (u64)m));
+            HIPCHK(hipEventRecord(e->done, s));
+            return RONK_OK;
+          }
+          // (no instantiation for this shape: the column pass just run is repeated by the four-launch form below)
+        }
+      }
+    }
     ronk_plan* const plinv = e->pli ? e->pli : pl;
     if (!e->fab) HIPCHK(hipMalloc((void**)&e->fab, 2 * N * 8));
     HIPCHK(hipStreamWaitEvent(s, e->done, 0));
-    const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
     RCHK(transform_dev(e->pl2, false, d_a, nullptr, e->fab, s, (u64)d, ~(u64)0, stride, (u64)d2));
     RCHK(transform_dev(plinv, true, e->fab, e->fab + N, d_out, s, ~(u64)0, (u64)m));
     HIPCHK(hipEventRecord(e->done, s));

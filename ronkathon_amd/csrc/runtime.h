@@ -128,6 +128,21 @@ struct CompiledPlan {
   // x0_add: added to the X offset of passes whose inter-pass twiddle depends on the column (column chunks of the
   // sharded four-step: chunk j starts j*Cwc columns further right, ronk_dist.hip)
   // sb0 / sbn: launch the pass for polynomials [sb0, sb0 + sbn) of the batch only (sbn = 0: all of them)
+  // the launch arguments of pass idx with buffers and tables bound, nothing else changed (the fused multiply hands two
+  // passes of two plans to one kernel: ronk_plan.hip conv_dev)
+  TileArgs bound(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp) const {
+    const PassDesc& ps = pd.passes[idx];
+    TileArgs a = ps.args;
+    const u64* bufs_in[3] = {in, out, tmp};
+    u64* bufs_out[3] = {nullptr, out, tmp};
+    a.in = bufs_in[ps.in_buf];
+    a.in2 = (ps.in_buf == BUF_IN) ? in2 : nullptr;
+    a.out = bufs_out[ps.out_buf];
+    a.wr = d_wr[ps.wr_id];
+    if (ps.tw_id >= 0) { a.tw_lo = d_tw[ps.tw_id].first; a.tw_hi = d_tw[ps.tw_id].second; }
+    if (ps.twf_id >= 0) a.tw_full = d_twf[ps.twf_id];
+    return a;
+  }
   int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
              u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u32 sb0 = 0, u32 sbn = 0,
              u64 in_valid1 = ~(u64)0) const {

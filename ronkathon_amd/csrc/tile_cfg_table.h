@@ -25,4 +25,4 @@
 #define RONK_CFG_TABLE_FEAT(X)                                                                \
   X(10, 2, 1, 1) X(11, 2, 1, 1) X(11, 2, 3, 1) X(8, 4, 3, 1)                                  \
   X(10, 2, 1, 2) X(11, 2, 1, 2) X(11, 3, 1, 2) X(11, 2, 3, 2) X(11, 3, 3, 2)                  \
-  X(10, 2, 2, 4) X(10, 3, 2, 4) X(11, 3, 2, 4)
+  X(10, 2, 2, 4) X(10, 3, 2, 4) X(11, 3, 2, 4) X(11, 2, 2, 4)

@@ -10,4 +10,8 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
 // the latency form of a pass (ntt_small.h: 4 coefficients per work-item), 2^4 .. 2^10 rows
 hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
                         hipStream_t stream);
+// the fused middle of a polynomial multiply (ntt_mul.h, tile_kernels_mul.hip): fa = the forward plan's row pass over the batch
+// of two operands, ia = the inverse plan's column pass; grid = tiles of ONE operand; *found = an instantiation exists
+hipError_t launch_mul_mid(int logr, int kindi, const TileArgs& fa, const TileArgs& ia, u32 grid, u32 block, size_t lds_bytes,
+                          hipStream_t stream, bool* found);
 }

@@ -118,10 +118,11 @@ def test_plonk_lagrange_polys_through_ifft_on_gpu(R, refvec, orc):
         L.check(L.lib.ronk_fft(p, g, L.ptr(c), L.ptr(back), L.ptr(nd), n))
         assert back.tolist() == vals and nd.tolist() == [int(w) for w in nodes] and int(nd[1]) == 13, name
         # coefficient form evaluated at the nodes on the GPU = the reference's values
+        import ctypes as C
         for i, w in enumerate(nodes):
-            y = np.zeros(1, dtype=np.uint64)
-            L.check(L.lib.ronk_poly_eval(p, L.ptr(c), n, int(w), L.ptr(y)))
-            assert int(y[0]) == vals[i], name
+            y = C.c_uint64(0)
+            L.check(L.lib.ronk_poly_eval(p, L.ptr(c), n, int(w), C.byref(y)))
+            assert int(y.value) == vals[i], name
     plan.close()
 
 
