@@ -39,6 +39,7 @@ sanitize:
 	./build/san/emu_tile 15 2 0 4 18 25 0 0 1 | tail -1
 	./build/san/emu_tile 20 1 0 3 | tail -1
 	./build/san/emu_tile dist 16 4 0 0 2 | tail -1
+	./build/san/emu_tile mul 20 300001 7 2 18 | tail -1
 	./build/san/emu_scan 18446744069414584321 70001 123456789 3 1 | tail -1
 	./build/san/emu_scan 101 5000 7 3 0 | tail -1
 .PHONY: sanitize

@@ -19,6 +19,15 @@
 
 namespace ronk {
 
+// hides a lane index from the optimiser (device build; a no-op for the host emulator)
+RONK_HD void mul_mid_opaque(u32& t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(t));
+#else
+  (void)t;
+#endif
+}
+
 // fa: the forward plan's ROW pass (KIND 2 shape, batch of two: polynomial b1 = 0 is a, 1 is b; in = its scratch)
 // ia: the inverse plan's COLUMN pass (KIND 1 or 3 shape; out = the inverse plan's scratch; `in` is not read)
 // bid in [0, tiles): the same tile number on both sides (same tile width: LOGC)
@@ -28,25 +37,33 @@ RONK_HD void mul_mid_body(const TileArgs& fa, const TileArgs& ia, u64* lds, u32 
   typedef TileCfg<LOGC, 2, false, false, FEAT_KEEP> CF;
   typedef TileCfg<LOGC, KINDI> CI;
   u64 x[16], ya[16], y[16];
+  // The three transforms address the same tile with the same lane: left alone, the compiler keeps every per-lane offset of
+  // the first one (16 load offsets, the LDS cells of each round, the table offsets) live for the other two -- 128 VGPRs and
+  // 350 bytes of scratch per lane.  An opaque copy of the lane index per phase makes it recompute them (a few dozen full-rate
+  // adds) instead.
+  u32 t1 = tid, t2 = tid, t3 = tid;
+  mul_mid_opaque(t1);
   {
-    const TileCtx cx = tile_ctx<LOGR, CF>(fa, tid, bid);
-    tile_load<LOGR, false, 0, CF>(cx, lds, tid, x, barrier);
-    tile_compute<LOGR, false, 0, CF>(cx, lds, tid, x, barrier);
+    const TileCtx cx = tile_ctx<LOGR, CF>(fa, t1, bid);
+    tile_load<LOGR, false, 0, CF>(cx, lds, t1, x, barrier);
+    tile_compute<LOGR, false, 0, CF>(cx, lds, t1, x, barrier);
   }
 #pragma unroll
   for (int r = 0; r < 16; r++) ya[keep_row_digit(LOGR, r)] = x[r];
   barrier();   // every lane has read its last-round rows of the a tile before the image is written again
+  mul_mid_opaque(t2);
   {
-    const TileCtx cx = tile_ctx<LOGR, CF>(fa, tid, bid + fa.tiles);   // b1 = 1
-    tile_load<LOGR, false, 0, CF>(cx, lds, tid, x, barrier);
-    tile_compute<LOGR, false, 0, CF>(cx, lds, tid, x, barrier);
+    const TileCtx cx = tile_ctx<LOGR, CF>(fa, t2, bid + fa.tiles);   // b1 = 1
+    tile_load<LOGR, false, 0, CF>(cx, lds, t2, x, barrier);
+    tile_compute<LOGR, false, 0, CF>(cx, lds, t2, x, barrier);
   }
 #pragma unroll
   for (int r = 0; r < 16; r++) y[keep_row_digit(LOGR, r)] = gl64::mul(ya[keep_row_digit(LOGR, r)], x[r]);
   barrier();
+  mul_mid_opaque(t3);
   {
-    const TileCtx cx = tile_ctx<LOGR, CI>(ia, tid, bid);
-    tile_compute<LOGR, true, 0, CI>(cx, lds, tid, y, barrier);
+    const TileCtx cx = tile_ctx<LOGR, CI>(ia, t3, bid);
+    tile_compute<LOGR, true, 0, CI>(cx, lds, t3, y, barrier);
   }
 }
 

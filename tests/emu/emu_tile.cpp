@@ -18,6 +18,7 @@
 #include "../../oracle/ronk_oracle.h"
 #include "../../ronkathon_amd/csrc/plan.h"
 #include "../../ronkathon_amd/csrc/ntt_small.h"
+#include "../../ronkathon_amd/csrc/ntt_mul.h"
 #include "../../ronkathon_amd/csrc/tile_cfg_table.h"
 
 using namespace ronk;
@@ -208,7 +209,111 @@ static int dist_main(int log2n, int world, bool inv, int chunks) {
   return 0;
 }
 
+// mul mode: the fused multiply (ntt_mul.h) the way ronk_plan.hip conv_dev runs it -- column pass of both operands (zero
+// padding implicit), mul_mid_body per tile (forward row pass of a and b, product, inverse column pass), inverse row pass with
+// truncated output -- against the oracle's schoolbook Mul on the host
+struct MidArgs { const TileArgs *fa, *ia; u64* lds; u32 bid; int logr, logc, kindi; };
+static MidArgs g_mid;
+static void mid_fiber(int tid) {
+  const MidArgs& m = g_mid;
+#define EMU_MID_CASE(LR, LC, KD) \
+  if (m.logr == LR && m.logc == LC && m.kindi == KD) mul_mid_body<LR, LC, KD>(*m.fa, *m.ia, m.lds, (u32)tid, m.bid, fiber_barrier);
+  EMU_MID_CASE(10, 2, 1) EMU_MID_CASE(10, 2, 3) EMU_MID_CASE(11, 2, 1) EMU_MID_CASE(11, 2, 3) EMU_MID_CASE(10, 3, 1) EMU_MID_CASE(11, 3, 1)
+#undef EMU_MID_CASE
+  g_done[tid] = 1;
+  swapcontext(&g_ctx[tid], &g_sched);
+}
+static void run_mid_block(u32 T) {
+  const size_t STK = 64 * 1024;
+  if (g_ctx.size() < T) { g_ctx.resize(T); g_stacks.resize((size_t)T * STK); g_done.resize(T); }
+  for (u32 t = 0; t < T; t++) {
+    getcontext(&g_ctx[t]);
+    g_ctx[t].uc_stack.ss_sp = &g_stacks[(size_t)t * STK];
+    g_ctx[t].uc_stack.ss_size = STK;
+    g_ctx[t].uc_link = &g_sched;
+    makecontext(&g_ctx[t], (void (*)())mid_fiber, 1, (int)t);
+    g_done[t] = 0;
+  }
+  for (;;) {
+    bool any = false;
+    for (u32 t = 0; t < T; t++) {
+      if (g_done[t]) continue;
+      any = true;
+      g_cur = (int)t;
+      swapcontext(&g_sched, &g_ctx[t]);
+    }
+    if (!any) break;
+  }
+}
+static TileArgs bind_pass(const PlanDesc& pd, size_t idx, const u64* in, u64* out, u64* tmp) {
+  const PassDesc& p = pd.passes[idx];
+  TileArgs a = p.args;
+  const u64* bufs_in[3] = {in, out, tmp};
+  u64* bufs_out[3] = {nullptr, out, tmp};
+  a.in = bufs_in[p.in_buf];
+  a.out = bufs_out[p.out_buf];
+  a.wr = pd.wr[p.wr_id].data();
+  if (p.tw_id >= 0) { a.tw_lo = pd.tw[p.tw_id].lo.data(); a.tw_hi = pd.tw[p.tw_id].hi.data(); }
+  if (p.twf_id >= 0) a.tw_full = pd.twf[p.twf_id].data();
+  return a;
+}
+static int mul_main(int log2n, u64 d, u64 d2, int logc, int inv_twf) {
+  const u64 n = (u64)1 << log2n, m = d + d2 - 1;
+  if (m > n) { printf("operands too long\n"); return 2; }
+  PlanDesc F = build_plan(log2n, 2, false, logc, 18), I = build_plan(log2n, 1, true, logc, inv_twf);
+  std::vector<u64> ab(2 * n, 0x1111), ftmp(2 * n, 0xDEADBEEFull), itmp(n, 0xDEADBEEFull), out(n, 0xDEADBEEFull), ref(m);
+  u64 s = 0x5EED0C00ull + log2n;
+  for (u64 i = 0; i < d; i++) { do ab[i] = splitmix(s); while (ab[i] >= gl64::P); }
+  for (u64 i = 0; i < d2; i++) { do ab[n + i] = splitmix(s); while (ab[n + i] >= gl64::P); }
+  ab[0] = gl64::P - 1; ab[n + d2 - 1] = gl64::P - 1;
+  std::vector<u64> lds;
+  {   // F1: column pass of the batch of two, padding limits d / d2
+    TileArgs a = bind_pass(F, 0, ab.data(), nullptr, ftmp.data());
+    a.in_valid = d; a.in_valid1 = d2;
+    const PassDesc& p = F.passes[0];
+    lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);
+    for (u32 bid = 0; bid < p.grid; bid++) {
+      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = false; g_fa.small = p.small;
+      run_block(p.block);
+    }
+  }
+  TileArgs fa = bind_pass(F, 1, nullptr, nullptr, ftmp.data()), ia = bind_pass(I, 0, nullptr, nullptr, itmp.data());
+  const int kindi = ia.tw_full ? 3 : 1, logr = F.passes[1].logr;
+  if (!mul_mid_matches(fa, ia, logr, (int)fa.logc, kindi)) { printf("passes do not fuse\n"); return 2; }
+  lds.assign(F.passes[1].lds_bytes / 8 + 1, 0);
+  for (u32 bid = 0; bid < fa.tiles; bid++) {
+    g_mid = MidArgs{&fa, &ia, lds.data(), bid, logr, (int)fa.logc, kindi};
+    run_mid_block(F.passes[1].block);
+  }
+  {   // I2: the inverse's row pass, output truncated to d + d2 - 1 coefficients
+    TileArgs a = bind_pass(I, 1, nullptr, out.data(), itmp.data());
+    a.out_valid = m;
+    const PassDesc& p = I.passes[1];
+    lds.assign(p.lds_bytes / 8 + 1 + ((size_t)1 << p.logr), 0);
+    for (u32 bid = 0; bid < p.grid; bid++) {
+      g_fa.a = &a; g_fa.lds = lds.data(); g_fa.bid = bid; g_fa.logr = p.logr; g_fa.inv = true; g_fa.small = p.small;
+      run_block(p.block);
+    }
+  }
+  // the oracle: NTT product of the zero-padded operands (the schoolbook Mul is O(d * d2); at these sizes the two agree by
+  // tests/test_oracle_golden.py) -- three oracle transforms
+  std::vector<u64> pa(n, 0), pb(n, 0), fa_(n), fb_(n), pr(n);
+  memcpy(pa.data(), ab.data(), d * 8); memcpy(pb.data(), ab.data() + n, d2 * 8);
+  if (orc_fft(gl64::P, 7, pa.data(), fa_.data(), n) || orc_fft(gl64::P, 7, pb.data(), fb_.data(), n)) return 1;
+  for (u64 i = 0; i < n; i++) fa_[i] = orc_mul(gl64::P, fa_[i], fb_[i]);
+  if (orc_ifft(gl64::P, 7, fa_.data(), pr.data(), n)) return 1;
+  for (u64 i = 0; i < n; i++) {
+    if (i >= m) { if (out[i] != 0xDEADBEEFull) { printf("store beyond the product at %llu\n", (unsigned long long)i); return 1; } continue; }
+    if (out[i] != pr[i]) { printf("MUL MISMATCH at %llu: got %llu want %llu\n", (unsigned long long)i, (unsigned long long)out[i], (unsigned long long)pr[i]); return 1; }
+  }
+  printf("OK mul log2n=%d d=%llu d2=%llu logc=%d inverse twiddles=%s\n", log2n, (unsigned long long)d, (unsigned long long)d2, logc,
+         kindi == 3 ? "matrix" : "two-level");
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 6 && !strcmp(argv[1], "mul"))   // emu_tile mul <log2n> <d> <d2> <logc> [inverse twf_max_log]
+    return mul_main(atoi(argv[2]), strtoull(argv[3], 0, 10), strtoull(argv[4], 0, 10), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 18);
   if (argc >= 6 && !strcmp(argv[1], "dist")) g_twf = atoi(argv[5]);
   if (argc >= 5 && !strcmp(argv[1], "dist"))   // emu_tile dist <log2n> <world> <inverse> [twf_max_log] [chunks]
     return dist_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0, argc >= 7 ? atoi(argv[6]) : 1);

@@ -15,7 +15,7 @@ EXE = os.path.join(ROOT, "build", "emu_tile")
 def emu():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "emu", "emu_tile.cpp")]
-    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "ntt_small.h", "plan.h", "gl64.h", "tile_cfg_table.h")]
+    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "ntt_small.h", "ntt_mul.h", "plan.h", "gl64.h", "tile_cfg_table.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
         subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
@@ -47,6 +47,15 @@ def test_two_pass(emu, k, batch, inv, logc):
 def test_tuned_tile_widths(emu, k, logc):
     """ronk_plan_create_tuned(tile_log2_columns = c): bench.py times c = 2 plans on two streams; 2^23 is a three-pass plan"""
     run(emu, k, 1, (k + logc) & 1, logc, 0, 23)
+
+
+@pytest.mark.parametrize("k,d,d2,logc,twf", [(20, 1 << 19, 1 << 19, 2, 18), (20, 300001, 7, 2, 20), (20, 1, 1 << 20, 2, 18),
+                                             (22, 1 << 21, 1 << 21, 2, 18), (22, (1 << 21) + 5, (1 << 21) - 4, 2, 22)])
+def test_fused_multiply_middle(emu, k, d, d2, logc, twf):
+    """ntt_mul.h: the multiply's forward row pass of both operands + product + inverse column pass as ONE tile body (what
+    ronk_plan.hip conv_dev launches at 2^20 / 2^22), every product coefficient against the oracle; ragged operand lengths,
+    both inverse twiddle forms (two-level tables / full matrix)"""
+    run(emu, "mul", k, d, d2, logc, twf)
 
 
 def test_specialised_kernels_are_selected_and_generic_bodies_still_match(emu):

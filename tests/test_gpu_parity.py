@@ -364,6 +364,23 @@ def test_config3_full_vector_2_22(R, orc):
     assert np.array_equal(prod, want[:2 * d - 1])
 
 
+@pytest.mark.parametrize("d,d2", [(1 << 19, 1 << 19), (300001, 7), (1, (1 << 20) - 3), ((1 << 21) + 5, (1 << 21) - 4), (1 << 20, 3 << 19)])
+def test_fused_multiply_ragged_lengths(R, orc, d, d2):
+    """the fused middle of the multiply (csrc/ntt_mul.h; NTT sizes 2^20 and 2^22): every product coefficient against the
+    oracle's ifft(fft(a) * fft(b)) for operand lengths that are not powers of two, the extreme 1 x long case, and twice in
+    a row through the cached plans (src/polynomial/arithmetic.rs:97-119: D + D2 - 1 coefficients)"""
+    F = R.GoldilocksField
+    a = splitmix_field(0x5EED0F00 + d % 97, d); b = splitmix_field(0x5EED0F80 + d2 % 89, d2)
+    m = d + d2 - 1
+    n = 1 << (m - 1).bit_length()
+    want = orc.ifft(GP, GG, orc.vec_mul(GP, orc.fft(GP, GG, np.concatenate([a, np.zeros(n - d, dtype=np.uint64)])),
+                                        orc.fft(GP, GG, np.concatenate([b, np.zeros(n - d2, dtype=np.uint64)]))))
+    assert not want[m:].any()
+    for _ in range(2):
+        prod = (R.Polynomial.new(F, a) * R.Polynomial.new(F, b)).coefficients
+        assert prod.size == m and np.array_equal(prod, want[:m])
+
+
 def test_config4_sixty_four_rows_vs_oracle(R, orc):
     """BASELINE configs[3]: 64 of the 1024 rows against the oracle -- the first and last rows, both sides of every eighth of
     the batch (the workgroup -> tile renumbering works in eighths: one per XCD), and one row out of every 32 in between; the
