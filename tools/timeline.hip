@@ -211,6 +211,40 @@ int main(int argc, char** argv) {
         }
       }
     }
+  } else if (!strcmp(what, "nlanes")) {
+    // timeline nlanes <streams> <logc> <half> [iters]: throughput only (no stamps): N streams, transforms back to back on each
+    const int NL = argc > 2 ? atoi(argv[2]) : 4;
+    const int lc = argc > 3 ? atoi(argv[3]) : 2;
+    const int half = argc > 4 ? atoi(argv[4]) : 1;
+    const int iters = argc > 5 ? atoi(argv[5]) : 24;
+    std::vector<DevPlan> d;
+    std::vector<hipStream_t> st(NL);
+    std::vector<std::vector<u64*>> in(NL), out(NL);
+    const int ROTN = getenv("TIMELINE_ROT") ? atoi(getenv("TIMELINE_ROT")) : 4;
+    for (int l = 0; l < NL; l++) {
+      d.push_back(upload(22, 1, lc, twf));
+      CK(hipStreamCreateWithFlags(&st[l], hipStreamNonBlocking));
+      for (int r = 0; r < ROTN; r++) {
+        u64 *a, *b; CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice));
+        in[l].push_back(a); out[l].push_back(b);
+      }
+    }
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipDeviceSynchronize());
+      std::vector<hipEvent_t> b0(NL), b1(NL);
+      for (int l = 0; l < NL; l++) { CK(hipEventCreate(&b0[l])); CK(hipEventCreate(&b1[l])); CK(hipEventRecord(b0[l], st[l])); }
+      for (int it = 0; it < iters; it++)
+        for (int l = 0; l < NL; l++) {
+          const int r = it % ROTN;
+          launch_pass(d[l], 0, bind(d[l], 0, in[l][r], out[l][r], d[l].tmp), half, false, nullptr, st[l]);
+          launch_pass(d[l], 1, bind(d[l], 1, in[l][r], out[l][r], d[l].tmp), half, false, nullptr, st[l]);
+        }
+      float mx = 0;
+      for (int l = 0; l < NL; l++) { CK(hipEventRecord(b1[l], st[l])); }
+      for (int l = 0; l < NL; l++) { CK(hipEventSynchronize(b1[l])); float m = 0; CK(hipEventElapsedTime(&m, b0[0], b1[l])); if (m > mx) mx = m; }
+      const double us = mx * 1e3 / (NL * iters);
+      printf("nlanes %d logc %d half %d rep %d: %.2f us per transform (%.0f NTT/s)\n", NL, lc, half, rep, us, 1e6 / us);
+    }
   } else if (!strcmp(what, "batch")) {
     const int polys = argc > 2 ? atoi(argv[2]) : 8;
     const int half = argc > 3 ? atoi(argv[3]) : 0;
