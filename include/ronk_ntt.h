@@ -117,9 +117,11 @@ typedef struct ronk_plan_opts {
   int tile_log2_columns;        /* as in ronk_plan_create_tuned */
   int twiddle_matrix_log2_max;  /* as in ronk_plan_create_tuned */
   int in_flight;                /* -1 auto, 1, 2 */
-  int reserved[5];              /* zero */
+  int split_log2_rows;          /* two-pass plans (2^13 .. 2^24): log2 of the first pass's rows, 0 = the planner's (balanced)
+                                   choice; values that leave a pass outside 2^4 .. 2^12 rows are ignored */
+  int reserved[4];              /* zero */
 } ronk_plan_opts;
-#define RONK_PLAN_OPTS_DEFAULT { -1, -1, -1, { 0, 0, 0, 0, 0 } }
+#define RONK_PLAN_OPTS_DEFAULT { -1, -1, -1, 0, { 0, 0, 0, 0 } }
 int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                           const ronk_plan_opts* opts);
 /* 1 or 2: the lanes the plan actually uses (see ronk_plan_opts::in_flight) */

@@ -168,7 +168,8 @@ def out_scalar(fn, *args):
 
 class PlanOpts(C.Structure):
     """ronk_plan_opts (include/ronk_ntt.h)"""
-    _fields_ = [("tile_log2_columns", _int), ("twiddle_matrix_log2_max", _int), ("in_flight", _int), ("reserved", _int * 5)]
+    _fields_ = [("tile_log2_columns", _int), ("twiddle_matrix_log2_max", _int), ("in_flight", _int), ("split_log2_rows", _int),
+                ("reserved", _int * 4)]
 
     def __init__(self, tile_log2_columns=-1, twiddle_matrix_log2_max=-1, in_flight=-1):
         super().__init__(tile_log2_columns, twiddle_matrix_log2_max, in_flight)

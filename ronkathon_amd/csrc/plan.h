@@ -194,8 +194,10 @@ struct PlanBuilder {
 // max_logc: widest tile (log2 columns) the builder may pick; 4 = 128-byte segments.
 // three_pass_from: smallest log2n that is split in three passes (25 = only when two do not fit).
 // auto_tiles: the caller left the tile width to the planner -- apply the measured per-pass preferences (below).
+// split_ka: rows (log2) of the first pass of a two-pass plan, 0 = the planner's choice (balanced; the fused multiply asks for the
+// other split of an odd log2n so that its inverse's column pass has the rows of the forward row pass, ntt_mul.h).
 inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0,
-                           int three_pass_from = 25, bool auto_tiles = false) {
+                           int three_pass_from = 25, bool auto_tiles = false, int split_ka = 0) {
   PlanBuilder b;
   b.twf_max_log = twf_max_log;
   if (const char* e = getenv("RONK_WG_FLOOR_LOG")) { int v = atoi(e); if (v >= 10 && v <= 14) b.multi_pass_floor_log = v; }
@@ -222,6 +224,7 @@ inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4,
     // RONK_SPLIT_KA overrides (planner experiments).
     int ka = log2n == 18 ? 10 : (log2n + 1) / 2;
     if (const char* e = getenv("RONK_SPLIT_KA")) { int v = atoi(e); if (v >= 4 && v <= 12 && log2n - v >= 4 && log2n - v <= 12) ka = v; }
+    if (split_ka >= 4 && split_ka <= 12 && log2n - split_ka >= 4 && log2n - split_ka <= 12) ka = split_ka;
     const int kb = log2n - ka;
     const u64 A = (u64)1 << ka, B = (u64)1 << kb;
     // The scratch buffer between the two passes is stored TILE BY TILE: element (ka, b) lives at

@@ -56,6 +56,7 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
   const int tile_log2_columns = opts ? opts->tile_log2_columns : -1;
   const int twiddle_matrix_log2_max = opts ? opts->twiddle_matrix_log2_max : -1;
   int in_flight = opts ? opts->in_flight : -1;
+  const int split_ka = opts ? opts->split_log2_rows : 0;
   if (!out || batch == 0 || log2n > 36) return RONK_ERR_INVALID;
   if (in_flight < -1 || in_flight == 0 || in_flight > 2) return RONK_ERR_INVALID;
   *out = nullptr;
@@ -119,8 +120,8 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // generic first pass, 110 with the (12, 2, 1) shape); batches of 2^23 keep three passes (measured in round 2).
     int three_from = (log2n == 23 && batch == 1) ? 24 : 23;
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
-    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles));
-    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles));
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles, split_ka));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka));
     for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
       if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
   } else {
@@ -185,28 +186,33 @@ static int generic_transform(ronk_plan* pl, bool inverse, const u64* in, u64* ou
 }
 
 // order `s` behind the previous user of the plan's scratch (see ronk_plan::scratch_ev); caller holds stream_mu.
-// Every call leaves an event behind its work (scratch_release): a stream handle kept from an earlier call cannot be used for
-// that later -- the caller may have destroyed it (tests/test_gpu_parity.py does so on purpose; hipEventRecord on a dead
-// handle crashes) -- and a device-wide wait here would stall unrelated streams while the plan lock is held and is illegal
-// beside a stream capture in global mode.  ~1 us of host time per call on a multi-pass plan, under 2 % of the enqueue.
+// While a plan stays on ONE stream nothing is recorded: an event per call is a marker packet in the stream between the
+// launches, measured at +3 us per forward + inverse pair of a 2^16 transform (21.5 -> 27.4 us, round 4) -- a quarter of
+// BASELINE config 2.  The first call that arrives on a second stream therefore finds no event behind the previous call, and
+// the previous stream's HANDLE cannot be used to place one (the caller may have destroyed it: recording on a dead handle
+// crashes -- tests/test_gpu_parity.py::test_plan_seen_on_several_streams does exactly that).  What is left is to drain the
+// plan's DEVICE once (not the caller's current one); from then on every call leaves its event.  Not reached for a
+// capturing stream (transform_dev skips the guard there: a captured graph owns its plan).
 static void scratch_acquire(ronk_plan* pl, hipStream_t s) {
   if (!pl->scratch_used || pl->scratch_stream == s) return;
-  if (pl->scratch_ev_valid && hipStreamWaitEvent(s, pl->scratch_ev, 0) == hipSuccess) return;
-  // no event (the record failed at release time): the last resort, on the PLAN's device
-  (void)hipGetLastError();
-  int cur = -1;
-  (void)hipGetDevice(&cur);
-  if (cur != pl->device) (void)hipSetDevice(pl->device);
-  (void)hipDeviceSynchronize();
-  if (cur >= 0 && cur != pl->device) (void)hipSetDevice(cur);
+  if (!pl->scratch_multi || !pl->scratch_ev_valid || hipStreamWaitEvent(s, pl->scratch_ev, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != pl->device) (void)hipSetDevice(pl->device);
+    (void)hipDeviceSynchronize();
+    if (cur >= 0 && cur != pl->device) (void)hipSetDevice(cur);
+  }
+  pl->scratch_multi = true;
 }
 static void scratch_release(ronk_plan* pl, hipStream_t s) {
   pl->scratch_stream = s; pl->scratch_used = true;
+  if (!pl->scratch_multi) return;
   hipError_t e = hipSuccess;
   if (!pl->scratch_ev) e = hipEventCreateWithFlags(&pl->scratch_ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventRecord(pl->scratch_ev, s);
   pl->scratch_ev_valid = e == hipSuccess;
-  if (e != hipSuccess) (void)hipGetLastError();
+  if (e != hipSuccess) (void)hipGetLastError();   // the next cross-stream acquire drains the device instead
 }
 
 int transform_dev(ronk_plan* pl, bool inverse, const u64* in, const u64* in2, u64* out, hipStream_t s, u64 in_valid,
@@ -752,11 +758,22 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
     // Fused middle (ntt_mul.h): forward row pass of both operands + pointwise product + inverse column pass in ONE launch --
     // three launches per product, NTT(a) / NTT(b) never written.  Needs the same tile width on both sides (a dedicated
-    // inverse plan with the pair plan's 4-column tiles) and square two-pass plans (2^20, 2^22).  RONK_MUL_FUSED=0: the
+    // inverse plan with the pair plan's 4-column tiles) and two-pass plans of 2^10 / 2^11-row passes (2^20 .. 2^22).  RONK_MUL_FUSED=0: the
     // four-launch form (A/B); RONK_MUL_INV_TWF picks the inverse's twiddle form as before (default there: two-level tables).
     static const bool fused_on = [] { const char* e_ = getenv("RONK_MUL_FUSED"); return !e_ || atoi(e_) != 0; }();
-    if (fused_on && (k == 20 || k == 22)) {
-      if (!e->plf) RCHK(ronk_plan_create_tuned(&e->plf, p, g, (u32)k, 1, pl->device, 2, inv_twf != -2 ? inv_twf : 18));
+    // Measured (round 4, same box, us per product): 2^22 158.6 -> 132.6, 2^21 88.0 -> 80.6, but 2^20 63.1 -> 68.1 -- there a
+    // pass has 256 tiles of four wavefronts, one wavefront per SIMD, and three transforms in sequence inside a workgroup are
+    // three times one wavefront's dependent instruction stream; the four-launch form spreads them over twice the tiles.
+    if (fused_on && (k == 21 || k == 22)) {
+      if (!e->plf) {
+        // the inverse whose COLUMN pass has the rows of the pair plan's ROW pass: the balanced split for even k, the other
+        // split of an odd one (2^21: pair plan 2^11 x 2^10, inverse 2^10 x 2^11)
+        ronk_plan_opts o = RONK_PLAN_OPTS_DEFAULT;
+        o.tile_log2_columns = 2;
+        o.twiddle_matrix_log2_max = inv_twf != -2 ? inv_twf : 18;
+        o.split_log2_rows = k / 2;
+        RCHK(ronk_plan_create_opts(&e->plf, p, g, (u32)k, 1, pl->device, &o));
+      }
       const CompiledPlan& F = e->pl2->fwd;
       const CompiledPlan& I = e->plf->inv;
       if (F.pd.passes.size() == 2 && I.pd.passes.size() == 2 && !F.pd.passes[1].small && !I.pd.passes[0].small) {

@@ -33,10 +33,14 @@ pub struct RonkPlanOpts {
   pub twiddle_matrix_log2_max: c_int,
   /// 1 = caller's stream only, 2 = two transforms in flight behind one handle, -1 = automatic
   pub in_flight:               c_int,
-  pub reserved:                [c_int; 5],
+  /// two-pass plans: log2 of the first pass's rows, 0 = the planner's (balanced) choice
+  pub split_log2_rows:         c_int,
+  pub reserved:                [c_int; 4],
 }
 impl Default for RonkPlanOpts {
-  fn default() -> Self { Self { tile_log2_columns: -1, twiddle_matrix_log2_max: -1, in_flight: -1, reserved: [0; 5] } }
+  fn default() -> Self {
+    Self { tile_log2_columns: -1, twiddle_matrix_log2_max: -1, in_flight: -1, split_log2_rows: 0, reserved: [0; 4] }
+  }
 }
 
 extern "C" {

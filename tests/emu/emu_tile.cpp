@@ -260,7 +260,7 @@ static TileArgs bind_pass(const PlanDesc& pd, size_t idx, const u64* in, u64* ou
 static int mul_main(int log2n, u64 d, u64 d2, int logc, int inv_twf) {
   const u64 n = (u64)1 << log2n, m = d + d2 - 1;
   if (m > n) { printf("operands too long\n"); return 2; }
-  PlanDesc F = build_plan(log2n, 2, false, logc, 18), I = build_plan(log2n, 1, true, logc, inv_twf);
+  PlanDesc F = build_plan(log2n, 2, false, logc, 18), I = build_plan(log2n, 1, true, logc, inv_twf, 25, false, log2n / 2);
   std::vector<u64> ab(2 * n, 0x1111), ftmp(2 * n, 0xDEADBEEFull), itmp(n, 0xDEADBEEFull), out(n, 0xDEADBEEFull), ref(m);
   u64 s = 0x5EED0C00ull + log2n;
   for (u64 i = 0; i < d; i++) { do ab[i] = splitmix(s); while (ab[i] >= gl64::P); }

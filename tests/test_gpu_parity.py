@@ -364,9 +364,10 @@ def test_config3_full_vector_2_22(R, orc):
     assert np.array_equal(prod, want[:2 * d - 1])
 
 
-@pytest.mark.parametrize("d,d2", [(1 << 19, 1 << 19), (300001, 7), (1, (1 << 20) - 3), ((1 << 21) + 5, (1 << 21) - 4), (1 << 20, 3 << 19)])
+@pytest.mark.parametrize("d,d2", [(1 << 19, 1 << 19), (300001, 7), (1, (1 << 20) - 3), ((1 << 21) + 5, (1 << 21) - 4), (1 << 20, 3 << 19),
+                                  (1 << 20, 1 << 20), (700001, 900000)])
 def test_fused_multiply_ragged_lengths(R, orc, d, d2):
-    """the fused middle of the multiply (csrc/ntt_mul.h; NTT sizes 2^20 and 2^22): every product coefficient against the
+    """the fused middle of the multiply (csrc/ntt_mul.h; NTT sizes 2^20, 2^21 -- the inverse plan split the other way round -- and 2^22): every product coefficient against the
     oracle's ifft(fft(a) * fft(b)) for operand lengths that are not powers of two, the extreme 1 x long case, and twice in
     a row through the cached plans (src/polynomial/arithmetic.rs:97-119: D + D2 - 1 coefficients)"""
     F = R.GoldilocksField

@@ -2,7 +2,7 @@
 # tools/profile_all.sh <tag> -- the round's evidence run on the GPU box (through gpurun): parity suite, bench lines of every
 # workload (driver arguments for the headline), rocprofv3 trace + PMC of the headline (one transform at a time, and the
 # two-lane throughput regime), the multiply and the batched shape.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
@@ -27,7 +27,10 @@ for lg in 20 21 23 24 26; do timeout 150 python bench.py --no-cpu --mode streams
 timeout 100 python bench.py --no-cpu --workload fourstep --log2n 26 --steps 20 --warmup 3 > $OUT/bench_fourstep_1gpu.json 2>> $OUT/err
 timeout 100 python bench.py --no-cpu --workload sharded --ranks 8 --log2n 26 --steps 20 --warmup 3 > $OUT/bench_sharded_8ranks_1gpu.json 2>> $OUT/err
 # the multi-rank control flow of bench.py (two ranks sharing this GPU over gloo: a smoke test of --gpus N, not a measurement)
-RONK_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu > $OUT/bench_2ranks_gloo_smoke.json 2>> $OUT/err
+# (plain `python bench.py --gpus 2`: bench.py starts its ranks itself)
+RONK_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu > $OUT/bench_2ranks_gloo_smoke.json 2>> $OUT/err
+RONK_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --workload fourstep --log2n 24 --steps 10 --warmup 2 --no-cpu > $OUT/bench_fourstep_2ranks_gloo_smoke.json 2>> $OUT/err
+RONK_MUL_FUSED=0 timeout 300 python bench.py --no-cpu --workload mul22 > $OUT/bench_mul22_four_launches.json 2>> $OUT/err
 tail -2 $OUT/err
 python - <<PY
 import json,glob

@@ -94,10 +94,10 @@ static TileArgs bind(const DevPlan& d, int pass, const u64* in, u64* out, u64* t
   return a;
 }
 
-template <int LOGC, int KIND, bool HALF, bool FORCE>
+template <int LOGC, int KIND, bool HALF, bool FORCE, int LOGR = 11>
 static void launch_k(const PassDesc& ps, const TileArgs& a, u64* rec, hipStream_t s) {
   static bool done = false;
-  auto fn = stamp_kernel<11, LOGC, KIND, HALF, FORCE>;
+  auto fn = stamp_kernel<LOGR, LOGC, KIND, HALF, FORCE>;
   if (!done) { CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
   hipLaunchKernelGGL(fn, dim3(ps.grid), dim3(ps.block), HALF ? ps.lds_bytes / 2 : ps.lds_bytes, s, a, rec);
 }
@@ -211,6 +211,54 @@ int main(int argc, char** argv) {
         }
       }
     }
+  } else if (!strcmp(what, "p24")) {
+    // timeline p24: the strided FIRST pass of the three-pass 2^24 plan (2^9 rows x 16 columns per tile, row stride 256 KiB on
+    // both sides), one stream, HBM-cold rotation; plain and FORCE
+    const size_t n24 = (size_t)1 << 24;
+    DevPlan d = upload(24, 1, 4, 18);
+    // (upload() builds with three_pass_from = 25: rebuild with 23 so that 2^24 is three passes like the library's plan)
+    d.pd = build_plan(24, 1, false, 4, 18, 23);
+    d.wr.clear(); d.tw.clear(); d.twf.clear();
+    for (auto& t : d.pd.wr) { u64* p; CK(hipMalloc(&p, t.size() * 8)); CK(hipMemcpy(p, t.data(), t.size() * 8, hipMemcpyHostToDevice)); d.wr.push_back(p); }
+    for (auto& t : d.pd.tw) {
+      u64 *lo, *hi;
+      CK(hipMalloc(&lo, t.lo.size() * 8)); CK(hipMemcpy(lo, t.lo.data(), t.lo.size() * 8, hipMemcpyHostToDevice));
+      CK(hipMalloc(&hi, t.hi.size() * 8)); CK(hipMemcpy(hi, t.hi.data(), t.hi.size() * 8, hipMemcpyHostToDevice));
+      d.tw.push_back({lo, hi});
+    }
+    for (auto& t : d.pd.twf) { u64* p; CK(hipMalloc(&p, t.size() * 8)); CK(hipMemcpy(p, t.data(), t.size() * 8, hipMemcpyHostToDevice)); d.twf.push_back(p); }
+    const PassDesc& ps = d.pd.passes[0];
+    printf("p24: %zu passes; pass 0 logr %d logc %u grid %u x %u lds %zu\n", d.pd.passes.size(), ps.logr, ps.args.logc, ps.grid, ps.block, ps.lds_bytes);
+    if (ps.logr != 9 || ps.args.logc != 4) { printf("unexpected shape\n"); return 1; }
+    const int R3 = 3;
+    std::vector<u64*> in(R3), out(R3);
+    std::vector<u64> h24(n24);
+    for (auto& v : h24) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = s % gl64::P; }
+    for (int r = 0; r < R3; r++) { CK(hipMalloc(&in[r], n24 * 8)); CK(hipMalloc(&out[r], n24 * 8)); CK(hipMemcpy(in[r], h24.data(), n24 * 8, hipMemcpyHostToDevice)); }
+    const size_t waves = (size_t)ps.grid * (ps.block / 64);
+    u64* rec; CK(hipMalloc(&rec, waves * NS * 8));
+    const int iters = 9;
+    for (int force = 0; force < 2; force++)
+      for (int stamped = 0; stamped < 2; stamped++) {
+        CK(hipMemset(rec, 0, waves * NS * 8));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        for (int it = 0; it < iters; it++) {
+          if (it == 3) CK(hipEventRecord(e0, 0));
+          const TileArgs a = bind(d, 0, in[it % R3], out[it % R3], out[it % R3]);   // pass 0: in -> tmp (here: the out buffer)
+          if (!tile_cfg_matches(a, 9, 4, 1)) { printf("pass 0 is not KIND 1\n"); return 1; }
+          if (force) launch_k<4, 1, false, true, 9>(ps, a, stamped ? rec : nullptr, 0);
+          else launch_k<4, 1, false, false, 9>(ps, a, stamped ? rec : nullptr, 0);
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / (iters - 3);
+        printf("p24 pass 0 force %d stamped %d: %.2f us per launch\n", force, stamped, us);
+        if (stamped) {
+          std::vector<u64> hr(waves * NS);
+          CK(hipMemcpy(hr.data(), rec, hr.size() * 8, hipMemcpyDeviceToHost));
+          dump("p24_pass0", force ? "force" : "plain", hr, waves, us, 1);
+        }
+      }
   } else if (!strcmp(what, "nlanes")) {
     // timeline nlanes <streams> <logc> <half> [iters]: throughput only (no stamps): N streams, transforms back to back on each
     const int NL = argc > 2 ? atoi(argv[2]) : 4;
