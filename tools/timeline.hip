@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../ronkathon_amd/csrc/plan.h"
+#include "experiments/ntt_tile_w.h"
 
 using namespace ronk;
 
@@ -60,6 +61,42 @@ __global__ void __launch_bounds__(1024, HALF ? 8 : 4) stamp_kernel(const TileArg
 #pragma unroll
     for (int i = 2; i < NS; i++) o[i] = i < k ? st[i] : 0;
   }
+}
+
+// the wave-local body (ntt_tile_w.h) with stamps: entry, loads issued (FORCE: landed), round 1 parked, before / after the one
+// workgroup barrier, last store issued, stores acknowledged -> the report sees ONE barrier pair
+template <int KIND, bool FORCE>
+__global__ void __launch_bounds__(512, 2) stamp_kernel_w(const TileArgs a, u64* rec) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u32 nb = gridDim.x, b = blockIdx.x;
+  const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+  const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  u64 st[NS];
+  int k = 2;
+  st[k++] = wall_clock64();
+  tile_body_w<false, KIND>(a, lds, threadIdx.x, bid, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); },
+                           [&](int what) {
+                             if (what == 0) { if (FORCE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[k++] = wall_clock64(); }
+                             else if (what == 2 || what == 3 || what == 4) st[k++] = wall_clock64();
+                           });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st[k++] = wall_clock64();
+  if (rec && (threadIdx.x & 63) == 0) {
+    const u32 hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+    const u32 xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+    u64* o = rec + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NS;
+    o[0] = (u64)k | ((u64)hw << 8);
+    o[1] = (u64)xcc | ((u64)blockIdx.x << 32);
+#pragma unroll
+    for (int i = 2; i < NS; i++) o[i] = i < k ? st[i] : 0;
+  }
+}
+template <int KIND, bool FORCE>
+static void launch_kw(const PassDesc& ps, const TileArgs& a, u64* rec, hipStream_t s) {
+  static bool done = false;
+  auto fn = stamp_kernel_w<KIND, FORCE>;
+  if (!done) { CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+  hipLaunchKernelGGL(fn, dim3(ps.grid), dim3(512), TW_LDS_BYTES, s, a, rec);
 }
 
 struct DevPlan {
@@ -211,6 +248,42 @@ int main(int argc, char** argv) {
         }
       }
     }
+  } else if (!strcmp(what, "wlat")) {
+    // timeline wlat: one 2^22 transform at a time with 4-column tiles (two workgroups of 8 wavefronts per CU), HBM-cold:
+    // ntt_tile.h's body ("c4") against the wave-local first exchange of ntt_tile_w.h ("c4w"), FORCE stamps (loads landed)
+    const int iters = 24;
+    DevPlan d = upload(22, 1, 2, twf);
+    std::vector<u64*> in(ROT), out(ROT);
+    for (int r = 0; r < ROT; r++) { CK(hipMalloc(&in[r], n * 8)); CK(hipMalloc(&out[r], n * 8)); CK(hipMemcpy(in[r], h.data(), n * 8, hipMemcpyHostToDevice)); }
+    const size_t waves = (size_t)d.pd.passes[0].grid * (d.pd.passes[0].block / 64);
+    u64* rec; CK(hipMalloc(&rec, 2 * waves * NS * 8));
+    for (int wl = 0; wl < 2; wl++)
+      for (int stamped = 0; stamped < 2; stamped++) {
+        CK(hipMemset(rec, 0, 2 * waves * NS * 8));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        for (int it = 0; it < iters; it++) {
+          if (it == iters / 2) CK(hipEventRecord(e0, 0));
+          const int r = it % ROT;
+          const TileArgs a0 = bind(d, 0, in[r], out[r], d.tmp), a1 = bind(d, 1, in[r], out[r], d.tmp);
+          if (wl) {
+            if (a0.tw_full) launch_kw<3, true>(d.pd.passes[0], a0, stamped ? rec : nullptr, 0);
+            else launch_kw<1, true>(d.pd.passes[0], a0, stamped ? rec : nullptr, 0);
+            launch_kw<2, true>(d.pd.passes[1], a1, stamped ? rec + waves * NS : nullptr, 0);
+          } else {
+            launch_pass(d, 0, a0, false, true, stamped ? rec : nullptr, 0);
+            launch_pass(d, 1, a1, false, true, stamped ? rec + waves * NS : nullptr, 0);
+          }
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / (iters - iters / 2);
+        printf("wlat wave-local %d stamped %d: %.2f us per transform\n", wl, stamped, us);
+        if (stamped) {
+          std::vector<u64> hr(2 * waves * NS);
+          CK(hipMemcpy(hr.data(), rec, hr.size() * 8, hipMemcpyDeviceToHost));
+          dump(wl ? "lat_c4w" : "lat_c4", "force", hr, 2 * waves, us, 2);
+        }
+      }
   } else if (!strcmp(what, "p24")) {
     // timeline p24: the strided FIRST pass of the three-pass 2^24 plan (2^9 rows x 16 columns per tile, row stride 256 KiB on
     // both sides), one stream, HBM-cold rotation; plain and FORCE

@@ -34,9 +34,10 @@ def read_records(path):
 def phase_names(nst):
     # nst stamps: entry, loaded, (a, l) * nb, issued, acked
     nb = (nst - 4) // 2
-    names = ["load (issue%s)" % "", "round 1 + park"]
+    names = ["load (issue%s)" % "", "round 1 + park" if nb != 1 else "rounds 1 + 2 (no workgroup barrier)"]
     seg = ["wait barrier %d" % (i + 1) for i in range(nb)]
-    comp = {3: ["read", "round 2 + park", "read + round 3 + twiddle + stores"]}.get(
+    comp = {3: ["read", "round 2 + park", "read + round 3 + twiddle + stores"],
+            1: ["read + round 3 + twiddle + stores"]}.get(
         nb, ["compute %d" % (i + 1) for i in range(nb)])
     out = [names[0], names[1]]
     for i in range(nb):
