@@ -248,6 +248,40 @@ int main(int argc, char** argv) {
         }
       }
     }
+  } else if (!strcmp(what, "b16")) {
+    // timeline b16 [half]: BASELINE config 4, 1024 x 2^16 in one launch pair (2^8-row passes, 16-column tiles), plain stamps
+    const int half = argc > 2 ? atoi(argv[2]) : 1;
+    const size_t n16 = (size_t)1 << 16, total = n16 * 1024;
+    DevPlan d = upload(16, 1024, 4, 18);
+    const PassDesc &p0 = d.pd.passes[0], &p1 = d.pd.passes[1];
+    printf("b16: pass 0 logr %d logc %u grid %u x %u, pass 1 logr %d logc %u, half %d\n", p0.logr, p0.args.logc, p0.grid, p0.block, p1.logr, p1.args.logc, half);
+    if (p0.logr != 8 || p0.args.logc != 4 || p1.logr != 8 || p1.args.logc != 4) { printf("unexpected shape\n"); return 1; }
+    u64 *in, *out; CK(hipMalloc(&in, total * 8)); CK(hipMalloc(&out, total * 8));
+    for (size_t off = 0; off < total; off += n) CK(hipMemcpy(in + off, h.data(), (total - off < n ? total - off : n) * 8, hipMemcpyHostToDevice));
+    const size_t waves = (size_t)p0.grid * (p0.block / 64);
+    u64* rec; CK(hipMalloc(&rec, 2 * waves * NS * 8));
+    for (int stamped = 0; stamped < 2; stamped++) {
+      CK(hipMemset(rec, 0, 2 * waves * NS * 8));
+      CK(hipDeviceSynchronize());
+      float ms = 0;
+      const int iters = 4;
+      for (int it = 0; it < iters; it++) {
+        if (it == 1) CK(hipEventRecord(e0, 0));
+        const TileArgs a0 = bind(d, 0, in, out, d.tmp), a1 = bind(d, 1, in, out, d.tmp);
+        if (!tile_cfg_matches(a0, 8, 4, 3) || !tile_cfg_matches(a1, 8, 4, 2)) { printf("passes are not (8,4,3) / (8,4,2)\n"); return 1; }
+        u64* r0 = stamped ? rec : nullptr; u64* r1 = stamped ? rec + waves * NS : nullptr;
+        if (half) { launch_k<4, 3, true, false, 8>(p0, a0, r0, 0); launch_k<4, 2, true, false, 8>(p1, a1, r1, 0); }
+        else { launch_k<4, 3, false, false, 8>(p0, a0, r0, 0); launch_k<4, 2, false, false, 8>(p1, a1, r1, 0); }
+      }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / (iters - 1);
+      printf("b16 half %d stamped %d: %.1f us per batch\n", half, stamped, us);
+      if (stamped) {
+        std::vector<u64> hr(2 * waves * NS);
+        CK(hipMemcpy(hr.data(), rec, hr.size() * 8, hipMemcpyDeviceToHost));
+        dump(half ? "b16_half" : "b16_full", "plain", hr, 2 * waves, us, 2);
+      }
+    }
   } else if (!strcmp(what, "wlat")) {
     // timeline wlat: one 2^22 transform at a time with 4-column tiles (two workgroups of 8 wavefronts per CU), HBM-cold:
     // ntt_tile.h's body ("c4") against the wave-local first exchange of ntt_tile_w.h ("c4w"), FORCE stamps (loads landed)
