@@ -133,7 +133,7 @@ mod tests {
   #[test]
   fn batch_and_lde_on_device() {
     let (k, n, batch) = (1usize << 12, 1usize << 13, 4usize);
-    let msgs: Vec<Goldilocks> = (0..(batch * k) as u64).map(|i| Goldilocks::new(i * 0x9E37_79B9_7F4A_7C15)).collect();
+    let msgs: Vec<Goldilocks> = (0..(batch * k) as u64).map(|i| Goldilocks::new(i.wrapping_mul(0x9E37_79B9_7F4A_7C15))).collect();
     let (plan_k, plan_n) = (Plan::new(12, batch), Plan::new(13, batch));
     let d = DevicePoly::from_host(&msgs);
     let ys = encode_batch(&plan_n, &d, k).to_host();
