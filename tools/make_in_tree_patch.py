@@ -172,6 +172,31 @@ where [(); D + D2 - 1]:
   fn mul(self, rhs: Polynomial<Monomial, Goldilocks, D2>) -> Self::Output { Accelerated::mul_gpu(&self, &rhs) }
 }
 
+/// `Display` as for `PrimeField` polynomials (mod.rs:326-342): `c0 + c1x^1 + c2x^2 + ...`
+impl<const D: usize> Display for Polynomial<Monomial, Goldilocks, D> {
+  fn fmt(&self, f: &mut Formatter<'_>) -> fmt::Result {
+    for (i, c) in self.coefficients.iter().enumerate() {
+      match i {
+        0 => write!(f, "{c}")?,
+        _ => write!(f, " + {c}x^{i}")?,
+      }
+    }
+    Ok(())
+  }
+}
+
+/// `Display` as for `PrimeField` polynomials in the Lagrange basis (mod.rs:487-501): `y0*l_x0(x) + y1*l_x1(x) + ...`,
+/// the subscript being the NODE
+impl<const D: usize> Display for Polynomial<Lagrange<Goldilocks>, Goldilocks, D> {
+  fn fmt(&self, f: &mut Formatter<'_>) -> fmt::Result {
+    for (idx, (y, x)) in self.coefficients.iter().zip(self.basis.nodes.iter()).enumerate() {
+      let sep = if idx == 0 { "" } else { " + " };
+      write!(f, "{sep}{y}*l_{x}(x)")?;
+    }
+    Ok(())
+  }
+}
+
 #[cfg(test)]
 mod tests {
   //! the accelerated methods against the reference bodies they replace; need a GPU and libronk_ntt.so
@@ -191,6 +216,9 @@ mod tests {
     let b = Polynomial::<Monomial, Goldilocks, 2>::new([Goldilocks(5), Goldilocks(1)]);
     assert_eq!(p / b, p.quotient_and_remainder_reference(b).0);
     assert_eq!(p % b, p.quotient_and_remainder_reference(b).1);
+    assert_eq!(format!("{p}"), "1 + 2x^1 + 3x^2 + 4x^3");
+    assert_eq!(format!("{}", p.fft()), format!("10*l_1(x) + {}*l_{}(x) + {}*l_{}(x) + {}*l_{}(x)",
+      18446181119461163007u64, 1u64 << 48, 18446744069414584319u64, 18446744069414584320u64, 562949953421310u64, 18446462594437873665u64));
   }
 
   #[test]
