@@ -7,7 +7,8 @@ options, host and device forms, several arrays per call), mul (products of rando
 path), generic (transforms, products, dft over small primes and non-power-of-two sizes), divrem (general divisors incl.
 trailing zeros and the Newton path), lindiv (division by a linear divisor + evaluate, whole-vector recurrence), codes
 (Reed-Solomon encode / decode / LDE), vec (element-wise operators incl. zero inverses), lagrange (barycentric evaluate), msm (BN254 G1 against known multiples of G),
-sharded (the in-library four-step plan with 1 .. 8 logical ranks on this GPU).
+sharded (the in-library four-step plan with 1 .. 8 logical ranks on this GPU), threads (four host threads, null stream and own
+streams mixed).
 Exit status 1 on any mismatch; every mismatch prints the arguments that reproduce it."""
 import os
 import random
@@ -428,8 +429,85 @@ def sec_sharded(deadline):
     counts["sharded"] = it
 
 
+def sec_threads(deadline):
+    """four host threads at once (the reference's `cargo test` runs tests on parallel threads): one-shot transforms, products up
+    to the fused sizes, linear and general divisions, evaluations -- half of the threads on the null stream, half on their own"""
+    import threading
+    total = [0]
+    lock = threading.Lock()
+
+    def worker(tid):
+        r = random.Random(SEED * 1000 + tid)
+        st = torch.cuda.Stream() if tid & 1 else None
+        sp = st.cuda_stream if st else 0
+        it = 0
+        while time.time() < deadline:
+            it += 1
+            op = r.choice(["fft", "mul", "mulbig", "lindiv", "divrem", "eval"])
+            try:
+                if op == "fft":
+                    k = r.randrange(4, 21); n = 1 << k
+                    x = splitmix_field(tid * 7919 + it, n)
+                    out = np.empty(n, dtype=np.uint64)
+                    L.check(L.lib.ronk_fft(GP, GG, L.ptr(x), L.ptr(out), None, n))
+                    if not np.array_equal(out, orc.fft(GP, GG, x)):
+                        report("threads", "fft", tid, k)
+                elif op in ("mul", "mulbig"):
+                    if op == "mul":
+                        d1, d2 = r.randrange(1, 100000), r.randrange(1, 100000)
+                    else:
+                        tot = r.randrange((1 << 20) + 2, (1 << 22) + 2); d1 = r.randrange(1, tot - 1); d2 = tot - d1
+                    a = splitmix_field(tid * 7919 + 2 * it, d1); b = splitmix_field(tid * 7919 + 2 * it + 1, d2)
+                    with torch.cuda.stream(st) if st else torch.cuda.stream(torch.cuda.default_stream()):
+                        da, db = dev(a), dev(b)
+                        do = torch.empty(d1 + d2 - 1, dtype=torch.int64, device="cuda")
+                        torch.cuda.current_stream().synchronize()
+                    L.check(L.lib.ronk_poly_mul_dev(GP, GG, da.data_ptr(), d1, db.data_ptr(), d2, do.data_ptr(), sp))
+                    (st or torch.cuda.default_stream()).synchronize()
+                    out = host(do)
+                    t = 0x1234567 + it
+                    if orc.poly_eval(GP, out, t) != orc.mul(GP, orc.poly_eval(GP, a, t), orc.poly_eval(GP, b, t)):
+                        report("threads", op, tid, d1, d2)
+                elif op in ("lindiv", "eval"):
+                    d = r.choice([r.randrange(1, 5000), r.randrange(1, 3000000)])
+                    a = splitmix_field(tid * 7919 + it, d)
+                    z = r.randrange(GP)
+                    with torch.cuda.stream(st) if st else torch.cuda.stream(torch.cuda.default_stream()):
+                        da = dev(a); dq = torch.empty(d, dtype=torch.int64, device="cuda"); dr = torch.zeros(2, dtype=torch.int64, device="cuda")
+                        torch.cuda.current_stream().synchronize()
+                    L.check(L.lib.ronk_poly_eval_dev(GP, da.data_ptr(), d, z, dr.data_ptr() + 8, sp))
+                    L.check(L.lib.ronk_poly_div_linear_dev(GP, da.data_ptr(), d, orc.neg(GP, z), 1, dq.data_ptr(), dr.data_ptr(), sp))
+                    (st or torch.cuda.default_stream()).synchronize()
+                    q = host(dq); rr = host(dr)
+                    val = orc.poly_eval(GP, a, z)
+                    ok = int(rr[0]) == val and int(rr[1]) == val
+                    if ok and d > 1:
+                        ok = np.array_equal(q[:-1], orc.vec_add(GP, a[1:], orc.vec_mul(GP, q[1:], np.full(d - 1, z, dtype=np.uint64))))
+                    if not ok:
+                        report("threads", op, tid, d, z)
+                else:
+                    d = r.randrange(2, 30000); d2 = r.randrange(1, d + 1)
+                    a = splitmix_field(tid * 7919 + 2 * it, d); b = splitmix_field(tid * 7919 + 2 * it + 1, d2)
+                    if not b[-1]:
+                        b[-1] = 1
+                    q = np.empty(d, dtype=np.uint64); rm = np.empty(d, dtype=np.uint64)
+                    L.check(L.lib.ronk_poly_divrem(GP, L.ptr(a), d, L.ptr(b), d2, L.ptr(q), L.ptr(rm)))
+                    wq, wr = orc.poly_divrem(GP, a, b)
+                    if not (np.array_equal(q, wq) and np.array_equal(rm, wr)):
+                        report("threads", "divrem", tid, d, d2)
+            except Exception as e:   # noqa: BLE001
+                report("threads", "exception in " + op, tid, repr(e))
+        with lock:
+            total[0] += it
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    counts["threads"] = total[0]
+
+
 SECTIONS = dict(ntt=sec_ntt, mul=sec_mul, generic=sec_generic, divrem=sec_divrem, lindiv=sec_lindiv, codes=sec_codes, vec=sec_vec,
-                lagrange=sec_lagrange, msm=sec_msm, sharded=sec_sharded)
+                lagrange=sec_lagrange, msm=sec_msm, sharded=sec_sharded, threads=sec_threads)
 
 
 def main():
