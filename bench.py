@@ -41,14 +41,20 @@ WORKLOADS = {
 }
 
 
+MODULUS = 0xFFFFFFFF00000001   # the field of the run: Goldilocks unless --prime says otherwise (main)
+GENERATOR = 7
+
+
 def synth(n, seed):
-    """i.i.d. uniform on [0, p), as int64-viewable uint64"""
+    """i.i.d. uniform on [0, p), as int64-viewable uint64: rejection sampling from 64 random bits (primes
+    near 2^64), from the bits the prime has (small primes)"""
     rng = np.random.default_rng(seed)
-    P = np.uint64(0xFFFFFFFF00000001)
-    x = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    P = np.uint64(MODULUS)
+    top = 1 << MODULUS.bit_length()
+    x = rng.integers(0, top, size=n, dtype=np.uint64)
     bad = x >= P
     while bad.any():
-        x[bad] = rng.integers(0, 2**64, size=int(bad.sum()), dtype=np.uint64)
+        x[bad] = rng.integers(0, top, size=int(bad.sum()), dtype=np.uint64)
         bad = x >= P
     return x
 
@@ -56,7 +62,8 @@ def synth(n, seed):
 KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", "ronkathon_amd/csrc/plan.h",
                   "ronkathon_amd/csrc/tile_kernels.hip", "ronkathon_amd/csrc/tile_kernels_cfg.hip",
                   "ronkathon_amd/csrc/tile_kernel_def.h", "ronkathon_amd/csrc/tile_cfg_table.h",
-                  "ronkathon_amd/csrc/tile_kernels_half.hip", "ronkathon_amd/csrc/tile_kernels_feat.hip")
+                  "ronkathon_amd/csrc/tile_kernels_half.hip", "ronkathon_amd/csrc/tile_kernels_feat.hip",
+                  "ronkathon_amd/csrc/field_policy.h", "ronkathon_amd/csrc/mont64.h", "ronkathon_amd/csrc/tile_kernels_mont.hip")
 VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
 
 
@@ -98,7 +105,7 @@ def cpu_baseline_mul(log2n, budget_s=10.0):
     in C, one thread; (b) the reference's own schoolbook Mul (polynomial/arithmetic.rs:97-119) timed at small D and
     EXTRAPOLATED ~ D^2 to the benchmark size (flagged as an extrapolation)."""
     import oracle as orc
-    P, G = orc.GOLDILOCKS_P, orc.GOLDILOCKS_G
+    P, G = MODULUS, GENERATOR
     n = 1 << log2n
     a = np.concatenate([synth(n // 2, 7), np.zeros(n // 2, dtype=np.uint64)])
     b = np.concatenate([synth(n // 2, 8), np.zeros(n // 2, dtype=np.uint64)])
@@ -130,7 +137,7 @@ def cpu_baseline_mul(log2n, budget_s=10.0):
 def cpu_baseline_roundtrip(log2n, budget_s=8.0):
     """forward + inverse (polynomial/mod.rs:295-323, :430-453: same recursion + n^-1 scaling), one thread"""
     import oracle as orc
-    P, G = orc.GOLDILOCKS_P, orc.GOLDILOCKS_G
+    P, G = MODULUS, GENERATOR
     x = synth(1 << log2n, 98)
     reps, t = 0, 0.0
     while t < budget_s and reps < 64:
@@ -145,17 +152,18 @@ def cpu_baseline_roundtrip(log2n, budget_s=8.0):
                       "restated in C, 1 thread" % (reps, log2n), "host_cores_available": os.cpu_count()}
 
 
-def cpu_baseline(log2n, budget_s=12.0):
+def cpu_baseline(log2n, budget_s=12.0, p=None, g=None):
     """oracle (port of the reference's recursive fft, polynomial/mod.rs:295-323) on one host core"""
     import oracle as orc
+    p, g = p or orc.GOLDILOCKS_P, g or orc.GOLDILOCKS_G
     n = 1 << log2n
     x = synth(n, 99)
-    w = orc.primitive_root_of_unity(orc.GOLDILOCKS_P, orc.GOLDILOCKS_G, n)  # root excluded from the timed region
+    w = orc.primitive_root_of_unity(p, g, n)  # root excluded from the timed region
     reps, t = 0, 0.0
     while True:
         v = x.copy()
         t0 = time.perf_counter()
-        orc.fft_recursive_inplace(orc.GOLDILOCKS_P, v, w)
+        orc.fft_recursive_inplace(p, v, w)
         t += time.perf_counter() - t0
         reps += 1
         if t > budget_s or reps >= 8:
@@ -237,6 +245,11 @@ def main():
                          "backend (fourstep, one process per GPU) or the library's dlopen'ed ncclGroup Send/Recv (sharded, one "
                          "process); mesh: the library's hipMemcpyPeerAsync mesh (sharded); host: staged through host memory "
                          "(gloo smoke runs); auto = rccl for fourstep, mesh for sharded")
+    ap.add_argument("--prime", type=lambda v: int(v, 0), default=0,
+                    help="ntt22 / batch16 / roundtrip16 / mul22: another odd 64-bit prime than Goldilocks (the tile kernels over "
+                         "Montgomery arithmetic, csrc/field_policy.h), e.g. 0xFFFFFFFC00000001")
+    ap.add_argument("--generator", type=lambda v: int(v, 0), default=0,
+                    help="primitive element for --prime (default: the smallest quadratic non-residue)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the contract's
@@ -269,8 +282,19 @@ def main():
     import ronkathon_amd as R
     from ronkathon_amd import _lib as L
     P, G = R.GOLDILOCKS_P, R.GOLDILOCKS_G
-
     wl = args.workload
+    mont = False
+    if args.prime and (args.prime, args.generator or 7) != (P, 7):
+        if wl not in ("ntt22", "batch16", "roundtrip16", "mul22"):
+            sys.exit("bench.py: --prime applies to the transform workloads (ntt22, batch16, roundtrip16, mul22)")
+        global MODULUS, GENERATOR
+        P = MODULUS = args.prime
+        G = args.generator
+        if not G:      # any quadratic non-residue gives omega_n = g^((p-1)/n) its exact order for every power of two n
+            G = next(c for c in range(2, 1000) if pow(c, (P - 1) // 2, P) == P - 1)
+        GENERATOR = G
+        mont = True
+
     if wl == "fourstep":
         from ronkathon_amd import dist as rdist
         # the exchange: RCCL all_to_all_single on the nccl backend (one process per GPU, the product path) or, on a backend
@@ -515,6 +539,8 @@ def main():
     # latency plan: one transform at a time on one stream, library defaults
     lat_plan = (L.Plan(P, G, log2n, batch, local_rank, twiddle_matrix_log2_max=args.twf, in_flight=1)
                 if (wl == "ntt22" and (tile_lc >= 0 or mode != "streams")) else plans[0])
+    if wl in ("ntt22", "batch16", "roundtrip16"):
+        assert lat_plan.path() == (2 if mont else 1), "the timed plan does not run the tile kernels (ronk_plan_path)"
     x, y, plan, stream = xs[0], ys[0], plans[0], main_stream.cuda_stream
     rot = {"R": R_cold, "lat": False}     # what run() cycles over: set before each measurement
     if wl == "mul22":
@@ -764,8 +790,13 @@ def main():
     # tools/rocprof_summary.py; FETCH_SIZE x2 gfx950 correction, calibrated on this kernel's known byte count).
     # bench.py cannot read PMCs itself: it reports the committed measurement of the dominant kernel IF that file was
     # taken on the current kernel sources (hash stored in the file), else null.
+    # Which file: the counters of the kernels `value` RAN.  The headline's regime is two lanes on the 4-column kernels
+    # (ntt_tile_kernel<11, false, 2, *>): profiles/latest_pmc_ntt22.json is taken from exactly this command line
+    # (tools/profile_all.sh, "many"); the one-transform-at-a-time kernels (8-column tiles) have their own file, reported as
+    # roofline.latency_regime.  A Montgomery prime runs other kernels again: latest_pmc_ntt22_mont.json.
     traffic, traffic_note, valu = None, None, None
-    pmc, why = load_if_current("profiles/latest_pmc_%s.json" % wl, wl)
+    pmc_key = wl + ("_mont" if mont else "") + ("_1stream" if (wl == "ntt22" and mode == "streams" and S == 1) else "")
+    pmc, why = load_if_current("profiles/latest_pmc_%s.json" % pmc_key, wl)
     if pmc and log2n == wl_log2n and batch == wl_batch:
         # every kernel of the step that moved data (the passes of a transform; the two scan kernels of a division): the
         # step's traffic and VALU count are SUMS over them, each counted once per step
@@ -781,7 +812,7 @@ def main():
                             "Infinity-Cache hits (MI355X_MICROARCH.md), so this is traffic at the L2's memory side, an upper "
                             "bound on HBM bytes" % (len(kerns), "; ".join("%s: %.0f" % (k_[:60], c["_hbm_bytes_per_launch"]["total"])
                                                                          for k_, c in zip(kerns, cs)),
-                                                  pmc.get("source", "latest_pmc_%s.json" % wl)))
+                                                  pmc.get("source", "latest_pmc_%s.json" % pmc_key)))
             if wl == "ntt22":
                 traffic_note += ("; algorithmic bytes per step = %d (16*n); a two-pass plan moves 2x that by construction, "
                                  "anything above is re-reads / split lines" % (16 * n))
@@ -792,7 +823,7 @@ def main():
         traffic_note = "no current PMC file for this workload/kernel (%s): re-run tools/profile.sh" % why
     # Secondary ceiling: 64-bit modular arithmetic is VALU-issue bound.  Static census of the executed
     # path (tools/census.py: instructions and issue slots per coefficient, weights from tools/instr_rate.hip).
-    if wl == "ntt22":
+    if wl == "ntt22" and not mont:
         cen, why_c = load_if_current("profiles/latest_census.json")
         if cen:
             valu = valu or {}
@@ -807,9 +838,25 @@ def main():
             valu = {"note": "census " + why_c}
     # `achieved` / `frac` follow `value`: the throughput regime, R_cold buffers, device clock over the timed region.  The
     # latency regime (one transform at a time: kernel durations add up) and the warm variants are reported beside it.
-    roofline = {"bound": "hbm", "achieved": achieved_thr, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_thr / HBM_PEAK_GBS, "frac_throughput": achieved_thr / HBM_PEAK_GBS,
-                "frac_latency": achieved / HBM_PEAK_GBS,
+    # `achieved` / `frac` are computed from the SAME clock as `ms_per_step` (the wall time of the median region, max over
+    # ranks): frac == algorithmic_bytes_per_step / (ms_per_step / 1e3) / 8e12, recomputable from the line itself.  The HIP-event
+    # figure over the same regions (device clock on the launch stream) is reported beside it as frac_device.
+    achieved_wall = alg_bytes_step / (dt / args.steps) / 1e9
+    lat_pmc = None
+    if wl == "ntt22" and not mont and pmc_key == "ntt22":
+        lp, _ = load_if_current("profiles/latest_pmc_ntt22_1stream.json", wl)
+        if lp:
+            lk = [c for kname, c in lp.get("counters", {}).items() if "_hbm_bytes_per_launch" in c and "ronk::" in kname]
+            if lk:
+                lat_pmc = {"traffic": sum(c["_hbm_bytes_per_launch"]["total"] for c in lk),
+                           "valu_insts_per_coeff": (sum(c["SQ_INSTS_VALU"]["avg"] for c in lk) * 64.0 / n
+                                                    if all("SQ_INSTS_VALU" in c for c in lk) else None),
+                           "source": lp.get("source"),
+                           "note": "counters of the kernels frac_latency times (one transform at a time, default plan: 8-column tiles)"}
+    roofline = {"bound": "hbm", "achieved": achieved_wall, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_wall / HBM_PEAK_GBS, "frac_device": achieved_thr / HBM_PEAK_GBS,
+                "frac_throughput": achieved_thr / HBM_PEAK_GBS,
+                "frac_latency": achieved / HBM_PEAK_GBS, "latency_regime": lat_pmc,
                 "frac_throughput_warm": (alg_bytes_step * warm["value"] / world / batch / 1e9 / HBM_PEAK_GBS) if warm else None,
                 "frac_latency_warm": (alg_bytes_step / (lat_warm_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS) if lat_warm_ms else None,
                 "rotate": R_cold,
@@ -819,8 +866,9 @@ def main():
                                                                                          plan.num_passes()),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "device_us_per_step_min": min(dev_ms_samples) * 1e3 / args.steps,
-                "note": "achieved / frac / frac_throughput: the regime of `value` (%s), HIP events on the launch stream over the "
-                        "timed region, inputs and outputs cycling over %d buffer pairs (%d MiB touched between two uses of a "
+                "note": "achieved / frac: the regime of `value` (%s) on the clock of ms_per_step (wall, median region); frac_device / "
+                        "frac_throughput: HIP events on the launch stream over the same "
+                        "timed regions; inputs and outputs cycling over %d buffer pairs (%d MiB touched between two uses of a "
                         "buffer); frac_latency: one transform at a time on ONE stream, default plan (kernel durations add up), "
                         "same rotation; *_warm: the same buffers every step (inputs stay in the 256 MiB Infinity Cache); median of "
                         "%d regions of %d steps" % (
@@ -839,7 +887,9 @@ def main():
         dist.all_reduce(one_)
         ranks_seen = int(one_.item())
     if rank == 0:
-        res = {"metric": "forward NTTs/s, degree 2^%d, 64-bit Goldilocks prime" % log2n if wl == "ntt22" else wl,
+        pdesc = "p = 2^64 - 2^32 + 1" if not mont else "p = %#x (g = %d; Montgomery tile kernels)" % (P, G)
+        res = {"metric": ("forward NTTs/s, degree 2^%d, 64-bit %s" % (log2n, "Goldilocks prime" if not mont else "prime %#x" % P))
+                         if wl == "ntt22" else wl,
                "value": value, "unit": wl_unit,
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": dt_min / args.steps * 1e3,
@@ -849,8 +899,8 @@ def main():
                "verified": bool(verified_what), "verified_how": verified_what,
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-               "config": {"workload": "forward NTT, n = 2^%d, batch %d, p = 2^64 - 2^32 + 1, natural order in/out, device resident"
-                          % (log2n, batch) if wl in ("ntt22", "batch16") else wl,
+               "config": {"workload": "forward NTT, n = 2^%d, batch %d, %s, natural order in/out, device resident"
+                          % (log2n, batch, pdesc) if wl in ("ntt22", "batch16") else (wl + (", " + pdesc if mont else "")),
                           "log2n": log2n, "batch": batch, "streams": S, "parallelism": "independent polynomials per GPU (x%d)" % world},
                "roofline": roofline}
         if warm:
@@ -860,7 +910,7 @@ def main():
         res["ranks_seen"] = ranks_seen
         assert ranks_seen == args.gpus, "ranks_seen %d != --gpus %d" % (ranks_seen, args.gpus)
         if not args.no_cpu and world == 1 and wl == "ntt22":       # reported at N = 1 only (bench contract)
-            res["cpu_baseline"] = cpu_baseline(log2n)
+            res["cpu_baseline"] = cpu_baseline(log2n, p=P, g=G)
         if not args.no_cpu and world == 1 and wl in ("batch16", "rs16"):
             res["cpu_baseline"] = cpu_baseline_batched(log2n)
         if not args.no_cpu and world == 1 and wl == "mul22":

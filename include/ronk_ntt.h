@@ -127,10 +127,14 @@ int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2
 /* 1 or 2: the lanes the plan actually uses (see ronk_plan_opts::in_flight) */
 int ronk_plan_in_flight(const ronk_plan* plan);
 int ronk_plan_destroy(ronk_plan* plan);
-/* Which kernel family the plan runs on: 1 = the tiled Goldilocks path (p = 2^64 - 2^32 + 1 with the explicit generator 7,
- * 2^4 <= n <= 2^30) -- the tuned one; 0 = the generic radix-2 path (any other odd prime, Goldilocks with another
- * generator, n < 16 or n > 2^30: Montgomery arithmetic, one HBM pass per stage, n <= 2^32 -- a parity vehicle for the
- * reference's small-field vectors, an order of magnitude slower per coefficient). */
+/* Which kernel family the plan runs on (2^4 <= n <= 2^30 for the tiled ones):
+ *   1 = the tiled Goldilocks path (p = 2^64 - 2^32 + 1 with the explicit generator 7): shift twiddles inside a register round;
+ *   2 = the SAME tile kernels over Montgomery arithmetic (R = 2^64): any other odd prime p < 2^64 -- PrimeField<P> is generic
+ *       over P, src/algebra/field/prime/mod.rs:39-52 -- and Goldilocks with another generator, whenever g is a quadratic
+ *       non-residue (then omega_n = g^((p-1)/n) has order exactly n for every power of two n | p - 1).  Coefficients stay
+ *       canonical; twiddle tables hold w * 2^64 mod p.  About twice the arithmetic of path 1 per coefficient;
+ *   0 = the radix-2 path (n < 16, n > 2^30, or a g that generates no full 2-power subgroup -- the reference's recursion
+ *       src/polynomial/mod.rs:295-323 is then not the DFT and is restated stage by stage): one HBM pass per stage, n <= 2^32. */
 int ronk_plan_path(const ronk_plan* plan);
 
 /* Polynomial::<Monomial,F,D>::fft() (polynomial/mod.rs:273-323; same values as dft() :240-258).

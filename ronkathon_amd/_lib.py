@@ -214,7 +214,7 @@ class Plan:
         return lib.ronk_plan_num_passes(self.h)
 
     def path(self):
-        """1 = tiled Goldilocks kernels, 0 = generic radix-2 path (ronk_plan_path)"""
+        """1 = tiled Goldilocks kernels, 2 = the tile kernels over a Montgomery prime, 0 = generic radix-2 path (ronk_plan_path)"""
         return lib.ronk_plan_path(self.h)
 
     def forward(self, x, nodes=False):

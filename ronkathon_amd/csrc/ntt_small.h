@@ -35,17 +35,19 @@ RONK_HD void small_keep(u64& v) {
 }
 
 // omega_4^{+-1} * x: omega_4 = omega_64^16 = 2^(39*16 mod 192) = 2^48; the inverse is 2^144 = -2^48
-template <bool INV>
-RONK_HD u64 mul_w4_of_diff(u64 a, u64 b) {   // (a - b) * omega_4^{+-1}
-  return INV ? gl64::mul_2exp<48>(gl64::sub(b, a)) : gl64::mul_2exp<48>(gl64::sub(a, b));
+// (Montgomery primes: one product by the table entry omega_16^{+-4}, field_policy.h)
+template <bool INV, class FLD>
+RONK_HD u64 mul_w4_of_diff(const FLD& f, u64 a, u64 b) {   // (a - b) * omega_4^{+-1}
+  return f.template sub_mul_root<4, 1, INV>(a, b);
 }
 
-template <int LOGR, bool INV, class Barrier>
+template <int LOGR, bool INV, class FLD = GlField, class Barrier>
 RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
   constexpr u32 R = 1u << LOGR;
   constexpr int S4 = LOGR / 2;              // radix-4 rounds
   constexpr bool ODD = (LOGR & 1) != 0;     // + one radix-2 round
   static_assert(LOGR >= 4 && LOGR <= 10, "small pass size");
+  const FLD f(a.fc);
   const u32 logc = a.logc, C = 1u << logc;
   const u32 c = tid & (C - 1), u = tid >> logc;   // u in [0, R/4)
   const u32 t = bid % a.tiles, bb = bid / a.tiles, b1 = bb % a.nb1, b2 = bb / a.nb1;
@@ -127,7 +129,7 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (!ok[i]) x[i] = 0;
-    else if (a.in2) x[i] = gl64::mul(x[i], x2[i]);
+    else if (a.in2) x[i] = f.mul_plain(x[i], x2[i]);
   }
   // ---- radix-4 rounds
 #pragma unroll
@@ -139,13 +141,13 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = lds[cell(p0 + i * q)];
     }
-    const u64 t0 = gl64::add(x[0], x[2]), t1 = gl64::sub(x[0], x[2]);
-    const u64 t2 = gl64::add(x[1], x[3]), t3 = mul_w4_of_diff<INV>(x[1], x[3]);
-    x[0] = gl64::add(t0, t2); x[1] = gl64::add(t1, t3); x[2] = gl64::sub(t0, t2); x[3] = gl64::sub(t1, t3);
+    const u64 t0 = f.add(x[0], x[2]), t1 = f.sub(x[0], x[2]);
+    const u64 t2 = f.add(x[1], x[3]), t3 = mul_w4_of_diff<INV>(f, x[1], x[3]);
+    x[0] = f.add(t0, t2); x[1] = f.add(t1, t3); x[2] = f.sub(t0, t2); x[3] = f.sub(t1, t3);
     // twiddles omega_L^{j r} = omega_R^{j r R/L} (fetched above)
     if (s < TWR) {
 #pragma unroll
-      for (int r = 1; r < 4; r++) x[r] = gl64::mul(x[r], twr[s < TWR ? s : 0][r - 1]);
+      for (int r = 1; r < 4; r++) x[r] = f.mul(x[r], twr[s < TWR ? s : 0][r - 1]);
     }
     if (s == S4 - 1 && !ODD) break;   // results stay in registers: output below
     // in place: the four positions belong to this work-item alone in this round, so no barrier between its reads and writes
@@ -159,8 +161,8 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
     for (int h = 0; h < 2; h++) {
       const u32 v = 2 * u + h;
       const u64 e0 = lds[cell(2 * v)], e1 = lds[cell(2 * v + 1)];
-      x[2 * h] = gl64::add(e0, e1);
-      x[2 * h + 1] = gl64::sub(e0, e1);
+      x[2 * h] = f.add(e0, e1);
+      x[2 * h + 1] = f.sub(e0, e1);
     }
   }
   // ---- output: inter-pass twiddle / scale, natural order
@@ -169,9 +171,9 @@ RONK_HD void small_body(const TileArgs& a, u64* lds, u32 tid, u32 bid, Barrier&&
   for (int i = 0; i < 4; i++) {
     const u32 k = natural(pos[i]);
     u64 v = x[i];
-    if (a.tw_full) v = gl64::mul(v, two[i]);
-    else if (a.tw_log) v = gl64::mul(v, gl64::mul(two[i], two_hi[i]));
-    if (a.scale != 1) v = gl64::mul(v, a.scale);
+    if (a.tw_full) v = f.mul(v, two[i]);
+    else if (a.tw_log) v = f.mul(v, f.mul(two[i], two_hi[i]));
+    if (a.scale != 1) v = f.mul(v, a.scale);
     const u64 lin = (u64)((i64)b2 * a.out_sb2 + (i64)t * a.out_st + (i64)c * a.out_sc + (i64)k * a.out_sk);
     if (a.out_valid == ~(u64)0 || lin < a.out_valid) out[(i64)k * a.out_sk] = v;
   }

@@ -28,7 +28,7 @@
 // The body is plain C++ over (tid, bid, lds, barrier) so that tests/emu can run the very
 // same code on host threads to check the index algebra without a GPU.
 #pragma once
-#include "gl64.h"
+#include "field_policy.h"
 
 namespace ronk {
 
@@ -78,6 +78,8 @@ struct TileArgs {
   // lane, 128-byte lane stride, outputs in bit-reversed order).  With stage_io the run is copied HBM <-> LDS with fully
   // coalesced accesses and the per-lane indexing happens against LDS (image e + e/16, e = c*R + row).
   u32 stage_io;
+  // the prime of a Montgomery pass (field_policy.h; p == 0: Goldilocks, nothing of it is read)
+  FieldConst fc;
 };
 
 // ---- compile-time helpers -------------------------------------------------------------
@@ -88,56 +90,39 @@ constexpr int brev(int x, int bits) {
   return r;
 }
 
-// exponent E with omega_N^j == 2^E (mod p), N | 64; inverse direction uses omega^-1
-constexpr int root_exp(int n, int j, bool inv) {
-  int e = (39 * (64 / n) * j) % 192;
-  return inv ? (192 - e) % 192 : e;
-}
-
-// (a - b) * omega_N^J
-template <int N, int J, bool INV>
-RONK_HD u64 sub_mul_root(u64 a, u64 b) {
-  constexpr int E = root_exp(N, J, INV);
-  if constexpr (E >= 96) {
-    return gl64::mul_2exp<E - 96>(gl64::sub(b, a));  // omega = -2^(E-96)
-  } else {
-    return gl64::mul_2exp<E>(gl64::sub(a, b));
-  }
-}
-
 // one DIF stage on x[0..N): (a, b) -> (a + b, (a - b) * omega_N^j), j = J..N/2-1.
 // LAZY (last stage, N == 2, when every output but x[0] is multiplied next): the sums skip the canonicalising compare
 // (gl64::add_lazy); `keep0` says whether this pair contains element 0 of the whole sub-transform, which is stored /
 // parked without a multiplication and must stay canonical.
-template <int N, bool INV, int J, bool LAZY = false>
-RONK_HD void dif_stage(u64* x, bool keep0 = true) {
+template <int N, bool INV, int J, bool LAZY = false, class FLD = GlField>
+RONK_HD void dif_stage(u64* x, const FLD& f, bool keep0 = true) {
   if constexpr (J < N / 2) {
     u64 a = x[J], b = x[J + N / 2];
-    if constexpr (LAZY) x[J] = keep0 ? gl64::add(a, b) : gl64::add_lazy(a, b);
-    else x[J] = gl64::add(a, b);
-    x[J + N / 2] = sub_mul_root<N, J, INV>(a, b);
-    dif_stage<N, INV, J + 1, LAZY>(x, keep0);
+    if constexpr (LAZY) x[J] = keep0 ? f.add(a, b) : f.add_lazy(a, b);
+    else x[J] = f.add(a, b);
+    x[J + N / 2] = f.template sub_mul_root<N, J, INV>(a, b);
+    dif_stage<N, INV, J + 1, LAZY, FLD>(x, f, keep0);
   }
 }
 
 // N-point DIF DFT in registers; x[t] ends up holding X[brev(t)].
 // LAZY: outputs other than X[0] may be non-canonical representatives (see dif_stage); `first` = this sub-block starts at
 // element 0 of the whole transform.
-template <int N, bool INV, bool LAZY = false>
+template <int N, bool INV, bool LAZY = false, class FLD = GlField>
 struct Dif {
-  static RONK_HD void run(u64* x, bool first = true) {
+  static RONK_HD void run(u64* x, const FLD& f, bool first = true) {
     if constexpr (N == 2) {
-      dif_stage<2, INV, 0, LAZY>(x, first);
+      dif_stage<2, INV, 0, LAZY, FLD>(x, f, first);
     } else {
-      dif_stage<N, INV, 0>(x);
-      Dif<N / 2, INV, LAZY>::run(x, first);
-      Dif<N / 2, INV, LAZY>::run(x + N / 2, false);
+      dif_stage<N, INV, 0, false, FLD>(x, f);
+      Dif<N / 2, INV, LAZY, FLD>::run(x, f, first);
+      Dif<N / 2, INV, LAZY, FLD>::run(x + N / 2, f, false);
     }
   }
 };
-template <bool INV, bool LAZY>
-struct Dif<1, INV, LAZY> {
-  static RONK_HD void run(u64*, bool = true) {}
+template <bool INV, bool LAZY, class FLD>
+struct Dif<1, INV, LAZY, FLD> {
+  static RONK_HD void run(u64*, const FLD&, bool = true) {}
 };
 
 // FEAT_KEEP: after a three-round pass of 2^logr rows, register r of lane m holds output row m + M * keep_row_digit(logr, r)
@@ -366,7 +351,7 @@ RONK_HD TileCtx tile_ctx(const TileArgs& a_in, u32 tid, u32 bid) {
 //   16 no global loads        32 no global stores        64 twiddle values without table loads
 
 // first half: the 16 coefficients of this lane, rows j = i*M + m, straight from HBM (or through the staged image)
-template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class FLD = GlField, class Barrier>
 RONK_HD void tile_load(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barrier&& barrier) {
   constexpr int R = 1 << LOGR;
   constexpr int M = R / 16;                      // threads per column
@@ -378,6 +363,7 @@ RONK_HD void tile_load(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barri
   const u32 in_sj = cx.in_sj, in_lane = cx.in_lane;
   const bool live = cx.live;
   constexpr int SH = NARROW ? 3 : 0;
+  const FLD f(a.fc);
   (void)c; (void)tid; (void)lds;
 
   // ---- round 1: j = j1*M + m, straight from HBM
@@ -438,12 +424,12 @@ RONK_HD void tile_load(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barri
   if (a.in2 && live) {
     const u64* in2 = a.in2 + (i64)b1 * a.in_sb1 + (i64)b2 * a.in_sb2 + (i64)t * a.in_st;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = gl64::mul(x[i], ld_g<NARROW>(in2, joff[i]));
+    for (int i = 0; i < 16; i++) x[i] = f.mul_plain(x[i], ld_g<NARROW>(in2, joff[i]));
   }
 }
 
 // second half: the register rounds, the LDS exchanges between them, the output twiddle and the stores
-template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class FLD = GlField, class Barrier>
 RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barrier&& barrier) {
   constexpr int R = 1 << LOGR;
   constexpr int Q = (LOGR + 3) / 4;              // rounds
@@ -459,6 +445,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
   u64* out = cx.out;
   const u32 out_sk = cx.out_sk, out_lane = cx.out_lane;
   const bool live = cx.live;
+  const FLD f(a.fc);
   (void)C; (void)col0; (void)SH;
 
   // LDS-staged round twiddles: table behind the image; filled now (its loads are in flight together with the tile's),
@@ -478,7 +465,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
   (void)T; (void)stage_valid;
 
   // rounds that are followed by a table twiddle on every output but X[0] take the lazy last stage
-  if (!(ABL & 4)) { if (Q > 1) Dif<16, INV, true>::run(x); else Dif<16, INV>::run(x); }
+  if (!(ABL & 4)) { if (Q > 1) Dif<16, INV, true, FLD>::run(x, f); else Dif<16, INV, false, FLD>::run(x, f); }
 
   if (Q > 1) {
     u64* const lc = lds + c;
@@ -508,7 +495,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
       if (k1 && !(ABL & 2))
-        x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1)
+        x[i] = f.mul(x[i], ((ABL & 64) ? ((u64)(m * k1) * 0x9E3779B97F4A7C15ull >> 1)
                                            : LDSTW ? *reinterpret_cast<const u64*>(twl + tb[k1]) : ld_tabb(a.wr, tb[k1])));
       if (!(ABL & 8)) {
         const u32 cell = p1cell(i);
@@ -552,7 +539,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
       // with kl = (v >> 4) + 16*(v & 15) they were 16 rows apart, with kl = 2m + g a lane wrote the two halves of a
       // 128-byte line at different times: +37 % write traffic in pass 1).  Not in place: read everything, then write.
       if (!(ABL & 8)) barrier();
-      if (!(ABL & 4)) Dif<16, INV, true>::run(x);
+      if (!(ABL & 4)) Dif<16, INV, true, FLD>::run(x, f);
       // omega_{R/16}^{d3*k2} = omega_R^{16*d3*k2}: byte offsets (16*d3*k2)*8 by the same add chain
       tb[1] = d3 << 7;
 #pragma unroll
@@ -564,7 +551,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
         if (k2 && !(ABL & 2))
-          x[i] = gl64::mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1)
+          x[i] = f.mul(x[i], ((ABL & 64) ? ((u64)(tstep * k2) * 0x9E3779B97F4A7C15ull >> 1)
                                              : LDSTW ? *reinterpret_cast<const u64*>(twl + tb[k2]) : ld_tabb(a.wr, tb[k2])));
         if (!(ABL & 8)) {
           const u32 cell = p2cell(i);
@@ -634,7 +621,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
 #pragma unroll
       for (int i = 0; i < GSZ; i++) {
         const u32 ee = ej[brev(i, LOGLAST)];
-        w[i] = gl64::mul(ld_tabb(a.tw_lo, ee & lmask8), ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8));
+        w[i] = f.mul(ld_tabb(a.tw_lo, ee & lmask8), ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8));
       }
     }
   };
@@ -645,7 +632,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
     u64* xg = x + g * GSZ;
     if constexpr ((CFG::FEAT & FEAT_KEEP) != 0) {   // the sub-transform only: results stay in x (keep_row_digit)
       static_assert(!(CFG::FEAT & FEAT_KEEP) || Q == 3, "FEAT_KEEP: three-round passes");
-      if (!(ABL & 4)) Dif<RLAST, INV, false>::run(xg, false);
+      if (!(ABL & 4)) Dif<RLAST, INV, false, FLD>::run(xg, f, false);
       continue;
     }
     u32 kg[GSZ];  // natural output row of each register of the group
@@ -656,14 +643,14 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
       for (int i = 0; i < GSZ; i++) kg[i] = brev(i, 4);
     } else {
       // column passes of known shape multiply EVERY output by the inter-pass twiddle next: lazy last stage throughout
-      if (!(ABL & 4)) Dif<RLAST, INV, (KIND == 1 || KIND == 3) && !(ABL & 1)>::run(xg, false);
+      if (!(ABL & 4)) Dif<RLAST, INV, (KIND == 1 || KIND == 3) && !(ABL & 1), FLD>::run(xg, f, false);
 #pragma unroll
       for (int i = 0; i < GSZ; i++) kg[i] = kl + (R / RLAST) * brev(i, LOGLAST);
     }
     if constexpr (TWPIPE) {
       if (g + 1 < NG) fetch_w(g + 1, wq[(g + 1) & 1]);
 #pragma unroll
-      for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], wq[g & 1][i]);
+      for (int i = 0; i < GSZ; i++) xg[i] = f.mul(xg[i], wq[g & 1][i]);
     } else if ((KIND == 3 || tf) && !(ABL & 1)) {   // KIND 3: the matrix is there by construction (tile_cfg_matches): no second variant in the binary
       if (live) {  // dead columns of a ragged tile hold zeros anyway
         // HALF kernels are built for 64 VGPRs: at most 8 table entries in flight at a time
@@ -678,7 +665,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
             w[i] = ld_g<NARROW>(tf, tbase + ci * tf_sk);
           }
 #pragma unroll
-          for (int i = 0; i < WCH; i++) xg[i0 + i] = gl64::mul(xg[i0 + i], w[i]);
+          for (int i = 0; i < WCH; i++) xg[i0 + i] = f.mul(xg[i0 + i], w[i]);
         }
       }
     } else if (a.tw_log && !(ABL & 1)) {
@@ -707,14 +694,14 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
           wl = ld_tab(a.tw_lo, e & lmask);
           wh = ld_tab(a.tw_hi, e >> a.tw_lo_bits);
         }
-        const u64 w = (ABL & 64) ? gl64::mul((u64)ee * 0x9E3779B97F4A7C15ull >> 1, (u64)(ee >> 3) * 0xC2B2AE3D27D4EB4Full >> 1)
-                                : gl64::mul(wl, wh);
-        xg[i] = gl64::mul(xg[i], w);
+        const u64 w = (ABL & 64) ? f.mul((u64)ee * 0x9E3779B97F4A7C15ull >> 1, (u64)(ee >> 3) * 0xC2B2AE3D27D4EB4Full >> 1)
+                                : f.mul(wl, wh);
+        xg[i] = f.mul(xg[i], w);
       }
     }
     if (a.scale != 1) {
 #pragma unroll
-      for (int i = 0; i < GSZ; i++) xg[i] = gl64::mul(xg[i], a.scale);
+      for (int i = 0; i < GSZ; i++) xg[i] = f.mul(xg[i], a.scale);
     }
     if (a.stage_io && !(ABL & 32)) {
 #pragma unroll
@@ -749,12 +736,12 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
 }
 
 // one tile, start to finish
-template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class Barrier>
+template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class FLD = GlField, class Barrier>
 RONK_HD void tile_body(const TileArgs& a_in, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
   const TileCtx cx = tile_ctx<LOGR, CFG>(a_in, tid, bid);
   u64 x[16];
-  tile_load<LOGR, INV, ABL, CFG>(cx, lds, tid, x, barrier);
-  tile_compute<LOGR, INV, ABL, CFG>(cx, lds, tid, x, barrier);
+  tile_load<LOGR, INV, ABL, CFG, FLD>(cx, lds, tid, x, barrier);
+  tile_compute<LOGR, INV, ABL, CFG, FLD>(cx, lds, tid, x, barrier);
 }
 
 }  // namespace ronk

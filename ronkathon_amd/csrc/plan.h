@@ -41,6 +41,7 @@ struct PassDesc {
 
 struct TwTable {
   int log_n, lo_bits;
+  u64 fold = 1;       // canonical factor folded into every entry of `lo` (the inverse's n^-1)
   std::vector<u64> lo, hi;
 };
 
@@ -56,41 +57,75 @@ struct PlanDesc {
   bool needs_tmp = false;
 };
 
-inline u64 root_of_unity_pow2(int log_n, bool inverse) {
-  // field/mod.rs:70-75 with PRIMITIVE_ELEMENT = 7: w = g^((p-1)/n)
-  u64 w = gl64::pow(gl64::GENERATOR, (gl64::P - 1) >> log_n);
-  return inverse ? gl64::inv(w) : w;
-}
+// The field a plan is built for (host side): Goldilocks with the reference-convention generator 7, or any odd prime
+// p < 2^64 with a caller-supplied primitive element g (PrimeField<P>::PRIMITIVE_ELEMENT, prime/mod.rs:87-90).  Host
+// arithmetic is canonical; `tab()` converts a twiddle to the form the kernels' tables hold (field_policy.h: canonical for
+// Goldilocks, w * 2^64 mod p for Montgomery primes).
+struct HostField {
+  u64 p = gl64::P, g = gl64::GENERATOR;
+  bool mont = false;
+  mont64::Field mf{};
+  static HostField goldilocks() { return HostField(); }
+  static HostField montgomery(u64 p_, u64 g_) {
+    HostField h;
+    h.p = p_; h.g = g_ % p_; h.mont = true; h.mf = mont64::make_field(p_);
+    return h;
+  }
+  u64 mul(u64 a, u64 b) const { return mont ? (u64)(((unsigned __int128)a * b) % p) : gl64::mul(a, b); }
+  u64 pow(u64 a, u64 e) const {
+    u64 r = 1 % p;
+    while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; }
+    return r;
+  }
+  u64 inv(u64 a) const { return pow(a, p - 2); }
+  u64 tab(u64 w) const { return mont ? (u64)((((unsigned __int128)w) << 64) % p) : w; }
+  // field/mod.rs:70-75: w = g^((p-1)/n), n = 2^log_n (the caller has checked n | p - 1)
+  u64 root_pow2(int log_n, bool inverse) const {
+    const u64 w = pow(g, (p - 1) >> log_n);
+    return inverse ? inv(w) : w;
+  }
+  // what the kernels need besides the tables (TileArgs::fc); p == 0 there means Goldilocks
+  FieldConst consts(bool inverse) const {
+    FieldConst c{};
+    if (!mont) return c;
+    c.p = p; c.pinv = mf.pinv; c.r2 = mf.r2;
+    const u64 w16 = root_pow2(4, inverse);
+    u64 x = 1;
+    for (int j = 0; j < 8; j++) { c.w16[j] = tab(x); x = mul(x, w16); }
+    return c;
+  }
+};
 
-inline std::vector<u64> power_table(u64 w, size_t count) {
+inline std::vector<u64> power_table(const HostField& hf, u64 w, size_t count, u64 first = 1) {
   std::vector<u64> t(count);
-  u64 x = 1;
-  for (size_t i = 0; i < count; i++) { t[i] = x; x = gl64::mul(x, w); }
+  u64 x = first;
+  for (size_t i = 0; i < count; i++) { t[i] = hf.tab(x); x = hf.mul(x, w); }
   return t;
 }
 
 struct PlanBuilder {
   PlanDesc d;
+  HostField hf;
 
   int wr_table(int logr) {
     for (size_t i = 0; i < d.wr_logr.size(); i++)
       if (d.wr_logr[i] == logr) return (int)i;
     d.wr_logr.push_back(logr);
-    d.wr.push_back(power_table(root_of_unity_pow2(logr, d.inverse), (size_t)1 << logr));
+    d.wr.push_back(power_table(hf, hf.root_pow2(logr, d.inverse), (size_t)1 << logr));
     return (int)d.wr.size() - 1;
   }
   // `fold` != 1 pre-multiplies the low-level table: every coefficient receives exactly one inter-pass twiddle,
   // so the inverse transform's n^-1 (F::from(D).inverse(), polynomial/mod.rs:442) rides along for free.
   int tw_table(int log_n, u64 fold = 1) {
     for (size_t i = 0; i < d.tw.size(); i++)
-      if (d.tw[i].log_n == log_n && fold == 1 && d.tw[i].lo[0] == 1) return (int)i;
+      if (d.tw[i].log_n == log_n && d.tw[i].fold == fold) return (int)i;
     TwTable t;
     t.log_n = log_n;
     t.lo_bits = (log_n + 1) / 2;
-    u64 w = root_of_unity_pow2(log_n, d.inverse);
-    t.lo = power_table(w, (size_t)1 << t.lo_bits);
-    if (fold != 1) for (auto& v : t.lo) v = gl64::mul(v, fold);
-    t.hi = power_table(gl64::pow(w, (u64)1 << t.lo_bits), (size_t)1 << (log_n - t.lo_bits));
+    t.fold = fold;
+    u64 w = hf.root_pow2(log_n, d.inverse);
+    t.lo = power_table(hf, w, (size_t)1 << t.lo_bits, fold);   // fold * w^i
+    t.hi = power_table(hf, hf.pow(w, (u64)1 << t.lo_bits), (size_t)1 << (log_n - t.lo_bits));
     d.tw.push_back(t);
     return (int)d.tw.size() - 1;
   }
@@ -129,6 +164,7 @@ struct PlanBuilder {
     p.args.scale = 1;
     p.args.in_valid = p.args.out_valid = p.args.in_valid1 = ~(u64)0;
     p.args.stage_io = 0;
+    p.args.fc = hf.consts(d.inverse);
     p.wr_id = wr_table(logr);
     p.args.wr = nullptr;
     p.tw_id = -1;
@@ -154,6 +190,15 @@ struct PlanBuilder {
     p.small = true;
   }
   int twf_max_log = 0;  // build the full twiddle matrix of a pass when it has at most 2^twf_max_log entries
+  // TileArgs::scale in table form; 1 stays the "no scale" sentinel.  (Montgomery: should s * 2^64 mod p come out as 1 for a real
+  // scale s != 1, the representative p + 1 is used -- the product accepts it, p <= 2^64 - 59, and it is not the sentinel.)
+  u64 tab_scale(u64 s) const {
+    if (s == 1) return 1;
+    const u64 t = hf.tab(s);
+    return (hf.mont && t == 1) ? hf.p + 1 : t;
+  }
+  // product of two TABLE-form entries, in table form (Montgomery: (aR)(bR)/R = abR -- what the kernel's mul computes)
+  u64 tab_mul(u64 a, u64 b) const { return hf.mont ? mont64::mmul(hf.mf, a, b) : gl64::mul(a, b); }
 
   // Full matrix of the pass's output twiddle, T[k*tf_sk + col*tf_sc + b2*tf_sb2] = omega_N^{X*Y}, strides chosen
   // like the pass's own output so the load is the same coalesced tile pattern.  Only the indices the
@@ -176,7 +221,7 @@ struct PlanBuilder {
         for (u64 c = 0; c < nc; c++) {
           const u64 X = a.xc * c + a.xb2 * b2 + a.x0, Y = a.yk * k + a.yb2 * b2 + a.y0;
           const u64 e = (X * Y) & nmask;
-          T[k * sk + b2 * sb2 + c * sc] = gl64::mul(t.lo[e & lmask], t.hi[e >> t.lo_bits]);
+          T[k * sk + b2 * sb2 + c * sc] = tab_mul(t.lo[e & lmask], t.hi[e >> t.lo_bits]);
         }
     d.twf.push_back(std::move(T));
     p.twf_id = (int)d.twf.size() - 1;
@@ -197,20 +242,22 @@ struct PlanBuilder {
 // split_ka: rows (log2) of the first pass of a two-pass plan, 0 = the planner's choice (balanced; the fused multiply asks for the
 // other split of an odd log2n so that its inverse's column pass has the rows of the forward row pass, ntt_mul.h).
 inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0,
-                           int three_pass_from = 25, bool auto_tiles = false, int split_ka = 0) {
+                           int three_pass_from = 25, bool auto_tiles = false, int split_ka = 0,
+                           const HostField& hf = HostField()) {
   PlanBuilder b;
+  b.hf = hf;
   b.twf_max_log = twf_max_log;
   if (const char* e = getenv("RONK_WG_FLOOR_LOG")) { int v = atoi(e); if (v >= 10 && v <= 14) b.multi_pass_floor_log = v; }
   b.d.log2n = log2n; b.d.batch = batch; b.d.inverse = inverse;
   const u64 n = (u64)1 << log2n;
-  const u64 scale = inverse ? gl64::inv(n % gl64::P) : 1;  // F::from(D).inverse(), mod.rs:442
+  const u64 scale = inverse ? hf.inv(n % hf.p) : 1;  // F::from(D).inverse(), mod.rs:442
   if (log2n <= 12) {
     // the batch is the column axis: column c = polynomial c, rows contiguous.  Neighbouring columns are n elements
     // apart, so narrow tiles (down to one wave) keep each wave on long contiguous runs of every polynomial.
     PassDesc& p = b.add_pass(log2n, batch, max_logc, 10);
     p.args.in_sj = 1; p.args.in_sc = (i64)n;
     p.args.out_sk = 1; p.args.out_sc = (i64)n;
-    p.args.scale = scale;
+    p.args.scale = b.tab_scale(scale);
     if (log2n <= 5) {   // n = 16, 32: HBM <-> LDS copies of the contiguous tile (TileArgs::stage_io); n = 16: 112 -> 58 us per
                         // 2^24 coefficients, n = 32: 0.428 -> 0.338 ms per 2^26; n = 64 is better without (0.301 vs 0.346 ms)
       p.args.stage_io = 1;
@@ -387,15 +434,16 @@ inline bool dist_chunks_ok(const DistShape& sh, int chunks) {
 }
 
 inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0,
-                                  int chunk = 0, int chunks = 1) {
+                                  int chunk = 0, int chunks = 1, const HostField& hf = HostField()) {
   DistShape sh;
   PlanBuilder b;
+  b.hf = hf;
   b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.inverse = inverse;
   if (!dist_shape(log2n, world, &sh) || !dist_chunks_ok(sh, chunks) || chunk < 0 || chunk >= chunks) return b.d;
   const u64 Cw = sh.Cw, Cwc = Cw / (u64)chunks;       // input row stride / columns of this chunk = output row stride
   const u64 g0 = (u64)rank * Cw + (u64)chunk * Cwc;   // global index of the chunk's first column
-  const u64 scale = inverse ? gl64::inv(sh.n % gl64::P) : 1;   // folded into the global twiddle of phase 1
+  const u64 scale = inverse ? hf.inv(sh.n % hf.p) : 1;   // folded into the global twiddle of phase 1
   // the launcher adds chunk*Cwc to the input pointer and chunk*R*Cwc to the output pointer (ronk_dist.hip)
   if (sh.logR <= 12) {
     PassDesc& p = b.add_pass(sh.logR, Cwc, max_logc);
@@ -434,10 +482,11 @@ inline PlanDesc build_dist_phase1(int log2n, bool inverse, int rank, int world, 
 }
 
 inline PlanDesc build_dist_phase2(int log2n, bool inverse, int rank, int world, int max_logc = 4, int twf_max_log = 0,
-                                  int chunks = 1) {
+                                  int chunks = 1, const HostField& hf = HostField()) {
   (void)rank;
   DistShape sh;
   PlanBuilder b;
+  b.hf = hf;
   b.twf_max_log = twf_max_log;
   b.d.log2n = log2n; b.d.inverse = inverse;
   if (!dist_shape(log2n, world, &sh) || !dist_chunks_ok(sh, chunks)) return b.d;

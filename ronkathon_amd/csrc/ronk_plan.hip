@@ -37,7 +37,15 @@ extern "C" int ronk_plan_create(ronk_plan** out, uint64_t p, uint64_t g, uint32_
   return ronk_plan_create_tuned(out, p, g, log2n, batch, device, -1, -1);
 }
 
-extern "C" int ronk_plan_path(const ronk_plan* pl) { return pl ? (pl->fast ? 1 : 0) : RONK_ERR_INVALID; }
+extern "C" int ronk_plan_path(const ronk_plan* pl) { return pl ? (pl->fast ? (pl->mont_tiled ? 2 : 1) : 0) : RONK_ERR_INVALID; }
+
+// would a plan for n = 2^k over (p, g) run the tile kernels?  (the rule of ronk_plan_create_opts, without building anything)
+static bool tiled_plan_exists(u64 p, u64 g, int k) {
+  if (k < 4 || k > 30 || p < 3 || !(p & 1) || (p - 1) % ((u64)1 << k) != 0) return false;
+  if (p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G) return true;
+  static const bool no_mont_tiles = getenv("RONK_NO_MONT_TILES") != nullptr;
+  return !no_mont_tiles && h_powmod(g % p, (p - 1) / 2, p) == p - 1;
+}
 
 extern "C" int ronk_plan_create_tuned(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                                       int tile_log2_columns, int twiddle_matrix_log2_max) {
@@ -71,10 +79,19 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
   pl->p = p; pl->g = g % p; pl->log2n = log2n; pl->n = n; pl->batch = batch; pl->device = device;
   int rc = make_field(p, &pl->field);
   if (rc) { delete pl; return rc; }
-  // tile path: Goldilocks with the reference generator, 16 <= n <= 2^30 (32-bit lane offsets inside a tile,
-  // grids below 2^31 workgroups); anything else takes the generic radix-2 path
-  pl->fast = (p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G && log2n >= 4 && log2n <= 30 &&
-              batch < ((u64)1 << 31) && (double)batch * (double)n / 2048.0 < 2.0e9);
+  // tile path: 16 <= n <= 2^30 (32-bit lane offsets inside a tile, grids below 2^31 workgroups), over
+  //   Goldilocks with the reference generator 7 -- the shift-twiddle kernels (gl64.h), or
+  //   any other odd prime (and Goldilocks with another generator) whose g is a quadratic non-residue, i.e. omega_n =
+  //   g^((p-1)/n) has order exactly n for every power of two n | p - 1 -- the same kernels over Montgomery arithmetic
+  //   (field_policy.h MontField, tile_kernels_mont.hip).  RONK_NO_MONT_TILES=1: the pre-round-5 behaviour (A/B).
+  // Anything else (a g that generates no full 2-power subgroup: the reference's recursion is then NOT the DFT and the
+  // radix-2 path restates it stage by stage; n < 16; n > 2^30) takes the generic radix-2 path.
+  const bool size_ok = log2n >= 4 && log2n <= 30 && batch < ((u64)1 << 31) && (double)batch * (double)n / 2048.0 < 2.0e9;
+  const bool gl_tiled = p == RONK_GOLDILOCKS_P && pl->g == RONK_GOLDILOCKS_G;
+  static const bool no_mont_tiles = getenv("RONK_NO_MONT_TILES") != nullptr;
+  pl->mont_tiled = !gl_tiled && !no_mont_tiles && size_ok && (p & 1) && p > 2 && h_powmod(pl->g, (p - 1) / 2, p) == p - 1;
+  pl->fast = size_ok && (gl_tiled || pl->mont_tiled);
+  const HostField hf = pl->mont_tiled ? HostField::montgomery(p, pl->g) : HostField::goldilocks();
   // generic radix-2 path: 32-bit bit reversal and element indices (field_kernels.h bitrev32)
   if (!pl->fast && log2n > 32) { delete pl; return RONK_ERR_UNSUPPORTED; }
   if (pl->fast) {
@@ -120,8 +137,8 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // generic first pass, 110 with the (12, 2, 1) shape); batches of 2^23 keep three passes (measured in round 2).
     int three_from = (log2n == 23 && batch == 1) ? 24 : 23;
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
-    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles, split_ka));
-    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka));
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
     for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
       if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
   } else {
@@ -657,7 +674,8 @@ extern "C" int ronk_dft_dev(uint64_t p, uint64_t g, const uint64_t* d_in, uint64
   RCHK(need_device());
   hipStream_t s = (hipStream_t)st;
   const bool gl = p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G;
-  if (is_pow2(n) && gl && n >= 16 && n <= ((size_t)1 << 30)) {
+  // (a tiled plan implies omega_n of order exactly n, so Polynomial::fft == Polynomial::dft there)
+  if (is_pow2(n) && n >= 16 && n <= ((size_t)1 << 30) && ronk_check_prime(p) == RONK_OK && tiled_plan_exists(p, g, ilog2(n))) {
     CacheEntry* e = nullptr;
     std::lock_guard<std::mutex> lk(g_cache_mu);
     RCHK(cache_get(p, g, (u32)ilog2(n), &e));
@@ -683,7 +701,7 @@ extern "C" int ronk_dft(uint64_t p, uint64_t g, const uint64_t* in, uint64_t* ou
   u64 w;
   RCHK(ronk_root_of_unity(p, g % p, n, &w));
   RCHK(need_device());
-  if (is_pow2(n) && p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 16)
+  if (is_pow2(n) && n >= 16 && n <= ((size_t)1 << 30) && ronk_check_prime(p) == RONK_OK && tiled_plan_exists(p, g, ilog2(n)))
     return fft_oneshot(false, p, g, in, out, nullptr, n);
   const bool chirp = p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && n >= 512 && n <= ((size_t)1 << 29);
   if (!chirp && n > ((size_t)1 << 16)) return RONK_ERR_UNSUPPORTED;
@@ -714,7 +732,12 @@ extern "C" int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, si
   const size_t m = d + d2 - 1;
   FieldCtx f;
   RCHK(make_field(p, &f));
-  const bool fast = (p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G && m > 64);
+  // the NTT path: Goldilocks, or any prime that has a tiled plan of the product's size (N | p - 1, g a non-residue) --
+  // the product does not depend on g, only the transform's existence does
+  int k = ilog2(m);
+  if (k < 4) k = 4;
+  const bool fast = m > 64 && ((p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G) ||
+                               (ronk_check_prime(p) == RONK_OK && tiled_plan_exists(p, g, k)));
   if (!fast) {
     if ((double)d * (double)d2 > 1.2e12) return RONK_ERR_UNSUPPORTED;
     FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_mul_schoolbook_kernel<decltype(ops)>), dim3(grid_for(m)), dim3(256), 0, s,
@@ -722,8 +745,6 @@ extern "C" int ronk_poly_mul_dev(uint64_t p, uint64_t g, const uint64_t* d_a, si
     HIPCHK(hipGetLastError());
     return RONK_OK;
   }
-  int k = ilog2(m);
-  if (k < 4) k = 4;
   return conv_dev(p, g, k, d_a, d, d_b, d2, d_out, m, s);
 }
 // cyclic convolution of size N = 2^k of a (d entries) and b (d2 entries), the first out_len entries stored
@@ -764,7 +785,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     // Measured (round 4, same box, us per product): 2^22 158.6 -> 132.6, 2^21 88.0 -> 80.6, but 2^20 63.1 -> 68.1 -- there a
     // pass has 256 tiles of four wavefronts, one wavefront per SIMD, and three transforms in sequence inside a workgroup are
     // three times one wavefront's dependent instruction stream; the four-launch form spreads them over twice the tiles.
-    if (fused_on && (k == 21 || k == 22)) {
+    if (fused_on && (k == 21 || k == 22) && !pl->mont_tiled) {   // (the fused middle is instantiated for Goldilocks)
       if (!e->plf) {
         // the inverse whose COLUMN pass has the rows of the pair plan's ROW pass: the balanced split for even k, the other
         // split of an odd one (2^21: pair plan 2^11 x 2^10, inverse 2^10 x 2^11)

@@ -225,7 +225,8 @@ struct ronk_plan {
   u64 n, batch;
   int device;
   FieldCtx field;
-  bool fast;                // Goldilocks tile path
+  bool fast;                // tile path (Goldilocks shift-twiddle kernels, or ...
+  bool mont_tiled = false;  // ... the same kernels over Montgomery arithmetic: any other prime with a full 2-power subgroup under g)
   CompiledPlan fwd, inv;    // fast path
   u64* d_tmp = nullptr;     // scratch [batch][n]
   u64* d_stage_in = nullptr;   // staging for the host-pointer API (lazy)

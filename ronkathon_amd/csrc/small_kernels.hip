@@ -4,6 +4,7 @@
 
 #include "ntt_small.h"
 #include "tile_launch.h"
+#include "tile_kernel_def.h"
 
 namespace ronk {
 
@@ -26,6 +27,7 @@ static hipError_t launch_small_dir(int logr, const TileArgs& a, u32 grid, u32 bl
 
 hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s) {
   if (block > 256 || lds > 48 * 1024) return hipErrorInvalidValue;   // make_small (plan.h): 256 work-items, <= 10 KiB
+  if (a.fc.p) return launch_small_mont(logr, inverse, a, grid, block, lds, s);
   return inverse ? launch_small_dir<true>(logr, a, grid, block, lds, s) : launch_small_dir<false>(logr, a, grid, block, lds, s);
 }
 

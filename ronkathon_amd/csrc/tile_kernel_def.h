@@ -10,7 +10,7 @@ namespace ronk {
 
 // Workgroup = 2^LOGR * C / 16 work-items (<= 1024), dynamic LDS = (2^LOGR + 2^LOGR/16) * C * 8 bytes (<= 136 KiB of the
 // CU's 160 KiB).
-template <int LOGR, bool INV, int LOGC, int KIND, bool HALF, int FEAT = 0>
+template <int LOGR, bool INV, int LOGC, int KIND, bool HALF, int FEAT = 0, class FLD = GlField>
 __device__ __forceinline__ void tile_kernel_main(const TileArgs& a, u64* lds) {
   // The dispatcher hands workgroup b to XCD b % 8 (observed, for speed only): renumber so that
   // each XCD works on a contiguous run of tiles -- neighbouring tiles share 128-byte lines and
@@ -18,7 +18,7 @@ __device__ __forceinline__ void tile_kernel_main(const TileArgs& a, u64* lds) {
   const u32 nb = gridDim.x, b = blockIdx.x;
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND, !HALF && !FEAT && cfg_ldstw(LOGR, LOGC, KIND), HALF, FEAT>>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
+  tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND, !HALF && !FEAT && !FLD::MONT && cfg_ldstw(LOGR, LOGC, KIND), HALF, FEAT>, FLD>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
 }
 
 // the shapes with features (tile_cfg_table.h RONK_CFG_TABLE_FEAT; tile_kernels_feat.hip)
@@ -87,6 +87,10 @@ static hipError_t launch_one(const TileArgs& a, u32 grid, u32 block, size_t lds,
   return hipGetLastError();
 }
 
+// tile_kernels_mont.hip: the same bodies over a Montgomery prime (field_policy.h MontField; TileArgs::fc.p != 0) -- the generic
+// kernel for every pass size and the specialised shapes of RONK_CFG_TABLE; launch_small_mont: the latency form
+hipError_t launch_tile_mont(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s);
+hipError_t launch_small_mont(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s);
 // tile_kernels_cfg.hip: launches the specialised instantiation for (logr, a.logc, kind) if there is one; *found says so
 hipError_t launch_tile_cfg(int logr, bool inverse, int kind, const TileArgs& a, u32 grid, u32 block, size_t lds,
                            hipStream_t s, bool* found);

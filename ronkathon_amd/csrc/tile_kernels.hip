@@ -43,6 +43,7 @@ static bool use_half(const TileArgs& a, int logr, u32 grid, u32 block, int kind)
 
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds,
                        hipStream_t s) {
+  if (a.fc.p) return launch_tile_mont(logr, inverse, a, grid, block, lds, s);   // a Montgomery prime (field_policy.h)
   static const bool no_cfg = getenv("RONK_NO_CFG_KERNELS") != nullptr;   // experiments: force the generic kernels
   if (!no_cfg) {
     const int feat = tile_features(a);

@@ -36,16 +36,35 @@ static FiberArgs g_fa;
 
 static void fiber_barrier() { swapcontext(&g_ctx[g_cur], &g_sched); }
 
-template <int LOGR, bool INV>
-static void run_body(u32 tid) { tile_body<LOGR, INV, 0>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); }
+// RONK_EMU_P / RONK_EMU_G: run the Montgomery instantiations (field_policy.h MontField) for this odd prime and primitive
+// element instead of the Goldilocks ones -- the same plan builder, tables in Montgomery form, the oracle called with (p, g)
+static u64 g_p = gl64::P, g_g = gl64::GENERATOR;
+static bool g_mont = false;
+static HostField g_hf;
+static u64 rnd_elem(u64& s);
+
+template <int LOGR, bool INV, class FLD>
+static void run_body(u32 tid) { tile_body<LOGR, INV, 0, TileCfg<-1, 0>, FLD>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); }
 
 // the compile-time-specialised instantiations the library launches for recognised pass shapes (tile_kernels.hip):
 // same selection rule, same table
 static int g_cfg_used = 0;
-template <bool INV>
+template <bool INV, class FLD>
 static bool dispatch_cfg(int logr, u32 tid) {
   const TileArgs& a = *g_fa.a;
   static const bool half = getenv("RONK_HALF_LDS") && atoi(getenv("RONK_HALF_LDS")) == 1;   // TileCfg::HALF instantiations
+  if constexpr (FLD::MONT) {   // the shapes the library instantiates for Montgomery primes (tile_kernels_mont.hip): the plain table
+    if (tile_features(a)) return false;
+#define EMU_MONT_CASE(LR, LC, KD)                                                                \
+  if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
+    tile_body<LR, INV, 0, TileCfg<LC, KD>, FLD>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier);      \
+    g_cfg_used = KD;                                                                             \
+    return true;                                                                                 \
+  }
+    RONK_CFG_TABLE(EMU_MONT_CASE)
+#undef EMU_MONT_CASE
+    return false;
+  } else {
   if (half) {
 #define EMU_HALF_CASE(LR, LC, KD)                                                                \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
@@ -78,38 +97,40 @@ static bool dispatch_cfg(int logr, u32 tid) {
   RONK_CFG_TABLE_DIST(EMU_CFG_CASE)
 #undef EMU_CFG_CASE
   return false;
+  }
 }
 
-template <bool INV>
+template <bool INV, class FLD>
 static void dispatch_small(int logr, u32 tid) {
   switch (logr) {
-#define EMU_SMALL_CASE(LR) case LR: small_body<LR, INV>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); break;
+#define EMU_SMALL_CASE(LR) case LR: small_body<LR, INV, FLD>(*g_fa.a, g_fa.lds, tid, g_fa.bid, fiber_barrier); break;
     EMU_SMALL_CASE(4) EMU_SMALL_CASE(5) EMU_SMALL_CASE(6) EMU_SMALL_CASE(7) EMU_SMALL_CASE(8) EMU_SMALL_CASE(9) EMU_SMALL_CASE(10)
 #undef EMU_SMALL_CASE
     default: abort();
   }
 }
 
-template <bool INV>
+template <bool INV, class FLD>
 static void dispatch(int logr, u32 tid) {
-  if (g_fa.small) { dispatch_small<INV>(logr, tid); return; }
-  if (!getenv("RONK_NO_CFG_KERNELS") && dispatch_cfg<INV>(logr, tid)) return;
+  if (g_fa.small) { dispatch_small<INV, FLD>(logr, tid); return; }
+  if (!getenv("RONK_NO_CFG_KERNELS") && dispatch_cfg<INV, FLD>(logr, tid)) return;
   switch (logr) {
-    case 4: run_body<4, INV>(tid); break;
-    case 5: run_body<5, INV>(tid); break;
-    case 6: run_body<6, INV>(tid); break;
-    case 7: run_body<7, INV>(tid); break;
-    case 8: run_body<8, INV>(tid); break;
-    case 9: run_body<9, INV>(tid); break;
-    case 10: run_body<10, INV>(tid); break;
-    case 11: run_body<11, INV>(tid); break;
-    case 12: run_body<12, INV>(tid); break;
+    case 4: run_body<4, INV, FLD>(tid); break;
+    case 5: run_body<5, INV, FLD>(tid); break;
+    case 6: run_body<6, INV, FLD>(tid); break;
+    case 7: run_body<7, INV, FLD>(tid); break;
+    case 8: run_body<8, INV, FLD>(tid); break;
+    case 9: run_body<9, INV, FLD>(tid); break;
+    case 10: run_body<10, INV, FLD>(tid); break;
+    case 11: run_body<11, INV, FLD>(tid); break;
+    case 12: run_body<12, INV, FLD>(tid); break;
     default: abort();
   }
 }
 
 static void fiber_main(int tid) {
-  if (g_fa.inv) dispatch<true>(g_fa.logr, (u32)tid); else dispatch<false>(g_fa.logr, (u32)tid);
+  if (g_mont) { if (g_fa.inv) dispatch<true, MontField>(g_fa.logr, (u32)tid); else dispatch<false, MontField>(g_fa.logr, (u32)tid); }
+  else if (g_fa.inv) dispatch<true, GlField>(g_fa.logr, (u32)tid); else dispatch<false, GlField>(g_fa.logr, (u32)tid);
   g_done[tid] = 1;
   swapcontext(&g_ctx[tid], &g_sched);
 }
@@ -145,6 +166,11 @@ static u64 splitmix(u64& s) {
   return z ^ (z >> 31);
 }
 
+static u64 rnd_elem(u64& s) {   // uniform by rejection for primes near 2^64, by remainder for small ones
+  if (g_p < ((u64)1 << 63)) return splitmix(s) % g_p;
+  u64 v; do v = splitmix(s); while (v >= g_p); return v;
+}
+
 static int g_dist_cfg = 0, g_dist_generic = 0;   // passes of the dist mode that ran a specialised / the generic body
 static void run_plan(const PlanDesc& pd, bool inv, const u64* in, u64* out, u64* tmp) {
   std::vector<u64> lds;
@@ -176,14 +202,14 @@ static int dist_main(int log2n, int world, bool inv, int chunks) {
   const u64 n = sh.n, per = n / sh.W, Cwc = sh.Cw / (u64)chunks;
   std::vector<u64> x(n), ref(n), got(n);
   u64 s = 0x5EED0005ull + log2n;
-  for (auto& v : x) { do v = splitmix(s); while (v >= gl64::P); }
+  for (auto& v : x) v = rnd_elem(s);
   std::vector<std::vector<u64>> loc(world), snd(world), rcv(world), res(world), tmp(world);
   for (int g = 0; g < world; g++) {
     loc[g].resize(per); snd[g].assign(per, 1); rcv[g].resize(per); res[g].assign(per, 2); tmp[g].assign(per, 3);
     for (u64 r = 0; r < sh.R; r++)
       for (u64 cl = 0; cl < sh.Cw; cl++) loc[g][r * sh.Cw + cl] = x[r * sh.C + g * sh.Cw + cl];
     for (int j = 0; j < chunks; j++) {
-      PlanDesc p1 = build_dist_phase1(log2n, inv, g, world, 4, g_twf, j, chunks);
+      PlanDesc p1 = build_dist_phase1(log2n, inv, g, world, 4, g_twf, j, chunks, g_hf);
       if (p1.passes.empty()) { printf("no phase-1 plan\n"); return 2; }
       run_plan(p1, inv, loc[g].data() + (u64)j * Cwc, snd[g].data() + (u64)j * sh.R * Cwc, tmp[g].data());
     }
@@ -194,13 +220,13 @@ static int dist_main(int log2n, int world, bool inv, int chunks) {
       for (int h = 0; h < world; h++)
         memcpy(&rcv[h][((u64)g * chunks + j) * blk], &snd[g][(u64)j * sh.R * Cwc + (u64)h * blk], blk * 8);
   for (int h = 0; h < world; h++) {
-    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world, 4, g_twf, chunks);
+    PlanDesc p2 = build_dist_phase2(log2n, inv, h, world, 4, g_twf, chunks, g_hf);
     if (p2.passes.empty()) { printf("no phase-2 plan\n"); return 2; }
     run_plan(p2, inv, rcv[h].data(), res[h].data(), tmp[h].data());
     for (u64 k2 = 0; k2 < sh.C; k2++)
       for (u64 k1l = 0; k1l < sh.Rw; k1l++) got[(h * sh.Rw + k1l) + sh.R * k2] = res[h][k2 * sh.Rw + k1l];
   }
-  int rc = inv ? orc_ifft(gl64::P, 7, x.data(), ref.data(), n) : orc_fft(gl64::P, 7, x.data(), ref.data(), n);
+  int rc = inv ? orc_ifft(g_p, g_g, x.data(), ref.data(), n) : orc_fft(g_p, g_g, x.data(), ref.data(), n);
   if (rc) return 1;
   for (u64 i = 0; i < n; i++)
     if (got[i] != ref[i]) { printf("DIST MISMATCH at %llu\n", (unsigned long long)i); return 1; }
@@ -312,6 +338,13 @@ static int mul_main(int log2n, u64 d, u64 d2, int logc, int inv_twf) {
 }
 
 int main(int argc, char** argv) {
+  if (const char* e = getenv("RONK_EMU_P")) {
+    g_p = strtoull(e, 0, 0);
+    g_g = getenv("RONK_EMU_G") ? strtoull(getenv("RONK_EMU_G"), 0, 0) : 0;
+    if (!g_g && orc_find_primitive_element(g_p, &g_g)) { printf("no generator\n"); return 2; }
+    g_mont = true;
+    g_hf = HostField::montgomery(g_p, g_g);
+  }
   if (argc >= 6 && !strcmp(argv[1], "mul"))   // emu_tile mul <log2n> <d> <d2> <logc> [inverse twf_max_log]
     return mul_main(atoi(argv[2]), strtoull(argv[3], 0, 10), strtoull(argv[4], 0, 10), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 18);
   if (argc >= 6 && !strcmp(argv[1], "dist")) g_twf = atoi(argv[5]);
@@ -329,19 +362,19 @@ int main(int argc, char** argv) {
   bool auto_tiles = argc > 9 && atoi(argv[9]) != 0;   // the planner's own per-pass tile rules (ronk_plan_create's default)
   u64 in_valid1 = argc > 10 ? strtoull(argv[10], 0, 10) : 0;   // TileArgs::in_valid1: the limit of batch entries >= 1 (paired multiply operands)
   const bool with_in2 = argc > 11 && atoi(argv[11]) != 0;      // TileArgs::in2: a second operand multiplied in on load (fused pointwise product)
-  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles);
+  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles, 0, g_hf);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
   u64 s = 0x5EED0000ull + log2n;
-  for (auto& v : in) { do v = splitmix(s); while (v >= gl64::P); }
+  for (auto& v : in) v = rnd_elem(s);
   // adversarial corners
-  in[0] = gl64::P - 1; if (n > 1) in[n - 1] = gl64::P - 1; if (n > 2) in[1] = 0;
+  in[0] = g_p - 1; if (n > 1) in[n - 1] = g_p - 1; if (n > 2) in[1] = 0;
 
   std::vector<u64> in2;
   if (with_in2) {
     in2.resize(n * batch);
-    for (auto& v : in2) { do v = splitmix(s); while (v >= gl64::P); }
-    in2[0] = gl64::P - 1; in2[n - 1] = 0;
+    for (auto& v : in2) v = rnd_elem(s);
+    in2[0] = g_p - 1; in2[n - 1] = 0;
   }
   std::vector<u64> lds;
   for (auto& p : pd.passes) {
@@ -370,9 +403,9 @@ int main(int argc, char** argv) {
            p.small ? "small" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = (b && in_valid1) ? in_valid1 : in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen
-  if (with_in2) for (u64 i = 0; i < n * batch; i++) in[i] = gl64::mul(in[i], in2[i]);
+  if (with_in2) for (u64 i = 0; i < n * batch; i++) in[i] = orc_mul(g_p, in[i], in2[i]);
   for (u64 b = 0; b < batch; b++) {
-    int rc = inv ? orc_ifft(gl64::P, 7, &in[b * n], &ref[b * n], n) : orc_fft(gl64::P, 7, &in[b * n], &ref[b * n], n);
+    int rc = inv ? orc_ifft(g_p, g_g, &in[b * n], &ref[b * n], n) : orc_fft(g_p, g_g, &in[b * n], &ref[b * n], n);
     if (rc) { printf("oracle rc %d\n", rc); return 1; }
   }
   for (u64 i = 0; i < n * batch; i++)
