@@ -306,6 +306,12 @@ def main():
                        "mesh": "--workload sharded (the one-process in-library form)"}[want]))
         res = rdist.bench_fourstep(args.log2n or 26, args.steps, args.warmup, chunks=args.chunks or None)
         res["config"]["exchange"] = want
+        # what the all-to-all rides on: can this rank's GPU reach the others peer-to-peer (xGMI)?  RCCL falls back to host
+        # staging where it cannot; reported so that a slow exchange is never mistaken for a result
+        nd_ = torch.cuda.device_count()
+        me_ = torch.cuda.current_device()
+        res["config"]["peer_access"] = {"device": me_, "visible_devices": nd_,
+                                        "can_access": [bool(torch.cuda.can_device_access_peer(me_, d_)) for d_ in range(nd_) if d_ != me_]}
         one_ = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(one_)
@@ -488,7 +494,12 @@ def main():
                           "config": {"workload": "four-step NTT n = 2^%d over %d rank(s) on %d GPU(s), %s, "
                                                  "%d column chunk(s)" % (lg, W, ndev, "ncclGroup Send/Recv (dlopen'ed RCCL)" if ex == L.EXCHANGE_RCCL
                                                                          else "hipMemcpyPeerAsync mesh", sp.chunks),
-                                     "ranks": W, "chunks": sp.chunks, "exchange": "rccl" if ex == L.EXCHANGE_RCCL else "mesh"},
+                                     "ranks": W, "chunks": sp.chunks, "exchange": "rccl" if ex == L.EXCHANGE_RCCL else "mesh",
+                                     # how blocks travel between ranks (ronk_sharded_plan_peer_access): a staged pair means the
+                                     # runtime refused peer access and copies go through host memory -- the number below would
+                                     # then measure THAT, not xGMI
+                                     "peer_access": dict(zip(("matrix", "staged_pairs"), sp.peer_access())),
+                                     "ranks_per_gpu": W / float(ndev)},
                           "roofline": {"bound": "hbm", "achieved": 16.0 * nn / ndev / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": 16.0 * nn / ndev / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None}}))
         sp.close()

@@ -322,6 +322,17 @@ int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n, int invers
 int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev, int chunks,
                                 int exchange);
 int ronk_sharded_plan_exchange(const ronk_sharded_plan* plan);
+/* How a block travels between the ranks of a mesh-exchange plan, decided at plan creation and kept (never silent):
+ * matrix[g * ndev + h] = RONK_PEER_SAME_DEVICE (ranks g and h share a GPU), RONK_PEER_DIRECT (hipDeviceCanAccessPeer said yes and
+ * peer access is enabled: xGMI / PCIe peer-to-peer) or RONK_PEER_STAGED (refused: hipMemcpyPeerAsync stages through host
+ * memory -- correct, roughly an order of magnitude slower).  `matrix` may be NULL; capacity >= ndev * ndev otherwise.
+ * Returns the number of STAGED pairs (0 on a healthy xGMI node), or a negative error.  RONK_REQUIRE_PEER=1 in the environment
+ * makes ronk_sharded_plan_create(_ex) fail with RONK_ERR_UNSUPPORTED instead of accepting a staged pair.
+ * (The reference has no counterpart: it is single-threaded CPU code) */
+#define RONK_PEER_SAME_DEVICE 0
+#define RONK_PEER_DIRECT 1
+#define RONK_PEER_STAGED 2
+int ronk_sharded_plan_peer_access(const ronk_sharded_plan* plan, int* matrix, int capacity);
 int ronk_sharded_plan_destroy(ronk_sharded_plan* plan);
 /* R, C (n = R*C), elements per rank (n / ndev) and the number of column chunks in use; any pointer may be NULL */
 int ronk_sharded_plan_info(const ronk_sharded_plan* plan, uint64_t* rows, uint64_t* cols, uint64_t* per_rank, int* chunks);

@@ -117,6 +117,7 @@ _SIG = {
     "ronk_sharded_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int]),
     "ronk_sharded_plan_create_ex": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int, _int]),
     "ronk_sharded_plan_exchange": (_int, [_vp]),
+    "ronk_sharded_plan_peer_access": (_int, [_vp, C.POINTER(_int), _int]),
     "ronk_sharded_plan_destroy": (_int, [_vp]),
     "ronk_sharded_plan_info": (_int, [_vp, _pu, _pu, _pu, C.POINTER(_int)]),
     "ronk_ntt_sharded_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -264,6 +265,16 @@ class ShardedPlan:
         r, c, per, ch = _u64(0), _u64(0), _u64(0), _int(0)
         check(lib.ronk_sharded_plan_info(h, C.byref(r), C.byref(c), C.byref(per), C.byref(ch)))
         self.R, self.C, self.per_rank, self.chunks = r.value, c.value, per.value, ch.value
+
+    def peer_access(self):
+        """(matrix, staged): matrix[g][h] in {0 same device, 1 direct peer access, 2 staged through the host}; staged = the
+        number of rank pairs whose blocks do NOT travel peer-to-peer (ronk_sharded_plan_peer_access)"""
+        w = self.ndev
+        m = (_int * (w * w))()
+        staged = lib.ronk_sharded_plan_peer_access(self.h, m, w * w)
+        if staged < 0:
+            check(staged)
+        return [[m[g * w + h] for h in range(w)] for g in range(w)], staged
 
     def transform(self, x):
         """host natural-order vector -> natural-order result (ronk_ntt_sharded)"""

@@ -119,6 +119,8 @@ struct Dif {
       Dif<N / 2, INV, LAZY, FLD>::run(x + N / 2, f, false);
     }
   }
+  // stateless fields (Goldilocks): no policy object to pass
+  static RONK_HD void run(u64* x, bool first = true) { run(x, FLD(), first); }
 };
 template <bool INV, bool LAZY, class FLD>
 struct Dif<1, INV, LAZY, FLD> {

@@ -156,6 +156,10 @@ struct ronk_sharded_plan {
   bool inverse = false;
   int exchange = RONK_EXCHANGE_MESH;
   std::vector<ShardRank> r;
+  // how a block travels from rank g to rank h, [g * ndev + h] (ronk_sharded_plan_peer_access): RONK_PEER_SAME_DEVICE,
+  // RONK_PEER_DIRECT (peer access enabled: xGMI / PCIe peer-to-peer) or RONK_PEER_STAGED (the runtime refused peer access:
+  // hipMemcpyPeerAsync then goes through host memory -- correct, an order of magnitude slower, and never silent)
+  std::vector<int> peer;
   std::mutex mu;
 };
 
@@ -220,6 +224,7 @@ extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log
   ronk_sharded_plan* pl = new ronk_sharded_plan();
   pl->sh = sh; pl->ndev = ndev; pl->chunks = chunks; pl->inverse = inverse != 0; pl->exchange = exchange;
   pl->r.resize(ndev);
+  pl->peer.assign((size_t)ndev * ndev, RONK_PEER_SAME_DEVICE);
   const size_t per = (size_t)(sh.n / sh.W);
   const int ncopy = exchange == RONK_EXCHANGE_RCCL ? 1 : ndev;
   int rc = RONK_OK;
@@ -227,10 +232,28 @@ extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log
     ShardRank& k = pl->r[g];
     k.device = devices[g];
     rc = on_device(k.device);
-    // peer access to every other device of the plan (xGMI); "already enabled" is fine, a refusal falls back to
-    // staged copies inside hipMemcpyPeerAsync
-    for (int h = 0; h < ndev && !rc; h++)
-      if (devices[h] != k.device) { (void)hipDeviceEnablePeerAccess(devices[h], 0); (void)hipGetLastError(); }
+    // peer access to every other device of the plan (xGMI); "already enabled" is fine.  A refusal (hipDeviceCanAccessPeer
+    // says no, or enabling fails) leaves hipMemcpyPeerAsync staging through host memory: the outcome is KEPT per pair and
+    // reported (ronk_sharded_plan_peer_access; bench.py prints it), and RONK_REQUIRE_PEER=1 turns it into an error at plan
+    // creation.  RONK_FORCE_NO_PEER=1 (tests) takes the refused branch without asking the runtime; RONK_FORCE_NO_PEER=ranks
+    // (tests on a ONE-GPU box) additionally treats two different logical ranks that share a device as a refused pair, so that
+    // the report, RONK_REQUIRE_PEER and the hipMemcpyPeerAsync route (sharded_enqueue) are exercised there as well.
+    static const char* const fnp = getenv("RONK_FORCE_NO_PEER");
+    static const bool force_no_peer = fnp != nullptr, force_ranks = fnp && !strcmp(fnp, "ranks");
+    for (int h = 0; h < ndev && !rc; h++) {
+      int& how = pl->peer[(size_t)g * ndev + h];
+      if (devices[h] == k.device && !(force_ranks && h != g)) { how = RONK_PEER_SAME_DEVICE; continue; }
+      int can = 0;
+      hipError_t pe = force_no_peer ? hipErrorPeerAccessUnsupported : hipDeviceCanAccessPeer(&can, k.device, devices[h]);
+      if (pe == hipSuccess && can) {
+        pe = hipDeviceEnablePeerAccess(devices[h], 0);
+        if (pe == hipErrorPeerAccessAlreadyEnabled) pe = hipSuccess;
+      } else if (pe == hipSuccess) {
+        pe = hipErrorPeerAccessUnsupported;
+      }
+      (void)hipGetLastError();
+      how = pe == hipSuccess ? RONK_PEER_DIRECT : RONK_PEER_STAGED;
+    }
     if (!rc) rc = k.p1.compile(build_dist_phase1((int)log2n, inverse != 0, g, ndev, 4, 0, 0, chunks));
     if (!rc) rc = k.p2.compile(build_dist_phase2((int)log2n, inverse != 0, g, ndev, 4, 0, chunks));
     if (!rc && (k.p1.pd.passes.empty() || k.p2.pd.passes.empty())) rc = RONK_ERR_UNSUPPORTED;
@@ -255,6 +278,10 @@ extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log
     if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
     if (!rc && e != hipSuccess) rc = hip_fail(e, "sharded plan resources");
   }
+  if (!rc && getenv("RONK_REQUIRE_PEER")) {
+    for (int v : pl->peer)
+      if (v == RONK_PEER_STAGED) { rc = RONK_ERR_UNSUPPORTED; g_rccl_err = "peer access refused between two devices of the plan (RONK_REQUIRE_PEER)"; break; }
+  }
   if (!rc && exchange == RONK_EXCHANGE_RCCL) {
     std::vector<rcclComm_t> comms(ndev, nullptr);
     const int r_ = g_rccl.CommInitAll(comms.data(), ndev, devices);
@@ -268,6 +295,18 @@ extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log
 }
 
 extern "C" int ronk_sharded_plan_exchange(const ronk_sharded_plan* pl) { return pl ? pl->exchange : RONK_ERR_INVALID; }
+
+extern "C" int ronk_sharded_plan_peer_access(const ronk_sharded_plan* pl, int* matrix, int capacity) {
+  if (!pl) return RONK_ERR_INVALID;
+  const int w = pl->ndev;
+  if (matrix && capacity < w * w) return RONK_ERR_INVALID;
+  int staged = 0;
+  for (int i = 0; i < w * w; i++) {
+    if (matrix) matrix[i] = pl->peer[i];
+    if (pl->peer[i] == RONK_PEER_STAGED) staged++;
+  }
+  return staged;
+}
 
 extern "C" int ronk_sharded_plan_info(const ronk_sharded_plan* pl, uint64_t* rows, uint64_t* cols, uint64_t* per_rank,
                                       int* chunks) {
@@ -313,7 +352,7 @@ static int sharded_enqueue(ronk_sharded_plan* pl, const uint64_t* const* d_in, u
         u64* dst = pl->r[h].recv + ((u64)g * chunks + j) * blk;
         const u64* src = piece + (u64)h * blk;
         HIPCHK(hipStreamWaitEvent(k.copy[h], k.chunk_done[j], 0));
-        if (pl->r[h].device == k.device) HIPCHK(hipMemcpyAsync(dst, src, blk * 8, hipMemcpyDeviceToDevice, k.copy[h]));
+        if (pl->peer[(size_t)g * W + h] == RONK_PEER_SAME_DEVICE) HIPCHK(hipMemcpyAsync(dst, src, blk * 8, hipMemcpyDeviceToDevice, k.copy[h]));
         else HIPCHK(hipMemcpyPeerAsync(dst, pl->r[h].device, src, k.device, blk * 8, k.copy[h]));
       }
     }

@@ -403,6 +403,17 @@ impl ShardedPlan {
     }
   }
 
+  /// How blocks travel between the ranks of the mesh exchange (`ronk_sharded_plan_peer_access`): the row-major
+  /// `ndev x ndev` matrix of `ffi::PEER_SAME_DEVICE` / `PEER_DIRECT` / `PEER_STAGED`, and the number of STAGED pairs -- pairs
+  /// whose copies the runtime routes through host memory because peer access was refused.  0 on a healthy xGMI node; a caller
+  /// that measures should assert it.
+  pub fn peer_access(&self) -> (Vec<i32>, usize) {
+    let mut m = vec![0 as c_int; self.ndev * self.ndev];
+    let staged = unsafe { ffi::ronk_sharded_plan_peer_access(self.raw, m.as_mut_ptr(), m.len() as c_int) };
+    check(if staged < 0 { staged } else { 0 });
+    (m, staged as usize)
+  }
+
   /// uninitialised per-rank blocks, block g on `devices[g]` (what `transform` takes on both sides)
   pub fn alloc_blocks(&self) -> Vec<DevicePoly> {
     let per = self.info().2 as usize;

@@ -14,6 +14,9 @@ pub const G: u64 = 7;
 /// `RONK_EXCHANGE_MESH` / `RONK_EXCHANGE_RCCL` (include/ronk_ntt.h)
 pub const EXCHANGE_MESH: c_int = 0;
 pub const EXCHANGE_RCCL: c_int = 1;
+pub const PEER_SAME_DEVICE: c_int = 0;
+pub const PEER_DIRECT: c_int = 1;
+pub const PEER_STAGED: c_int = 2;
 
 /// `ronk_plan` (opaque)
 #[repr(C)]
@@ -146,6 +149,7 @@ extern "C" {
     exchange: c_int,
   ) -> c_int;
   pub fn ronk_sharded_plan_exchange(plan: *const RonkShardedPlan) -> c_int;
+  pub fn ronk_sharded_plan_peer_access(plan: *const RonkShardedPlan, matrix: *mut c_int, capacity: c_int) -> c_int;
   pub fn ronk_sharded_plan_destroy(plan: *mut RonkShardedPlan) -> c_int;
   pub fn ronk_sharded_plan_info(
     plan: *const RonkShardedPlan, rows: *mut u64, cols: *mut u64, per_rank: *mut u64, chunks: *mut c_int,

@@ -228,6 +228,16 @@ static void replay_placement(int ndev) {
   ronk_sharded_plan* sp = NULL;
   EXPECT(ronk_sharded_plan_create_ex(&sp, log2n, 0, devices, 2, 0, RONK_EXCHANGE_MESH) == 0, "ronk_sharded_plan_create_ex(mesh)");
   EXPECT(ronk_sharded_plan_exchange(sp) == RONK_EXCHANGE_MESH, "ronk_sharded_plan_exchange");
+  {   /* ShardedPlan::peer_access: the diagonal is SAME_DEVICE; the off-diagonal pair too when both ranks share device 0,
+         DIRECT or STAGED (and counted by the return value) when they sit on two GPUs */
+    int pm[4] = {9, 9, 9, 9};
+    const int staged = ronk_sharded_plan_peer_access(sp, pm, 4);
+    EXPECT(staged >= 0 && pm[0] == RONK_PEER_SAME_DEVICE && pm[3] == RONK_PEER_SAME_DEVICE, "ronk_sharded_plan_peer_access");
+    if (ndev > 1) EXPECT((pm[1] == RONK_PEER_DIRECT || pm[1] == RONK_PEER_STAGED) && (pm[2] == RONK_PEER_DIRECT || pm[2] == RONK_PEER_STAGED) &&
+                         staged == (pm[1] == RONK_PEER_STAGED) + (pm[2] == RONK_PEER_STAGED), "peer_access across two GPUs");
+    else EXPECT(staged == 0 && pm[1] == RONK_PEER_SAME_DEVICE && pm[2] == RONK_PEER_SAME_DEVICE, "peer_access on one GPU");
+    EXPECT(ronk_sharded_plan_peer_access(sp, pm, 3) == RONK_ERR_INVALID, "peer_access capacity check");
+  }
   uint64_t rows = 0, cols = 0, per = 0; int chunks = 0;
   EXPECT(ronk_sharded_plan_info(sp, &rows, &cols, &per, &chunks) == 0 && per == n / 2, "info");
   /* alloc_blocks: block g on devices[g] (OnDevice around every alloc / copy) */

@@ -15,7 +15,8 @@ EXE = os.path.join(ROOT, "build", "emu_tile")
 def emu():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "emu", "emu_tile.cpp")]
-    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "ntt_small.h", "ntt_mul.h", "plan.h", "gl64.h", "tile_cfg_table.h")]
+    deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "ntt_small.h", "ntt_mul.h", "plan.h", "gl64.h", "tile_cfg_table.h",
+                                                                                  "field_policy.h", "mont64.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
         subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
@@ -23,9 +24,45 @@ def emu():
     return EXE
 
 
-def run(emu, *args):
-    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+def run(emu, *args, env=None):
+    out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, **env) if env else None)
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("OK"), out.stdout[-400:] + out.stderr[-400:]
+    return out.stdout
+
+
+# Generic odd primes on the SAME kernel source (field_policy.h MontField: Montgomery products, table-form twiddles): a prime
+# above 2^63 (sums carry into bit 64), one below 2^62, a 32-bit one.  (p, primitive element) -- the GPU suite's list.
+MONT_PRIMES = [(0xFFFFFFFC00000001, 10), (29 * 2**57 + 1, 3), (3 * 2**30 + 1, 5)]
+
+
+def mont_env(p, g):
+    return {"RONK_EMU_P": hex(p), "RONK_EMU_G": str(g)}
+
+
+@pytest.mark.parametrize("p,g", MONT_PRIMES)
+def test_montgomery_primes_on_the_tile_kernels(emu, p, g):
+    """single-pass (staged I/O, ragged tiles), two-pass (latency form, tile form with the specialised column / row shapes and
+    the full twiddle matrix, batched, inverse with the folded n^-1), implicit padding + second operand + truncation (the
+    polynomial multiply's features on the generic body), three passes -- every output against the oracle called with (p, g)"""
+    e = mont_env(p, g)
+    for k in (4, 5, 8, 12):
+        run(emu, k, 3, 0, 4, env=e)
+        run(emu, k, 37, 1, 0, env=e)
+    run(emu, 13, 2, 0, 4, env=e)
+    out = run(emu, 16, 2, 1, 4, 18, env=e)
+    assert "cfg:column/matrix" in out and "cfg:row" in out      # the specialised shapes run for Montgomery primes too
+    out = run(emu, 16, 1, 0, 4, 18, 25, 0, 0, 1, env=e)
+    assert "kernel=small" in out                                 # the planner's latency form
+    run(emu, 15, 2, 0, 4, 18, 25, 20000, 30000, 0, 9000, 1, env=e)   # in_valid / out_valid / in_valid1 / in2
+    run(emu, 14, 1, 1, 2, 0, 13, env=e)                              # three passes (4, 5, 5)
+
+
+def test_montgomery_dist_phases(emu):
+    """the four-step phase builders take the field as well (plan.h build_dist_phase1 / 2 with a HostField)"""
+    p, g = MONT_PRIMES[0]
+    run(emu, "dist", 16, 4, 0, 0, 2, env=mont_env(p, g))
+    run(emu, "dist", 16, 2, 1, 18, 1, env=mont_env(p, g))
 
 
 @pytest.mark.parametrize("k", [4, 5, 6, 7, 8, 9, 10, 11, 12])

@@ -56,11 +56,9 @@ def test_patch_applies_to_the_reference_and_is_current(tmp_path):
     for f in ("build.rs", "src/polynomial/dispatch.rs", "src/algebra/field/goldilocks/mod.rs", "src/algebra/field/goldilocks/ffi.rs",
               "src/algebra/field/goldilocks/gpu.rs"):
         assert (scratch / f).is_file()
-    # the committed patch is what the generator makes from the crate's sources today
-    before = open(PATCH).read()
-    try:
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_in_tree_patch.py"), REF], stdout=subprocess.DEVNULL)
-        assert open(PATCH).read() == before, "rust sources changed: re-run tools/make_in_tree_patch.py and commit the patch"
-    finally:
-        with open(PATCH, "w") as f:
-            f.write(before)
+    # the committed patch is what the generator makes from the crate's sources today (written to a scratch file: the tracked
+    # patch is only read)
+    fresh = tmp_path / "fresh.patch"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_in_tree_patch.py"), REF, "--output=%s" % fresh],
+                          stdout=subprocess.DEVNULL)
+    assert fresh.read_text() == open(PATCH).read(), "rust sources changed: re-run tools/make_in_tree_patch.py and commit the patch"

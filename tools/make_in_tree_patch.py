@@ -20,9 +20,17 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+# usage: make_in_tree_patch.py [reference checkout] [--output FILE]   (default output: the tracked in_tree/ronkathon.patch;
+# the test suite writes to a scratch file and compares, so a killed test run never leaves the working tree modified)
+_args = [a for a in sys.argv[1:] if not a.startswith("--output")]
+REF = _args[0] if _args and sys.argv[sys.argv.index(_args[0]) - 1] != "--output" else "/root/reference"
 CRATE = os.path.join(ROOT, "rust", "ronk-goldilocks")
 OUT = os.path.join(CRATE, "in_tree", "ronkathon.patch")
+for _i, _a in enumerate(sys.argv[1:], 1):
+    if _a == "--output" and _i + 1 < len(sys.argv):
+        OUT = sys.argv[_i + 1]
+    elif _a.startswith("--output="):
+        OUT = _a.split("=", 1)[1]
 
 
 def read(path):

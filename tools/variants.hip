@@ -12,6 +12,12 @@
 //      odd lanes
 //   D  32 coefficients per lane: Dif<32> + 31 table multiplies at 4 waves per SIMD (the registers allow no more), against two
 //      shipped 16-point rounds at 8
+//   E  (round 5) a twiddle layer whose row digit is WAVE-UNIFORM (the review's proposal: a pass as [16 . 4] . [4 . 8], the digit that
+//      meets the register index taken from the top bits of the lane's row group, so omega_64^(a k) = 2^(39 a k) is selected by a
+//      scalar branch among compile-time mul_2exp<K> bodies): E1 the shift layer against E0 the table layer it would replace, and
+//      E2 what the extra round costs -- one more LDS exchange (16 ds_write_b64 + barrier + 16 ds_read_b64 per lane).  A pass of
+//      2^11 rows is (16, 16, 8) = 2 table layers + 2 exchanges today; [16 . 4] . [4 . 8] is 1 table layer + 2 shift layers +
+//      3 exchanges.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/variants.hip -o gpurun_bin/variants
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -175,6 +181,65 @@ __global__ void __launch_bounds__(256) xlane_stage_kernel(u64* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// ---------------------------------------------------------------- E: wave-uniform shift layer / table layer / LDS exchange
+// x[i] *= omega_64^(a * k_i), k_i = brev4(i): a in [0, 4) is wave-uniform -> one scalar branch per layer, compile-time shifts inside
+template <int A, int I>
+__device__ __forceinline__ void shift_layer_regs(u64* x) {
+  if constexpr (I < 16) {
+    constexpr int K = brev(I, 4);
+    constexpr int E = (39 * A * K) % 192;
+    if constexpr (E >= 96) x[I] = gl64::neg(gl64::mul_2exp<E - 96>(x[I]));
+    else if constexpr (E > 0) x[I] = gl64::mul_2exp<E>(x[I]);
+    shift_layer_regs<A, I + 1>(x);
+  }
+}
+__global__ void __launch_bounds__(256) shift_layer_kernel(u64* out, int iters) {
+  u64 x[16];
+  for (int i = 0; i < 16; i++) x[i] = (u64)(threadIdx.x * 7919u + blockIdx.x + i + 1) * 0x9E3779B97F4A7C15ull % gl64::P;
+  const u32 a = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave index: 0..3, in an SGPR
+  for (int it = 0; it < iters; it++) {
+    switch ((a + it) & 3) {
+      case 0: shift_layer_regs<0, 0>(x); break;
+      case 1: shift_layer_regs<1, 0>(x); break;
+      case 2: shift_layer_regs<2, 0>(x); break;
+      default: shift_layer_regs<3, 0>(x); break;
+    }
+  }
+  u64 acc = 0;
+  for (int i = 0; i < 16; i++) acc ^= x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) table_layer_kernel(u64* out, const u64* tw, int iters) {
+  u64 x[16];
+  for (int i = 0; i < 16; i++) x[i] = (u64)(threadIdx.x * 7919u + blockIdx.x + i + 1) * 0x9E3779B97F4A7C15ull % gl64::P;
+  const u32 tb = (threadIdx.x & 63) << 3;
+  for (int it = 0; it < iters; it++)
+#pragma unroll
+    for (int i = 1; i < 16; i++) x[i] = gl64::mul(x[i], ld_tabb(tw, (tb * i + it) & 0x3FF8));
+  u64 acc = 0;
+  for (int i = 0; i < 16; i++) acc ^= x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+// one LDS exchange of the tile kernel's kind: 16 ds_write_b64 at one per-lane base + immediates, barrier, 16 ds_read_b64 at
+// another (256 lanes x 16 x 8 B = 32 KiB per workgroup + the dummy rows; two workgroups per CU: 4 waves per SIMD as in the kernel)
+__global__ void __launch_bounds__(256) exchange_kernel(u64* out, int iters) {
+  extern __shared__ u64 lds[];
+  u64 x[16];
+  for (int i = 0; i < 16; i++) x[i] = (u64)(threadIdx.x * 7919u + blockIdx.x + i + 1) * 0x9E3779B97F4A7C15ull % gl64::P;
+  const u32 t = threadIdx.x, wbase = t + (t >> 4), rbase = 17 * (t >> 4) * 16 + (t & 15);
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) lds[wbase + i * 272] = x[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = lds[(rbase + i * 17) % 4352] + (u64)it;
+    __syncthreads();
+  }
+  u64 acc = 0;
+  for (int i = 0; i < 16; i++) acc ^= x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // ---------------------------------------------------------------- plain v_add_u32 reference (1 slot)
 __global__ void __launch_bounds__(256) slot_kernel(u64* out, u32 y, int iters) {
   u32 x[16];
@@ -224,6 +289,16 @@ int main() {
   printf("D  32-point round + 31 multiplies, 4 waves per SIMD      %8.1f us  for 5 stages + 1 multiply layer per coefficient\n", d32);
   printf("D  two shipped 16-point rounds, 8 waves per SIMD         %8.1f us  for 8 stages + 2 multiply layers per coefficient\n", a16x2);
   printf("   per stage-equivalent: 32-point %.2f us, 16-point pair %.2f us (same %.0f coefficients)\n", d32 / 5.0, a16x2 / 8.0, lanes * 16);
+  // E: the review's wave-uniform shift layer
+  const double e0 = time_us([&] { hipLaunchKernelGGL(table_layer_kernel, dim3(G), dim3(T), 0, 0, d_out, d_tw, it2); });
+  const double e1 = time_us([&] { hipLaunchKernelGGL(shift_layer_kernel, dim3(G), dim3(T), 0, 0, d_out, it2); });
+  const double e2 = time_us([&] { hipLaunchKernelGGL(exchange_kernel, dim3(G), dim3(T), 4352 * 8, 0, d_out, it2); });
+  printf("E0 table-twiddle layer (15 multiplies + table loads)      %8.1f us  %6.1f slots per coefficient\n", e0, slots_per_coeff(e0, 16, it2));
+  printf("E1 wave-uniform shift layer omega_64^(a k), a in SGPR    %8.1f us  %6.1f slots per coefficient\n", e1, slots_per_coeff(e1, 16, it2));
+  printf("E2 one LDS exchange (16 writes, barrier, 16 reads)       %8.1f us  %6.1f slot-equivalents per coefficient (LDS pipe + barrier, not VALU)\n", e2, slots_per_coeff(e2, 16, it2));
+  printf("   a 2^11-row pass today: 2 x E0 + 2 x E2 = %.1f; as [16.4].[4.8]: E0 + 2 x E1 + 3 x E2 = %.1f slot-equivalents per coefficient (butterflies equal)\n",
+         2 * slots_per_coeff(e0, 16, it2) + 2 * slots_per_coeff(e2, 16, it2),
+         slots_per_coeff(e0, 16, it2) + 2 * slots_per_coeff(e1, 16, it2) + 3 * slots_per_coeff(e2, 16, it2));
   (void)lanes;
   return 0;
 }
