@@ -210,14 +210,19 @@ def self_launch_command(gpus, environ, argv):
         return None
     if any(a == "--workload=sharded" for a in argv):
         return None
-    port = environ.get("MASTER_PORT") or str(29500 + os.getpid() % 1000)
+    port = environ.get("MASTER_PORT")
+    if not port:            # a free port, asked of the kernel (a fixed formula can collide with another job or a stale rendezvous)
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
             "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(argv[0])] + list(argv[1:])
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks = GPUs of the job (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="ntt22")
@@ -251,6 +256,8 @@ def main():
     ap.add_argument("--generator", type=lambda v: int(v, 0), default=0,
                     help="primitive element for --prime (default: the smallest quadratic non-residue)")
     args = ap.parse_args()
+    if args.gpus <= 0:      # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the job
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the contract's
     # torch.distributed.run command line), then fall through as rank RANK of WORLD_SIZE.  Under a launcher the two must agree.

@@ -70,12 +70,8 @@ struct MontField {
     for (int j = 0; j < 8; j++) w16[j] = c.w16[j];
   }
   RONK_HD u64 add(u64 a, u64 b) const { return mont64::add(f, a, b); }
-  // the consumer is a Montgomery product, which accepts any 64-bit representative of its first operand (x * wR < 2^64 * p):
-  // only a wrap is folded back (2^64 = f.one mod p; after a wrap s < 2p - 2^64 < p, so s + one = a + b - p cannot wrap again)
-  RONK_HD u64 add_lazy(u64 a, u64 b) const {
-    const u64 s = a + b;
-    return s + ((s < a) ? f.one : 0);
-  }
+  // (a "lazy" sum -- only the wrap folded back, as for Goldilocks -- costs the same six instructions as the canonical one here)
+  RONK_HD u64 add_lazy(u64 a, u64 b) const { return mont64::add(f, a, b); }
   RONK_HD u64 sub(u64 a, u64 b) const { return mont64::sub(f, a, b); }
   RONK_HD u64 mul(u64 x, u64 w) const { return mont64::mmul(f, x, w); }
   RONK_HD u64 mul_plain(u64 x, u64 y) const { return mont64::mmul(f, mont64::mmul(f, x, y), f.r2); }

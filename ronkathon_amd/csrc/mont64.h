@@ -38,32 +38,60 @@ RONK_HD void mul64(u64 a, u64 b, u64& lo, u64& hi) {
   lo = (p10 << 32) | (u32)p00;
 }
 
-// prime/arithmetic.rs:3-7 without the `%`: a, b < p
+// prime/arithmetic.rs:3-7 without the `%`: a, b < p.  p may exceed 2^63: the sum carries into bit 64.
+// Device form (6 VALU + 2 SALU on gfx950): s = a + b with carry C, d = s - p with borrow B on 32-bit limbs; the sum is >= p
+// exactly when C or not B, and the two candidates are selected by that one mask (no 64-bit compare: those cost 1.6 issue
+// slots each, tools/rate_probe.hip).
 RONK_HD u64 add(const Field& f, u64 a, u64 b) {
+#if defined(__clang__)
+  u32 c1, c2, b1, b2;
+  const u32 sl = __builtin_addc((u32)a, (u32)b, 0u, &c1);
+  const u32 sh = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+  const u32 dl = __builtin_subc(sl, (u32)f.p, 0u, &b1);
+  const u32 dh = __builtin_subc(sh, (u32)(f.p >> 32), b1, &b2);
+  const bool take = c2 | !b2;
+  return take ? (((u64)dh << 32) | dl) : (((u64)sh << 32) | sl);
+#else
   u64 s = a + b;
   return (s < a || s >= f.p) ? s - f.p : s;
+#endif
 }
-// prime/arithmetic.rs:19-28
+// prime/arithmetic.rs:19-28.  Valid for ANY a < 2^64 and b < p with a - b > -p (what redc needs).  Device form: borrow chain,
+// then + (B ? p : 0) selected by the borrow itself (6 VALU).
 RONK_HD u64 sub(const Field& f, u64 a, u64 b) {
+#if defined(__clang__)
+  u32 b1, b2, c1, c2;
+  const u32 lo = __builtin_subc((u32)a, (u32)b, 0u, &b1);
+  const u32 hi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b1, &b2);
+  const u32 pl = b2 ? (u32)f.p : 0u, ph = b2 ? (u32)(f.p >> 32) : 0u;
+  const u32 rl = __builtin_addc(lo, pl, 0u, &c1);
+  const u32 rh = __builtin_addc(hi, ph, c1, &c2);
+  return ((u64)rh << 32) | rl;
+#else
   u64 d = a - b;
   return (a < b) ? d + f.p : d;
+#endif
 }
 RONK_HD u64 neg(const Field& f, u64 a) { return a ? f.p - a : 0; }
 
-// REDC(hi:lo) = (hi:lo) * 2^-64 mod p, for hi < p
+// REDC(hi:lo) = (hi:lo) * 2^-64 mod p, for hi < p.  With the POSITIVE inverse q = p^-1 mod 2^64 and m = lo * q mod 2^64 the
+// product m * p has exactly the low half `lo`, so hi:lo - m*p = (hi - hi64(m p)) * 2^64 with NO carry to track: the result is
+// hi - hi64(m p), plus p when that is negative (both terms are below p).  26 VALU per Montgomery product on gfx950 (4 + 4
+// v_mad_u64_u32 / v_mul_hi for the two wide products, 1 mad + 2 v_mul_lo for m, the borrow-chain subtraction) against 36
+// for the textbook form with -p^-1, the carry of the low halves and a compare against p.
 RONK_HD u64 redc(const Field& f, u64 lo, u64 hi) {
-  u64 m = lo * f.pinv;
-  u64 mlo, mhi;
-  mul64(m, f.p, mlo, mhi);
-  // lo + mlo == 0 mod 2^64; carry out is 1 unless lo == 0
-  u64 carry = lo != 0;
-  u64 t = hi + mhi;
-  bool over = t < hi;
-  u64 t2 = t + carry;
-  over |= t2 < t;
-  return (over || t2 >= f.p) ? t2 - f.p : t2;
+  const u64 q = (u64)0 - f.pinv;                 // + p^-1 (wave-uniform: scalar ALU)
+  const u32 t0 = (u32)lo, t1 = (u32)(lo >> 32), q0 = (u32)q, q1 = (u32)(q >> 32);
+  const u64 ml = (u64)t0 * q0;
+  const u32 m0 = (u32)ml, m1 = (u32)(ml >> 32) + t0 * q1 + t1 * q0;   // m = lo * q mod 2^64
+  const u32 p0 = (u32)f.p, p1 = (u32)(f.p >> 32);
+  const u64 c00 = (u64)m0 * p0;                  // only its high word is needed (v_mul_hi_u32)
+  const u64 c01 = (u64)m0 * p1 + (c00 >> 32);
+  const u64 c10 = (u64)m1 * p0 + (u32)c01;
+  const u64 mhi = (u64)m1 * p1 + (c01 >> 32) + (c10 >> 32);
+  return sub(f, hi, mhi);
 }
-// Montgomery product: a*b*2^-64 mod p
+// Montgomery product: a*b*2^-64 mod p.  a: ANY 64-bit value, b < p (then hi64(a b) < p); result canonical.
 RONK_HD u64 mmul(const Field& f, u64 a, u64 b) {
   u64 lo, hi;
   mul64(a, b, lo, hi);

@@ -64,8 +64,19 @@ struct WsLease {
     if (!slot) return;
     std::lock_guard<std::mutex> lk(g_ws_mu);
     if (slot->oneoff) {   // never pooled: an event behind its work, freed by whoever finds it complete
-      slot->ev_valid = hipEventRecord(slot->done, s) == hipSuccess;
-      if (!slot->ev_valid) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+      // A capturing stream: an event recorded inside a capture never completes for hipEventQuery / hipEventSynchronize, so the
+      // buffer would sit in the grave for ever (through ronk_trim_workspace as well).  A captured graph may be replayed long
+      // after this call returned, so its one-off workspace cannot be freed at all while the graph lives: acquire() refuses
+      // one-off workspaces under capture (RONK_ERR_UNSUPPORTED); should one get here regardless, it is kept, not leaked
+      // silently: the grave entry has no event and is freed by the next reap.
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+      if (cap != hipStreamCaptureStatusNone) {
+        slot->ev_valid = false;
+      } else {
+        slot->ev_valid = hipEventRecord(slot->done, s) == hipSuccess;
+        if (!slot->ev_valid) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+      }
       slot->busy = false;
       g_ws_grave.push_back(slot);
       ws_reap(false);
@@ -82,6 +93,11 @@ struct WsLease {
     if (oneoff) need = (bytes + 255) & ~(size_t)255;   // exactly what was asked for, not the next power of two
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
+    if (oneoff) {   // (see ~WsLease: a captured graph would use the buffer after it has been freed)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+      if (cap != hipStreamCaptureStatusNone) return RONK_ERR_UNSUPPORTED;
+    }
     std::lock_guard<std::mutex> lk(g_ws_mu);
     ws_reap(false);
     size_t on_dev = 0;
@@ -108,6 +124,13 @@ struct WsLease {
       WsSlot* w = new WsSlot();
       w->oneoff = oneoff;
       hipError_t e = hipMalloc(&w->p, need);
+      if (e == hipErrorOutOfMemory && !g_ws_grave.empty()) {
+        // two back-to-back large divisions on one stream: the first one's one-off buffer (gigabytes) is still in the grave
+        // behind its event -- wait for the grave instead of reporting out-of-memory, then try once more
+        (void)hipGetLastError();
+        ws_reap(true);
+        e = hipMalloc(&w->p, need);
+      }
       if (e == hipSuccess) e = hipMalloc((void**)&w->ctl, 64);
       if (e == hipSuccess) e = hipMemset(w->ctl, 0, 64);
       if (e == hipSuccess) e = hipMalloc((void**)&w->lb, (size_t)2 * LB_WORDS * 8);

@@ -381,24 +381,36 @@ extern "C" int ronk_ntt_inverse_dev(ronk_plan* pl, const uint64_t* in, uint64_t*
 // OVERLAPS a foreign registration partially is refused by the runtime: the copies of that call then run synchronously
 // (correct, un-overlapped).  The lock covers the runtime calls only.
 static std::mutex g_pin_mu;
-static std::map<const void*, std::pair<size_t, int>> g_pins;   // base -> (bytes, users)
-static bool pin_acquire(const void* p, size_t bytes) {
+static std::map<uintptr_t, std::pair<size_t, int>> g_pins;   // base -> (bytes, users), disjoint intervals
+// Returns the base of OUR registration that now covers [p, p + bytes) (the caller hands it back to pin_release), or 0 when
+// the copies of this call have to run synchronously / the memory is page-locked by somebody else already.  Lookup is by
+// INTERVAL: a sub-range of a range this library registered for another thread shares that registration (reference count on
+// the owning entry), so the owner's release cannot unregister memory a second thread's copies are still reading; a range
+// that only partially overlaps one of ours is left alone (synchronous copies).
+static uintptr_t pin_acquire(const void* p, size_t bytes) {
+  const uintptr_t a = (uintptr_t)p, b = a + bytes;
   std::lock_guard<std::mutex> lk(g_pin_mu);
-  auto it = g_pins.find(p);
-  if (it != g_pins.end() && it->second.first >= bytes) { it->second.second++; return true; }
-  if (it != g_pins.end()) return false;                       // ours, but shorter: leave it to its owner
+  auto it = g_pins.upper_bound(a);                 // first entry that starts after a
+  if (it != g_pins.begin()) {
+    auto prev = std::prev(it);
+    const uintptr_t pa = prev->first, pb = pa + prev->second.first;
+    if (a >= pa && b <= pb) { prev->second.second++; return pa; }   // contained in one of ours
+    if (a < pb) return 0;                                           // partial overlap with ours
+  }
+  if (it != g_pins.end() && it->first < b) return 0;                // runs into the next one of ours
   hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return false;   // page-locked by the caller
+  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return 0;   // page-locked by the caller
   (void)hipGetLastError();
-  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
-  g_pins[p] = {bytes, 1};
-  return true;
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  g_pins[a] = {bytes, 1};
+  return a;
 }
-static void pin_release(const void* p) {
+static void pin_release(uintptr_t base) {
+  if (!base) return;
   std::lock_guard<std::mutex> lk(g_pin_mu);
-  auto it = g_pins.find(p);
+  auto it = g_pins.find(base);
   if (it == g_pins.end() || --it->second.second > 0) return;
-  (void)hipHostUnregister(const_cast<void*>(p));
+  (void)hipHostUnregister((void*)base);
   g_pins.erase(it);
 }
 
@@ -436,8 +448,8 @@ static int transform_host_pipelined(ronk_plan* pl, bool inverse, const u64* in, 
   // again; buffers that are already page-locked (hipHostMalloc, an earlier registration) are used as they are, and if a
   // registration is refused the copies simply fall back to their synchronous behaviour.
   const size_t total_bytes = (size_t)(pl->batch * n * 8);
-  const bool reg_in = pin_acquire(in, total_bytes);
-  const bool reg_out = pin_acquire(out, total_bytes);
+  const uintptr_t reg_in = pin_acquire(in, total_bytes);
+  const uintptr_t reg_out = pin_acquire(out, total_bytes);
   int rc = RONK_OK;
   for (u32 i = 0; i < nsl && !rc; i++) {
     const u64 b0 = (u64)i * per, cnt = pl->batch - b0 < per ? pl->batch - b0 : per;
@@ -458,8 +470,8 @@ static int transform_host_pipelined(ronk_plan* pl, bool inverse, const u64* in, 
   hipError_t e1 = hipStreamSynchronize(pl->st_h2d), e2 = hipStreamSynchronize(pl->st_exec), e3 = hipStreamSynchronize(pl->st_d2h);
   if (!rc && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
     rc = hip_fail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3, "pipeline drain");
-  if (reg_in) pin_release(in);
-  if (reg_out) pin_release(out);
+  pin_release(reg_in);
+  pin_release(reg_out);
   return rc;
 }
 
@@ -779,7 +791,8 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
     // Fused middle (ntt_mul.h): forward row pass of both operands + pointwise product + inverse column pass in ONE launch --
     // three launches per product, NTT(a) / NTT(b) never written.  Needs the same tile width on both sides (a dedicated
-    // inverse plan with the pair plan's 4-column tiles) and two-pass plans of 2^10 / 2^11-row passes (2^20 .. 2^22).  RONK_MUL_FUSED=0: the
+    // inverse plan with the pair plan's 4-column tiles) and two-pass plans of 2^10 / 2^11-row passes; fused for NTT sizes 2^21
+    // and 2^22 only (2^20 measured slower, below).  RONK_MUL_FUSED=0: the
     // four-launch form (A/B); RONK_MUL_INV_TWF picks the inverse's twiddle form as before (default there: two-level tables).
     static const bool fused_on = [] { const char* e_ = getenv("RONK_MUL_FUSED"); return !e_ || atoi(e_) != 0; }();
     // Measured (round 4, same box, us per product): 2^22 158.6 -> 132.6, 2^21 88.0 -> 80.6, but 2^20 63.1 -> 68.1 -- there a
@@ -802,7 +815,11 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
         TileArgs ia = I.bound(0, nullptr, nullptr, nullptr, e->plf->d_tmp);
         const PassDesc& fp = F.pd.passes[1];
         const int kindi = ia.tw_full ? 3 : 1;
-        if (mul_mid_matches(fa, ia, fp.logr, (int)fa.logc, kindi)) {
+        // (lookup first: without an instantiation nothing is enqueued here and the four-launch form below runs alone.
+        //  pl2->d_tmp and plf->d_tmp are used directly, without stream_mu / scratch_acquire / scratch_release: both plans are
+        //  private to this cache entry, and every use of the entry is serialised by g_cache_mu (held here) + e->done -- that
+        //  pair is the ONLY guard of these two scratch buffers.)
+        if (mul_mid_matches(fa, ia, fp.logr, (int)fa.logc, kindi) && mul_mid_available(fp.logr, (int)fa.logc, kindi)) {
           HIPCHK(hipStreamWaitEvent(s, e->done, 0));
           RCHK(F.launch(0, d_a, nullptr, nullptr, e->pl2->d_tmp, s, (u64)d, ~(u64)0, stride, 0, 0, 0, (u64)d2));
           bool found = false;
@@ -813,7 +830,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
             HIPCHK(hipEventRecord(e->done, s));
             return RONK_OK;
           }
-          // (no instantiation for this shape: the column pass just run is repeated by the four-launch form below)
+          // (not reached: mul_mid_available said yes)
         }
       }
     }

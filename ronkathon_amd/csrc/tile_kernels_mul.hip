@@ -34,8 +34,17 @@ static hipError_t launch_mid(const TileArgs& fa, const TileArgs& ia, u32 grid, u
   return hipGetLastError();
 }
 
-// the (rows, tile width, inverse twiddle form) combinations of the multiply's plans: NTT sizes 2^20 and 2^22, 4- and 8-column tiles
+// the (rows, tile width, inverse twiddle form) combinations of the multiply's plans, 4- and 8-column tiles: 2^11-row passes = NTT
+// size 2^22; 2^10-row passes = NTT size 2^21 (pair plan 2^11 x 2^10, inverse split the other way round) and 2^20 (instantiated,
+// but conv_dev keeps four launches there: measured slower fused)
 #define RONK_MUL_MID_TABLE(X) X(11, 2, 1) X(11, 2, 3) X(11, 3, 1) X(11, 3, 3) X(10, 2, 1) X(10, 2, 3) X(10, 3, 1) X(10, 3, 3)
+
+bool mul_mid_available(int logr, int logc, int kindi) {
+#define RONK_MID_HAS(LR, LC, KD) if (logr == LR && logc == LC && kindi == KD) return true;
+  RONK_MUL_MID_TABLE(RONK_MID_HAS)
+#undef RONK_MID_HAS
+  return false;
+}
 
 hipError_t launch_mul_mid(int logr, int kindi, const TileArgs& fa, const TileArgs& ia, u32 grid, u32 block, size_t lds,
                           hipStream_t s, bool* found) {

@@ -12,6 +12,8 @@ hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32
                         hipStream_t stream);
 // the fused middle of a polynomial multiply (ntt_mul.h, tile_kernels_mul.hip): fa = the forward plan's row pass over the batch
 // of two operands, ia = the inverse plan's column pass; grid = tiles of ONE operand; *found = an instantiation exists
+// is there an instantiation for (rows, log2 tile columns, inverse twiddle form)?  Asked BEFORE the forward column pass is enqueued
+bool mul_mid_available(int logr, int logc, int kindi);
 hipError_t launch_mul_mid(int logr, int kindi, const TileArgs& fa, const TileArgs& ia, u32 grid, u32 block, size_t lds_bytes,
                           hipStream_t stream, bool* found);
 }

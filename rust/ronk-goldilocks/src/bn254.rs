@@ -4,7 +4,10 @@
 //! are `usize`-wide (src/algebra/mod.rs:8-13), so a 254-bit curve is a new pair of plain-data types here rather than an
 //! `EllipticCurve` implementor: 4 x 64-bit little-endian limbs, standard (non-Montgomery) form, `(0, 0)` = infinity --
 //! byte-identical to what `ronk_msm_bn254` takes, so slices are passed without conversion.
-use crate::{device::DevicePoly, ffi};
+use crate::{
+  device::{DevicePoly, OnDevice},
+  ffi,
+};
 
 /// element of F_p (coordinates) or an integer scalar, 4 x 64-bit little-endian limbs
 pub type Limbs = [u64; 4];
@@ -37,7 +40,9 @@ pub fn commit(coeffs: &[Limbs], g1_srs: &[G1Affine]) -> G1Affine {
 /// (x then y), `scalars` = n x 4 limbs, both as [`DevicePoly`] buffers of 64-bit words on the same GPU.  With
 /// `DevicePoly::div_linear` before it, `kzg::open` (src/kzg/setup.rs:63-78) followed by `commit` never leaves the device.
 pub fn commit_dev(scalars: &DevicePoly, g1_srs: &DevicePoly, n: usize) -> G1Affine {
-  assert!(scalars.len() >= 4 * n && g1_srs.len() >= 8 * n && scalars.device() == g1_srs.device());
+  assert!(scalars.len() >= 4 * n && g1_srs.len() >= 8 * n);
+  scalars.same_device(g1_srs);
+  let _g = OnDevice::new(scalars.device());   // `ronk_msm_bn254_dev` (kernels and workspace) runs on the CURRENT device
   let mut out = G1Affine::INFINITY;
   ffi::check(unsafe {
     ffi::ronk_msm_bn254_dev(g1_srs.as_ptr(), scalars.as_ptr(), n, &mut out as *mut G1Affine as *mut u64, core::ptr::null_mut())

@@ -15,7 +15,7 @@ use core::ffi::{c_int, c_void};
 use std::ptr;
 
 use crate::{
-  device::{DevicePoly, Plan},
+  device::{DevicePoly, OnDevice, Plan},
   ffi::{self, check, G, P},
   field::Goldilocks,
 };
@@ -71,7 +71,9 @@ impl<const K: usize> Message<K> {
 pub fn encode_batch(plan: &Plan, msgs: &DevicePoly, k: usize) -> DevicePoly {
   assert!(k >= 1 && k <= plan.n(), "Code size must be greater than or equal to K");
   assert!(msgs.len() == plan.batch * k);
-  let out = DevicePoly::alloc_on(msgs.device(), plan.batch * plan.n());
+  plan.same_device(msgs);
+  let _g = OnDevice::new(plan.device());
+  let out = DevicePoly::alloc_on(plan.device(), plan.batch * plan.n());
   check(unsafe { ffi::ronk_rs_encode_batch_dev(plan.raw(), msgs.as_ptr(), k, out.as_mut_ptr(), ptr::null_mut()) });
   out
 }
@@ -81,6 +83,9 @@ pub fn encode_batch(plan: &Plan, msgs: &DevicePoly, k: usize) -> DevicePoly {
 pub fn lde(plan_k: &Plan, plan_n: &Plan, evals: &DevicePoly, coset_shift: Goldilocks) -> (DevicePoly, DevicePoly) {
   assert!(plan_k.batch == plan_n.batch && plan_n.n() >= plan_k.n());
   assert!(evals.len() == plan_k.batch * plan_k.n());
+  assert!(plan_k.device() == plan_n.device(), "the two plans of an extension live on one GPU");
+  plan_k.same_device(evals);
+  let _g = OnDevice::new(plan_k.device());
   let coeffs = DevicePoly::alloc_on(evals.device(), evals.len());
   let out = DevicePoly::alloc_on(evals.device(), plan_n.batch * plan_n.n());
   check(unsafe {
@@ -91,7 +96,9 @@ pub fn lde(plan_k: &Plan, plan_n: &Plan, evals: &DevicePoly, coset_shift: Goldil
 
 /// `Message::decode` on device-resident coordinates (k of each); the reference's panics arrive through the status word
 pub fn decode_dev(xs: &DevicePoly, ys: &DevicePoly) -> DevicePoly {
-  assert!(xs.len() == ys.len() && xs.device() == ys.device());
+  assert!(xs.len() == ys.len());
+  xs.same_device(ys);
+  let _g = OnDevice::new(xs.device());   // `ronk_rs_decode_dev` (kernels and workspace) runs on the CURRENT device
   let k = xs.len();
   let out = DevicePoly::alloc_on(xs.device(), k);
   let status = DevicePoly::alloc_on(xs.device(), 1);

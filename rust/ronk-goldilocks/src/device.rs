@@ -37,6 +37,9 @@ pub struct Plan {
   raw:       *mut RonkPlan,
   pub log2n: u32,
   pub batch: usize,
+  /// the GPU the plan's tables and scratch live on (the current device at creation): every polynomial handed to it must
+  /// live there too -- its kernels dereference both
+  device:    i32,
 }
 // the library serialises concurrent calls on one plan internally (stream_mu / staging lock)
 unsafe impl Send for Plan {}
@@ -53,11 +56,19 @@ impl Plan {
 
   pub fn with_opts(log2n: u32, batch: usize, opts: RonkPlanOpts) -> Self {
     let mut raw: *mut RonkPlan = ptr::null_mut();
-    check(unsafe { ffi::ronk_plan_create_opts(&mut raw, P, G, log2n, batch as u64, -1, &opts) });
-    Self { raw, log2n, batch }
+    let device = current_device();
+    check(unsafe { ffi::ronk_plan_create_opts(&mut raw, P, G, log2n, batch as u64, device, &opts) });
+    Self { raw, log2n, batch, device }
   }
 
   pub fn n(&self) -> usize { 1usize << self.log2n }
+
+  pub fn device(&self) -> i32 { self.device }
+
+  /// panics unless `p` lives on the plan's GPU (a kernel of GPU a dereferencing memory of GPU b faults when peer access is off)
+  pub(crate) fn same_device(&self, p: &DevicePoly) {
+    assert!(p.device == self.device, "polynomial on GPU {} handed to a plan on GPU {}", p.device, self.device);
+  }
 
   /// the `ronk_plan*` for the crate's other modules (codes.rs)
   pub(crate) fn raw(&self) -> *mut RonkPlan { self.raw }
@@ -78,21 +89,29 @@ impl Plan {
   /// device-resident, asynchronous on the null stream; `src` and `dst` may be the same polynomial (see `*_in_place`)
   pub fn forward(&self, src: &DevicePoly, dst: &mut DevicePoly) {
     assert!(src.len == self.batch * self.n() && dst.len == src.len);
+    self.same_device(src); self.same_device(dst);
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_ntt_forward_dev(self.raw, src.ptr, dst.ptr, ptr::null_mut()) });
   }
 
   pub fn inverse(&self, src: &DevicePoly, dst: &mut DevicePoly) {
     assert!(src.len == self.batch * self.n() && dst.len == src.len);
+    self.same_device(src); self.same_device(dst);
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_ntt_inverse_dev(self.raw, src.ptr, dst.ptr, ptr::null_mut()) });
   }
 
   pub fn forward_in_place(&self, p: &mut DevicePoly) {
     assert!(p.len == self.batch * self.n());
+    self.same_device(p);
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_ntt_forward_dev(self.raw, p.ptr, p.ptr, ptr::null_mut()) });
   }
 
   pub fn inverse_in_place(&self, p: &mut DevicePoly) {
     assert!(p.len == self.batch * self.n());
+    self.same_device(p);
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_ntt_inverse_dev(self.raw, p.ptr, p.ptr, ptr::null_mut()) });
   }
 
@@ -100,15 +119,17 @@ impl Plan {
   /// store phases of one transform with the butterflies of another
   pub fn forward_many(&self, src: &[&DevicePoly], dst: &mut [&mut DevicePoly]) {
     assert!(src.len() == dst.len());
-    let ins: Vec<*const u64> = src.iter().map(|p| { assert!(p.len == self.batch * self.n()); p.ptr as *const u64 }).collect();
-    let outs: Vec<*mut u64> = dst.iter().map(|p| { assert!(p.len == self.batch * self.n()); p.ptr }).collect();
+    let ins: Vec<*const u64> = src.iter().map(|p| { assert!(p.len == self.batch * self.n()); self.same_device(p); p.ptr as *const u64 }).collect();
+    let outs: Vec<*mut u64> = dst.iter().map(|p| { assert!(p.len == self.batch * self.n()); self.same_device(p); p.ptr }).collect();
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_ntt_forward_many_dev(self.raw, ins.as_ptr(), outs.as_ptr(), ins.len(), ptr::null_mut()) });
   }
 
   pub fn inverse_many(&self, src: &[&DevicePoly], dst: &mut [&mut DevicePoly]) {
     assert!(src.len() == dst.len());
-    let ins: Vec<*const u64> = src.iter().map(|p| { assert!(p.len == self.batch * self.n()); p.ptr as *const u64 }).collect();
-    let outs: Vec<*mut u64> = dst.iter().map(|p| { assert!(p.len == self.batch * self.n()); p.ptr }).collect();
+    let ins: Vec<*const u64> = src.iter().map(|p| { assert!(p.len == self.batch * self.n()); self.same_device(p); p.ptr as *const u64 }).collect();
+    let outs: Vec<*mut u64> = dst.iter().map(|p| { assert!(p.len == self.batch * self.n()); self.same_device(p); p.ptr }).collect();
+    let _g = OnDevice::new(self.device);
     check(unsafe { ffi::ronk_ntt_inverse_many_dev(self.raw, ins.as_ptr(), outs.as_ptr(), ins.len(), ptr::null_mut()) });
   }
 }
@@ -139,10 +160,11 @@ pub fn current_device() -> i32 {
   d
 }
 
-/// selects `device` for the scope, restores the previous one on drop
-struct OnDevice(i32);
+/// selects `device` for the scope, restores the previous one on drop (crate-wide: codes.rs and bn254.rs bracket their FFI
+/// calls with it -- the `_dev` entry points run on the calling thread's CURRENT device)
+pub(crate) struct OnDevice(i32);
 impl OnDevice {
-  fn new(device: i32) -> Self {
+  pub(crate) fn new(device: i32) -> Self {
     let prev = current_device();
     if prev != device {
       check(unsafe { ffi::ronk_set_device(device) });
@@ -183,6 +205,11 @@ impl DevicePoly {
 
   pub fn device(&self) -> i32 { self.device }
 
+  /// panics unless `other` lives on the same GPU: the kernels of one GPU dereference both operands
+  pub(crate) fn same_device(&self, other: &DevicePoly) {
+    assert!(other.device == self.device, "operands on different GPUs ({} and {})", self.device, other.device);
+  }
+
   /// raw device pointers for the crate's other modules (codes.rs, bn254.rs) and for callers that bind further entry points
   pub fn as_ptr(&self) -> *const u64 { self.ptr }
 
@@ -219,6 +246,7 @@ impl DevicePoly {
 
   /// `impl Mul` (arithmetic.rs:97-119): `self.len + rhs.len - 1` coefficients; NTT - pointwise - inverse NTT on the device
   pub fn mul(&self, rhs: &DevicePoly) -> DevicePoly {
+    self.same_device(rhs);
     let _g = OnDevice::new(self.device);
     let out = DevicePoly::alloc_on(self.device, self.len + rhs.len - 1);
     check(unsafe { ffi::ronk_poly_mul_dev(P, G, self.ptr, self.len, rhs.ptr, rhs.len, out.ptr, ptr::null_mut()) });
@@ -247,6 +275,7 @@ impl DevicePoly {
 
   /// `self / rhs`, `self % rhs` for any divisor (quotient_and_remainder, mod.rs:170-225): both with `len` coefficients
   pub fn div_rem(&self, rhs: &DevicePoly) -> (DevicePoly, DevicePoly) {
+    self.same_device(rhs);
     let _g = OnDevice::new(self.device);
     let (quot, rem) = (DevicePoly::alloc_on(self.device, self.len), DevicePoly::alloc_on(self.device, self.len));
     let mut status = 0 as c_int;
@@ -274,6 +303,7 @@ impl DevicePoly {
     rhs: &DevicePoly,
     f: unsafe extern "C" fn(u64, *const u64, *const u64, *mut u64, usize, *mut c_void) -> c_int,
   ) -> DevicePoly {
+    self.same_device(rhs);
     let _g = OnDevice::new(self.device);
     assert!(self.len == rhs.len);
     let out = DevicePoly::alloc_on(self.device, self.len);

@@ -35,3 +35,13 @@ def test_gpus_must_match_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=120)
     assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+
+
+def test_free_port_and_default_gpus():
+    """no MASTER_PORT: the port comes from the kernel (bind to port 0), not from a formula; `torchrun ... bench.py` without
+    --gpus takes the launcher's WORLD_SIZE instead of aborting"""
+    cmd = bench.self_launch_command(2, {}, ["bench.py", "--gpus", "2"])
+    port = int(cmd[cmd.index("--master-port") + 1])
+    assert 1024 < port < 65536
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.gpus = int(os.environ.get("WORLD_SIZE", "1"))' in src
