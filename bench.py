@@ -63,7 +63,8 @@ KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", 
                   "ronkathon_amd/csrc/tile_kernels.hip", "ronkathon_amd/csrc/tile_kernels_cfg.hip",
                   "ronkathon_amd/csrc/tile_kernel_def.h", "ronkathon_amd/csrc/tile_cfg_table.h",
                   "ronkathon_amd/csrc/tile_kernels_half.hip", "ronkathon_amd/csrc/tile_kernels_feat.hip",
-                  "ronkathon_amd/csrc/field_policy.h", "ronkathon_amd/csrc/mont64.h", "ronkathon_amd/csrc/tile_kernels_mont.hip")
+                  "ronkathon_amd/csrc/field_policy.h", "ronkathon_amd/csrc/mont64.h", "ronkathon_amd/csrc/tile_kernels_mont.hip",
+                  "ronkathon_amd/csrc/tile_kernels_mont_feat.hip")
 VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
 
 

@@ -91,6 +91,9 @@ static hipError_t launch_one(const TileArgs& a, u32 grid, u32 block, size_t lds,
 // kernel for every pass size and the specialised shapes of RONK_CFG_TABLE; launch_small_mont: the latency form
 hipError_t launch_tile_mont(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s);
 hipError_t launch_small_mont(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s);
+// tile_kernels_mont_feat.hip: the shapes with features over a Montgomery prime; *found says whether there is one
+hipError_t launch_tile_mont_feat(int logr, bool inverse, int feat, const TileArgs& a, u32 grid, u32 block, size_t lds,
+                                 hipStream_t s, bool* found);
 // tile_kernels_cfg.hip: launches the specialised instantiation for (logr, a.logc, kind) if there is one; *found says so
 hipError_t launch_tile_cfg(int logr, bool inverse, int kind, const TileArgs& a, u32 grid, u32 block, size_t lds,
                            hipStream_t s, bool* found);

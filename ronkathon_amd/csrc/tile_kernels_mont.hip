@@ -59,6 +59,11 @@ static hipError_t launch_dir_mont(int logr, const TileArgs& a, u32 grid, u32 blo
 
 hipError_t launch_tile_mont(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s) {
   static const bool no_cfg = getenv("RONK_NO_CFG_KERNELS") != nullptr;
+  if (!no_cfg && tile_features(a) != 0) {   // the multiply's / the encode's passes (tile_kernels_mont_feat.hip)
+    bool found = false;
+    hipError_t e = launch_tile_mont_feat(logr, inverse, tile_features(a), a, grid, block, lds, s, &found);
+    if (found) return e;
+  }
   if (!no_cfg && tile_features(a) == 0) {
 #define RONK_MONT_CASE(LR, LC, KD)                                                               \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD))                        \

@@ -54,7 +54,17 @@ static bool dispatch_cfg(int logr, u32 tid) {
   const TileArgs& a = *g_fa.a;
   static const bool half = getenv("RONK_HALF_LDS") && atoi(getenv("RONK_HALF_LDS")) == 1;   // TileCfg::HALF instantiations
   if constexpr (FLD::MONT) {   // the shapes the library instantiates for Montgomery primes (tile_kernels_mont.hip): the plain table
-    if (tile_features(a)) return false;
+    if (const int feat = tile_features(a)) {   // ... and the feature shapes in the direction they occur in (tile_kernels_mont_feat.hip)
+#define EMU_MONT_FEAT_CASE(LR, LC, KD, FT)                                                       \
+  if (logr == LR && (int)a.logc == LC && feat == FT && INV == (FT != 1) && tile_cfg_matches(a, LR, LC, KD, FT)) { \
+    tile_body<LR, (FT != 1), 0, TileCfg<LC, KD, false, false, FT>, FLD>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
+    g_cfg_used = KD + 100 * FT;                                                                  \
+    return true;                                                                                 \
+  }
+      RONK_CFG_TABLE_FEAT(EMU_MONT_FEAT_CASE)
+#undef EMU_MONT_FEAT_CASE
+      return false;
+    }
 #define EMU_MONT_CASE(LR, LC, KD)                                                                \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
     tile_body<LR, INV, 0, TileCfg<LC, KD>, FLD>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier);      \

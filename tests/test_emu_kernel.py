@@ -56,6 +56,11 @@ def test_montgomery_primes_on_the_tile_kernels(emu, p, g):
     assert "kernel=small" in out                                 # the planner's latency form
     run(emu, 15, 2, 0, 4, 18, 25, 20000, 30000, 0, 9000, 1, env=e)   # in_valid / out_valid / in_valid1 / in2
     run(emu, 14, 1, 1, 2, 0, 13, env=e)                              # three passes (4, 5, 5)
+    if p > 2**63:   # the multiply's specialised feature shapes (tile_kernels_mont_feat.hip): padded pair forward, in2 + truncation inverse
+        out = run(emu, 20, 2, 0, 2, 18, 25, 300000, 0, 0, 7, env=e)
+        assert "feat:column" in out
+        out = run(emu, 20, 1, 1, 2, 18, 25, 0, 700001, 0, 0, 1, env=e)
+        assert "feat:column" in out and "feat:row" in out
 
 
 def test_montgomery_dist_phases(emu):
