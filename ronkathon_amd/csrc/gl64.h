@@ -219,4 +219,33 @@ RONK_HD u64 mul_2exp(u64 x) {
   }
 }
 
+// -x * 2^K for a compile-time 0 <= K < 96 (i.e. x * 2^(K + 96): the upper half of the powers of two, 2^96 = -1).  The negation
+// rides on the last subtraction of mul_2exp where there is one (K >= 32: operands swapped, no extra instruction); K < 32 pays
+// a negation (4 VALU).  Input: any 64-bit value; output canonical.
+template <int K>
+RONK_HD u64 mul_2exp_neg(u64 x) {
+  static_assert(K >= 0 && K < 96, "shift out of range");
+  constexpr int q = K / 32, s = K % 32;
+  const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+  u32 y0, y1, y2;
+  if constexpr (s == 0) {
+    y0 = x0; y1 = x1; y2 = 0;
+  } else {
+    y0 = x0 << s;
+    y1 = (x1 << s) | (x0 >> ((32 - s) & 31));
+    y2 = x1 >> ((32 - s) & 31);
+  }
+  if constexpr (q == 0) {
+    const u64 n = ((u64)y1 << 32) | y0;
+    return sub(0, mad_eps_canon(y2, n));                      // 0 - r: r canonical
+  } else if constexpr (q == 1) {
+    const u64 r = mad_eps_canon(y1, (u64)y0 << 32);           // canonical
+    return sub((u64)y2, r);                                   // y2 - r (+ p)
+  } else {
+    const u64 t = (u64)y0 * 0xFFFFFFFFu;                      // < p
+    const u64 m = ((u64)y2 << 32) | y1;                       // < p
+    return sub(m, t);
+  }
+}
+
 }  // namespace gl64

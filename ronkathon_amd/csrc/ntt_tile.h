@@ -202,15 +202,47 @@ RONK_HD void st_out(u64* p, u64 v) {
 //   FEAT_KEEP       the results stay in the lane's registers -- no output twiddle, no scale, no store (three-round passes
 //                   only): register r = g*RLAST + i ends with output row m + M*keep_row_digit(r) of column c.  Never a launch
 //                   feature (tile_features() does not report it): the fused multiply (ntt_mul.h) instantiates it directly.
+// R4 (round 5): passes of 2^9 / 2^10 rows as [16 . 4] . [8 | 16] instead of (16, 16, 2 | 4) -- three rounds either way, but the
+// twiddle after the first round is a SHIFT: with the row group m = a*B + m' (B = R/64 rows per 64-point block, a in [0, 4)) the
+// factor omega_R^(m k1) splits into omega_64^(a k1) = +-2^K, applied at once, and omega_R^(m' k1), which does not depend on a,
+// commutes with the 4-point transform over a and merges with the next layer: ONE table twiddle omega_R^(m' (k1 + 16 k_a)) per
+// pass instead of two.  `a` is the top of the lane's row group: wave-uniform whenever B * C >= 64 (cfg_r4 below), so the shift
+// amounts are selected by ONE scalar branch among compile-time mul_2exp bodies.  Measured trade: a table layer costs 26.3
+// issue slots per coefficient, the shift layer 12.0 (profiles/r05_arith_variants.txt).  Goldilocks only (the Montgomery
+// roots are no powers of two); not with the half-size LDS image, not with FEAT_KEEP.
 constexpr int FEAT_IN_VALID = 1, FEAT_IN2 = 2, FEAT_OUT_VALID = 4, FEAT_KEEP = 8;
-template <int LOGC_, int KIND_, bool LDSTW_ = false, bool HALF_ = false, int FEAT_ = 0>
+template <int LOGC_, int KIND_, bool LDSTW_ = false, bool HALF_ = false, int FEAT_ = 0, bool R4_ = false>
 struct TileCfg {
   static constexpr int LOGC = LOGC_;
   static constexpr int KIND = KIND_;
   static constexpr bool LDSTW = LDSTW_;
   static constexpr bool HALF = HALF_;
   static constexpr int FEAT = FEAT_;
+  static constexpr bool R4 = R4_;
 };
+// which specialised shapes can run the R4 round structure: the 64-point block's row count B = R/64 times the tile width
+// must cover a wavefront, so that the digit a = m / B is wave-uniform
+constexpr bool cfg_r4(int logr, int logc, int kind) {
+  return (logr == 9 || logr == 10) && kind >= 1 && kind <= 3 && logc >= 0 && (logr - 6 + logc) >= 6;
+}
+// a value every lane of the wavefront agrees on, as a scalar (device: an SGPR)
+RONK_HD u32 wave_uniform(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+// x[i] *= omega_64^(A * brev4(i)) (forward) or its inverse: register i of a 16-point DIF round holds output k1 = brev4(i)
+template <int A, bool INV, int I = 0>
+RONK_HD void shift_layer64(u64* x) {
+  if constexpr (I < 16) {
+    constexpr int E = root_exp(64, (A * brev(I, 4)) % 64, INV);
+    if constexpr (E >= 96) x[I] = gl64::mul_2exp_neg<E - 96>(x[I]);
+    else if constexpr (E > 0) x[I] = gl64::mul_2exp<E>(x[I]);
+    shift_layer64<A, INV, I + 1>(x);
+  }
+}
 // which specialised instantiations stage their round twiddles in LDS (launcher, emulator and kernel agree through this).
 // MEASURED AND SWITCHED OFF (round 2, 2^22, 2^11 x 8 tiles, the only shape where 16 KiB fit beside the image without
 // costing a resident workgroup): pass 1 / pass 2 33.8 / 24.4 us with the staged table against 31.1 / 22.9 us with the
@@ -434,14 +466,17 @@ RONK_HD void tile_load(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barri
 template <int LOGR, bool INV, int ABL = 0, class CFG = TileCfg<-1, 0>, class FLD = GlField, class Barrier>
 RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Barrier&& barrier) {
   constexpr int R = 1 << LOGR;
+  // R4: rounds of radix 16, 4, RLAST = R/64 (TileCfg::R4); otherwise radices 16, .., 16, 2^LOGLAST
+  constexpr bool R4 = CFG::R4 && (LOGR == 9 || LOGR == 10) && !FLD::MONT && !CFG::HALF && !(CFG::FEAT & FEAT_KEEP);
   constexpr int Q = (LOGR + 3) / 4;              // rounds
-  constexpr int LOGLAST = LOGR - 4 * (Q - 1);    // 1..4
+  constexpr int LOGLAST = R4 ? LOGR - 6 : LOGR - 4 * (Q - 1);    // 1..4
   constexpr int RLAST = 1 << LOGLAST;
   constexpr int M = R / 16;                      // threads per column
   constexpr int KIND = CFG::KIND;
   constexpr bool NARROW = KIND != 0;
   constexpr int SH = NARROW ? 3 : 0;             // lane offsets in bytes (NARROW) or elements
   static_assert(LOGR >= 4 && LOGR <= 12, "pass size");
+  static_assert(!R4 || (CFG::LOGC >= 0 && LOGLAST + CFG::LOGC >= 6), "R4: the digit a = m / RLAST must be wave-uniform");
   const TileArgs& a = cx.a;
   const u32 logc = cx.logc, C = cx.C, c = cx.c, m = cx.m, t = cx.t, b1 = cx.b1, b2 = cx.b2, col0 = cx.col0, col = cx.col;
   u64* out = cx.out;
@@ -467,7 +502,8 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
   (void)T; (void)stage_valid;
 
   // rounds that are followed by a table twiddle on every output but X[0] take the lazy last stage
-  if (!(ABL & 4)) { if (Q > 1) Dif<16, INV, true, FLD>::run(x, f); else Dif<16, INV, false, FLD>::run(x, f); }
+  // (R4: a wavefront with a == 0 parks its round-1 results without any twiddle, so they stay canonical)
+  if (!(ABL & 4)) { if (Q > 1 && !R4) Dif<16, INV, true, FLD>::run(x, f); else Dif<16, INV, false, FLD>::run(x, f); }
 
   if (Q > 1) {
     u64* const lc = lds + c;
@@ -488,11 +524,26 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
     const u32 park1 = ((m + (m >> 4)) << logc) + c;
     auto p1cell = [&](int i) -> u32 {   // LDS cell that register i of round 1 is parked in
       const u32 k1 = brev(i, 4);
-      if (Q == 3) return park1 + ((u32)(k1 * (M + M / 16)) << logc);
+      if (Q == 3 || R4) return park1 + ((u32)(k1 * (M + M / 16)) << logc);
       const u32 blk = (k1 & (M - 1)) * (16 / RLAST) + k1 / M;
       return (swz_row(blk * M + m) << logc) + c;
     };
     (void)lc;
+    if constexpr (R4) {
+      // omega_R^(m k1) = omega_64^(a k1) * omega_R^(m' k1), m = a*RLAST + m': the first factor is +-2^K with a wave-uniform a
+      // (one scalar branch, compile-time shifts), the second waits for the table layer after the 4-point round
+      if (!(ABL & 2)) {
+        switch (wave_uniform(m >> LOGLAST)) {
+          case 0: break;
+          case 1: shift_layer64<1, INV>(x); break;
+          case 2: shift_layer64<2, INV>(x); break;
+          default: shift_layer64<3, INV>(x); break;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (!(ABL & 8)) lds[p1cell(i)] = x[i];
+    } else {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
@@ -504,6 +555,7 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
         if (HALF) l32[cell] = (u32)x[i]; else lds[cell] = x[i];
       }
     }
+    }
     if (!(ABL & 8)) barrier();
 
     // round-2 lane coordinates (Q == 3): thread (d1, d3) = (m / RLAST, m % RLAST); its results are parked at p2cell(i)
@@ -513,7 +565,38 @@ RONK_HD void tile_compute(const TileCtx& cx, u64* lds, u32 tid, u64 (&x)[16], Ba
       const u32 k2 = brev(i, 4);
       return park2 + ((u32)(272 * (k2 % RLAST) + RLAST * (k2 / RLAST)) << logc);
     };
-    if (Q == 3) {
+    if constexpr (R4) {
+      // ---- round 2 (R4): lane (g, m') = (m / RLAST, m % RLAST) takes the four 4-point transforms over a for k1 = g + 4t,
+      // t = 0..3: register 4t + a <- row k1*M + a*RLAST + m'  (swz: k1*(M + M/16) + a*RLAST + (a*RLAST)/16 + m', since
+      // (a*RLAST) mod 16 + m' < 16 for RLAST = 8, 16)
+      const u32 rd2 = ((d1 * (u32)(M + M / 16) + d3) << logc) + c;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int tt = i >> 2, aa = i & 3;
+        if (!(ABL & 8)) x[i] = lds[rd2 + ((u32)(4 * tt * (M + M / 16) + aa * RLAST + (aa * RLAST) / 16) << logc)];
+      }
+      if (!(ABL & 8)) barrier();   // not in place: everything is read before anything is parked
+      if (!(ABL & 4)) {
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) Dif<4, INV, true, FLD>::run(x + 4 * tt, f, false);   // every output meets the table twiddle next
+      }
+      // omega_R^(m' (k1 + 16 k_a)), k1 = g + 4t, k_a = brev2(a'): byte offsets e0 + (t + 4 k_a) * (32 m') by an add chain
+      u32 ch[16];
+      ch[0] = (d1 * d3) << 3;
+      const u32 st4 = d3 << 5;
+#pragma unroll
+      for (int j = 1; j < 16; j++) ch[j] = ch[j - 1] + st4;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int tt = i >> 2, ka = brev(i & 3, 2);
+        if (!(ABL & 2)) x[i] = f.mul(x[i], (ABL & 64) ? ((u64)ch[tt + 4 * ka] * 0x9E3779B97F4A7C15ull >> 1) : ld_tabb(a.wr, ch[tt + 4 * ka]));
+        // park at the last round's group slot of kl = k1 + 16 k_a (same rule as the three-round tiles below):
+        // row = 16 (kl mod M) + RLAST (kl div M) + m'  ->  swz = 17 (g + 4t + 16 (k_a mod (M/16))) + RLAST (k_a div (M/16)) + m'
+        constexpr int KM = M / 16;   // 4 (RLAST 16) or 2 (RLAST 8)
+        if (!(ABL & 8)) lds[park2 + ((u32)(17 * (4 * tt + 16 * (ka % KM)) + RLAST * (ka / KM)) << logc)] = x[i];
+      }
+      if (!(ABL & 8)) barrier();
+    } else if (Q == 3) {
       // ---- round 2: thread (d1, d3) = (m / RLAST, m % RLAST), register digit d2
       // rows d1*16*RLAST + d3 + i*RLAST: swz = (17*RLAST*d1 + d3) + (i*RLAST + i*RLAST/16)     (d3 + (i*RLAST mod 16) < 16)
       const u32 rd2 = ((d1 * (17 * RLAST) + d3) << logc) + c;

@@ -87,6 +87,10 @@ static hipError_t launch_one(const TileArgs& a, u32 grid, u32 block, size_t lds,
   return hipGetLastError();
 }
 
+// tile_kernels_r4.hip: the 2^9 / 2^10-row shapes of RONK_CFG_TABLE with the [16 . 4] . [8 | 16] round structure (TileCfg::R4:
+// one table-twiddle layer and one wave-uniform shift layer per pass instead of two table layers); *found = there is one
+hipError_t launch_tile_r4(int logr, bool inverse, int kind, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s,
+                          bool* found);
 // tile_kernels_mont.hip: the same bodies over a Montgomery prime (field_policy.h MontField; TileArgs::fc.p != 0) -- the generic
 // kernel for every pass size and the specialised shapes of RONK_CFG_TABLE; launch_small_mont: the latency form
 hipError_t launch_tile_mont(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds, hipStream_t s);

@@ -59,6 +59,16 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
         hipError_t e = launch_tile_cfg_half(logr, inverse, kind, a, grid, block, lds, s, &found);
         if (found) return e;
       }
+      // 2^9 / 2^10-row passes: the [16 . 4] . [8 | 16] round structure (tile_kernels_r4.hip), OPT-IN with RONK_R4MID=1.
+      // Measured (round 5, same box, A/B/A/B: profiles/r05_r4_ab.txt): it executes 5.5 % fewer VALU instructions per pass
+      // (one table-twiddle layer traded for a wave-uniform shift layer) and is not faster anywhere -- one 2^20 transform
+      // 27.7 -> 28.1 us, two lanes 17.05 -> 17.3 us per transform, 64 x 2^20 / 256 x 2^18 / 2^24 .. 2^26 within +-1 % -- so
+      // the (16, 16, 2 | 4) kernels stay the default.
+      static const bool r4_on = [] { const char* e_ = getenv("RONK_R4MID"); return e_ && atoi(e_) != 0; }();
+      if (r4_on && kind < 4 && (logr == 9 || logr == 10)) {
+        hipError_t e = launch_tile_r4(logr, inverse, kind, a, grid, block, lds, s, &found);
+        if (found) return e;
+      }
       hipError_t e = launch_tile_cfg(logr, inverse, kind, a, grid, block, lds, s, &found);
       if (found) return e;
     }

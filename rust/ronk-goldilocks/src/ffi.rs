@@ -87,6 +87,11 @@ extern "C" {
     out: *mut *mut RonkPlan, p: u64, g: u64, log2n: u32, batch: u64, device: c_int, opts: *const RonkPlanOpts,
   ) -> c_int;
   pub fn ronk_plan_in_flight(plan: *const RonkPlan) -> c_int;
+  /// which kernels the plan runs: 1 = tiled Goldilocks, 2 = the tile kernels over Montgomery arithmetic (any other odd prime whose
+  /// g is a quadratic non-residue), 0 = the radix-2 path
+  pub fn ronk_plan_path(plan: *const RonkPlan) -> c_int;
+  /// `PrimeField::new`'s `is_prime` assertion (src/algebra/field/prime/mod.rs:48-51) as a deterministic Miller-Rabin
+  pub fn ronk_check_prime(p: u64) -> c_int;
   pub fn ronk_plan_destroy(plan: *mut RonkPlan) -> c_int;
   /// host pointers through the plan's pinned staging ring (`nodes` may be null)
   pub fn ronk_ntt_forward(plan: *mut RonkPlan, input: *const u64, output: *mut u64, nodes: *mut u64) -> c_int;

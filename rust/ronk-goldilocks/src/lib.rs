@@ -8,6 +8,9 @@
 //!   `kzg::{commit, open}` to `PlutoScalarField` / `PlutoExtendedCurve` (src/kzg/setup.rs:48-78); they keep working on the
 //!   small fields they were written for, and their 64-bit counterparts are [`codes`] (same `Message` / `Codeword` /
 //!   `Coordinate` shapes over `Goldilocks`) and [`bn254`] + `DevicePoly::div_linear` (commit / open on BN254).
+//! * [`prime64::Prime64`] -- the same for ANY odd 64-bit prime, modulus and primitive element as const generics: the 64-bit
+//!   counterpart of the reference's generic `PrimeField<const P: usize>`; its arrays run the same tile kernels over Montgomery
+//!   arithmetic ([`prime64::AcceleratedPrime`], [`prime64::PrimePlan`]).
 //! * [`polynomial::Accelerated`] / [`polynomial::AcceleratedLagrange`] -- `fft` / `ifft` / `dft` / `Mul` / `Div` / `Rem` /
 //!   `evaluate` on the GPU through the C ABI (include/ronk_ntt.h), bit-exact with the reference's CPU results.
 //! * [`device::HeapPoly`] / [`device::DevicePoly`] / [`device::Plan`] / [`device::ShardedPlan`] -- heap- and HBM-resident
@@ -31,7 +34,9 @@ pub mod device;
 pub mod ffi;
 pub mod field;
 pub mod polynomial;
+pub mod prime64;
 
 pub use device::{DevicePoly, Exchange, HeapPoly, Plan, ShardedPlan};
 pub use field::Goldilocks;
 pub use polynomial::{rs_decode, Accelerated, AcceleratedLagrange};
+pub use prime64::{AcceleratedPrime, AcceleratedPrimeLagrange, Prime64, PrimePlan};

@@ -1,5 +1,5 @@
 /* test_rust_ffi_replay.c -- replays, in plain C through the real libronk_ntt.so, the FFI call sequence of the Rust shim
- * rust/ronk-goldilocks (src/polynomial.rs, device.rs, codes.rs, bn254.rs): the same entry points, argument order, buffer shapes (`[u64; D]` arrays, a
+ * rust/ronk-goldilocks (src/polynomial.rs, prime64.rs, device.rs, codes.rs, bn254.rs): the same entry points, argument order, buffer shapes (`[u64; D]` arrays, a
  * D-element node vector, NULL never passed where the shim passes a pointer) and the same error-code -> panic mapping.
  * Results are checked against the oracle's restatement of the reference (oracle/ronk_oracle.c, the CHECKER).
  * TEST INFRASTRUCTURE; built and run by tests/test_cpp_host_mirror.py (needs a GPU to run). */
@@ -286,6 +286,45 @@ static void replay_placement(int ndev) {
   free(x); free(ref); free(got); free(blk);
 }
 
+/* prime64.rs: Prime64::<P, G>::assert_prime, AcceleratedPrime::{fft_gpu, dft_gpu, evaluate_gpu, mul_gpu,
+ * quotient_and_remainder_gpu}, AcceleratedPrimeLagrange::ifft_gpu, PrimePlan::{new, path, forward, inverse} for a generic odd
+ * 64-bit prime: the same entry points as for Goldilocks with p = P2, g = G2 (the tile kernels over Montgomery arithmetic) */
+static void replay_prime64(uint64_t P2, uint64_t G2, size_t D, size_t D2) {
+  EXPECT(ronk_check_prime(P2) == 0, "Prime64::assert_prime");
+  uint64_t *c = malloc(D * 8), *b = malloc(D2 * 8), *out = calloc(D, 8), *nodes = calloc(D, 8), *ref = calloc(D + D2, 8), *back = calloc(D, 8);
+  for (size_t i = 0; i < D; i++) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; c[i] = rng_state % P2; }
+  for (size_t i = 0; i < D2; i++) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; b[i] = rng_state % P2; }
+  EXPECT(ronk_fft(P2, G2, c, out, nodes, D) == 0, "prime64 ronk_fft");
+  EXPECT(orc_fft(P2, G2, c, ref, D) == 0 && !memcmp(out, ref, D * 8), "prime64 fft values");
+  EXPECT(orc_lagrange_nodes(P2, G2, ref, D) == 0 && !memcmp(nodes, ref, D * 8), "prime64 fft nodes");
+  EXPECT(ronk_ifft(P2, G2, out, back, D) == 0 && !memcmp(back, c, D * 8), "prime64 ifft round trip");
+  memset(out, 0, D * 8);
+  EXPECT(ronk_dft(P2, G2, c, out, D) == 0 && ronk_lagrange_nodes(P2, G2, nodes, D) == 0, "prime64 ronk_dft + nodes");
+  EXPECT(orc_fft(P2, G2, c, ref, D) == 0 && !memcmp(out, ref, D * 8), "prime64 dft values");
+  uint64_t y = 0, x = c[D / 2];
+  EXPECT(ronk_poly_eval(P2, c, D, x, &y) == 0 && y == orc_poly_eval(P2, c, D, x), "prime64 evaluate");
+  uint64_t* prod = calloc(D + D2 - 1, 8);
+  EXPECT(ronk_poly_mul(P2, G2, c, D, b, D2, prod) == 0, "prime64 ronk_poly_mul");
+  orc_poly_mul(P2, c, D, b, D2, ref);
+  EXPECT(!memcmp(prod, ref, (D + D2 - 1) * 8), "prime64 mul values");
+  if (D <= 4096) {
+    uint64_t *q = calloc(D, 8), *r = calloc(D, 8), *qr = calloc(D, 8), *rr = calloc(D, 8);
+    EXPECT(ronk_poly_divrem(P2, c, D, b, D2, q, r) == 0, "prime64 ronk_poly_divrem");
+    EXPECT(orc_poly_divrem(P2, c, D, b, D2, qr, rr) == 0 && !memcmp(q, qr, D * 8) && !memcmp(r, rr, D * 8), "prime64 divrem values");
+    free(q); free(r); free(qr); free(rr);
+  }
+  /* PrimePlan::new(log2n, 1): ronk_plan_create(&raw, P, G, log2n, 1, -1); path(); forward; inverse; drop */
+  unsigned lg = 0; while (((size_t)1 << lg) < D) lg++;
+  ronk_plan* pl = NULL;
+  EXPECT(ronk_plan_create(&pl, P2, G2, lg, 1, -1) == 0, "PrimePlan::new");
+  EXPECT(ronk_plan_path(pl) == (lg >= 4 ? 2 : 0), "PrimePlan::path: the tile kernels over Montgomery arithmetic");
+  memset(out, 0, D * 8);
+  EXPECT(ronk_ntt_forward(pl, c, out, NULL) == 0 && orc_fft(P2, G2, c, ref, D) == 0 && !memcmp(out, ref, D * 8), "PrimePlan::forward");
+  EXPECT(ronk_ntt_inverse(pl, out, back) == 0 && !memcmp(back, c, D * 8), "PrimePlan::inverse");
+  EXPECT(ronk_plan_destroy(pl) == 0, "PrimePlan drop");
+  free(c); free(b); free(out); free(nodes); free(ref); free(back); free(prod);
+}
+
 int main(void) {
   int ndev = 0;
   if (ronk_device_count(&ndev) != 0 || ndev < 1) { printf("no device\n"); return 2; }
@@ -302,6 +341,10 @@ int main(void) {
   replay_sharded(16); replay_sharded(20);
   replay_codes();
   replay_placement(ndev);
+  /* prime64.rs: a prime above 2^63 (2-adicity 34), one below 2^62, a 32-bit one */
+  replay_prime64(0xFFFFFFFC00000001ull, 10, 16, 3); replay_prime64(0xFFFFFFFC00000001ull, 10, 4096, 100);
+  replay_prime64(0xFFFFFFFC00000001ull, 10, 1u << 16, 5); replay_prime64(0x3A00000000000001ull, 3, 1u << 14, 1u << 14);
+  replay_prime64(0xC0000001ull, 5, 1024, 1024);
   /* rs_decode::<K> */
   { enum { K = 64 };
     uint64_t xs[K], *ys = fresh(K), out[K], ref[K];

@@ -97,6 +97,20 @@ static bool dispatch_cfg(int logr, u32 tid) {
 #undef EMU_FEAT_CASE
     if (feat) return false;
   }
+  // the R4 round structure of the 2^9 / 2^10-row shapes (tile_kernels_r4.hip; opt-in with RONK_R4MID=1 like the library)
+  static const bool r4_on = getenv("RONK_R4MID") && atoi(getenv("RONK_R4MID")) != 0;
+  if (r4_on && (logr == 9 || logr == 10)) {
+#define EMU_R4_CASE(LR, LC, KD)                                                                  \
+  if constexpr (cfg_r4(LR, LC, KD)) {                                                            \
+    if (logr == LR && (int)a.logc == LC && KD < 4 && tile_cfg_matches(a, LR, LC, KD)) {          \
+      tile_body<LR, INV, 0, TileCfg<LC, KD, false, false, 0, true>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
+      g_cfg_used = KD + 20;                                                                      \
+      return true;                                                                               \
+    }                                                                                            \
+  }
+    RONK_CFG_TABLE(EMU_R4_CASE)
+#undef EMU_R4_CASE
+  }
 #define EMU_CFG_CASE(LR, LC, KD)                                                                 \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
     tile_body<LR, INV, 0, TileCfg<LC, KD, cfg_ldstw(LR, LC, KD)>>(a, g_fa.lds, tid, g_fa.bid, fiber_barrier); \
@@ -409,7 +423,7 @@ int main(int argc, char** argv) {
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
            g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 5 ? "cfg:whole" : g_cfg_used == 4 ? "cfg:general" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
-           g_cfg_used == 12 ? "half:row" : g_cfg_used >= 100 ? (g_cfg_used % 100 == 2 ? "feat:row" : g_cfg_used % 100 == 3 ? "feat:column/matrix" : "feat:column/two-level") :
+           g_cfg_used == 12 ? "half:row" : g_cfg_used == 21 ? "r4:column/two-level" : g_cfg_used == 23 ? "r4:column/matrix" : g_cfg_used == 22 ? "r4:row" : g_cfg_used >= 100 ? (g_cfg_used % 100 == 2 ? "feat:row" : g_cfg_used % 100 == 3 ? "feat:column/matrix" : "feat:column/two-level") :
            p.small ? "small" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = (b && in_valid1) ? in_valid1 : in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen

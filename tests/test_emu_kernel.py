@@ -330,3 +330,12 @@ def test_linear_division_kernels_on_fibers(emu_scan, direct):
     run(emu_scan, 101, 300, 0, 1, direct)
     run(emu_scan, 2, 3000, 1, 1, direct)
     run(emu_scan, GP, 700001, 987654321987, 3, direct, 5)       # 342 chunks: two sums per lane for the low chunks
+
+
+@pytest.mark.parametrize("args", [(20, 1, 0, 4), (20, 1, 1, 3), (20, 1, 0, 2), (19, 2, 1, 4, 18), (18, 1, 0, 4, 18), (21, 1, 0, 2, 21)])
+def test_r4_round_structure(emu, args):
+    """TileCfg::R4 (tile_kernels_r4.hip, opt-in RONK_R4MID=1): passes of 2^9 / 2^10 rows as [16 . 4] . [8 | 16] -- a wave-uniform
+    shift layer omega_64^(a k1) after the first round, ONE table twiddle after the 4-point round -- column passes with both
+    inter-pass twiddle forms, row passes, forward and inverse, 4 / 8 / 16-column tiles; every output against the oracle"""
+    out = run(emu, *args, env={"RONK_R4MID": "1"})
+    assert "kernel=r4:" in out

@@ -1320,6 +1320,36 @@ def test_large_plans_whole_vector(R, orc, k):
     plan.close()
 
 
+def test_r4_round_structure_opt_in():
+    """RONK_R4MID=1 (read once per process: a subprocess): the 2^9 / 2^10-row passes as [16 . 4] . [8 | 16] with a wave-uniform
+    shift layer (tile_kernels_r4.hip) -- forward and inverse against the oracle at sizes whose plans contain such passes, one
+    transform and batched"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from ronkathon_amd import _lib as L
+import oracle as orc
+from conftest import splitmix_field
+P, G = 0xFFFFFFFF00000001, 7
+for k, batch, opts in ((18, 1, {}), (19, 1, {}), (20, 1, {}), (20, 3, {"tile_log2_columns": 2}), (21, 1, {}), (19, 5, {"tile_log2_columns": 4}), (24, 1, {})):
+    n = 1 << k
+    x = splitmix_field(0xA400 + k, n * batch)
+    plan = L.Plan(P, G, k, batch, **opts)
+    y, z = plan.forward(x), plan.inverse(x)
+    for b in range(batch):
+        assert np.array_equal(y[b * n:(b + 1) * n], orc.fft(P, G, x[b * n:(b + 1) * n])), (k, b)
+        assert np.array_equal(z[b * n:(b + 1) * n], orc.ifft(P, G, x[b * n:(b + 1) * n])), (k, b)
+    plan.close()
+print("R4 OK")
+""" % (root, root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, RONK_R4MID="1"))
+    assert out.returncode == 0 and "R4 OK" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+
+
 def test_sharded_peer_access_is_reported(R, orc):
     """the outcome of hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess is kept per rank pair and reported
     (ronk_sharded_plan_peer_access), never discarded.  Logical ranks on one device are SAME_DEVICE; with more than one visible
