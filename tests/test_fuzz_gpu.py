@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_seeded_fuzz_sweep():
-    env = dict(os.environ, FUZZ_SEED="4", FUZZ_SECONDS="33")
+    env = dict(os.environ, FUZZ_SEED="4", FUZZ_SECONDS="36")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py")], env=env, capture_output=True, text=True,
                        timeout=900)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])

@@ -4,7 +4,8 @@ the fixed cases live in tests/).  usage: FUZZ_SEED=n FUZZ_SECONDS=s python tools
 
 Sections (all by default, each gets an equal share of the time): ntt (plans of random size / batch / direction / planner
 options, host and device forms, several arrays per call), mul (products of random lengths, incl. the fused N = 2^21 / 2^22
-path), generic (transforms, products, dft over small primes and non-power-of-two sizes), divrem (general divisors incl.
+path), generic (transforms, products, dft over small primes and non-power-of-two sizes), mont (random NTT-friendly primes of
+33 .. 64 bits on the Montgomery tile path: transforms, products, dft), divrem (general divisors incl.
 trailing zeros and the Newton path), lindiv (division by a linear divisor + evaluate, whole-vector recurrence), codes
 (Reed-Solomon encode / decode / LDE), vec (element-wise operators incl. zero inverses), lagrange (barycentric evaluate), msm (BN254 G1 against known multiples of G),
 sharded (the in-library four-step plan with 1 .. 8 logical ranks on this GPU), threads (four host threads, null stream and own
@@ -182,6 +183,102 @@ def sec_generic(deadline):
         elif (p - 1) % (1 << (d1 + d2 - 2).bit_length()) == 0:
             report("generic", "poly_mul rc", p, d1, d2, rc)
     counts["generic"] = it
+
+
+def _is_prime(n):
+    if n < 2:
+        return False
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % a == 0:
+            return n == a
+    d, s_ = n - 1, 0
+    while d % 2 == 0:
+        d //= 2; s_ += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s_ - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def random_ntt_prime(min_adicity):
+    """a random odd prime c * 2^t + 1 below 2^64 with t >= min_adicity, of a random bit length (33 .. 64), and a quadratic
+    non-residue g: every such (p, g) runs the tile kernels over Montgomery arithmetic (ronk_plan_path() == 2)"""
+    while True:
+        bits = rng.randrange(max(33, min_adicity + 2), 65)
+        t = rng.randrange(min_adicity, min(bits - 1, 40))
+        c = rng.randrange(1 << (bits - t - 1), 1 << (bits - t)) | 1
+        p = c * (1 << t) + 1
+        if p < (1 << 64) and p != GP and _is_prime(p):
+            g = next(x for x in range(2, 200) if pow(x, (p - 1) // 2, p) == p - 1)
+            return p, g
+
+
+def sec_mont(deadline):
+    """random NTT-friendly primes of every bit length on the Montgomery tile path: transforms of random size / batch / planner
+    options (host and device forms), products through the NTT path against the schoolbook oracle, dft, round trips"""
+    it = 0
+    while time.time() < deadline:
+        it += 1
+        k = rng.choice([rng.randrange(4, 13), rng.randrange(13, 19), rng.randrange(19, 23)])
+        p, g = random_ntt_prime(max(k, 12))
+        n = 1 << k
+        batch = rng.choice([1, 1, 2, 3, 5, 17, 40]) if k <= 16 else (rng.choice([1, 2, 3]) if k <= 19 else 1)
+        opts = {}
+        if rng.random() < 0.5:
+            opts = dict(tile_log2_columns=rng.choice([-1, 2, 3, 4]), twiddle_matrix_log2_max=rng.choice([-1, 0, 18, 25]),
+                        in_flight=rng.choice([-1, 1, 2]))
+        x = edge_values(p, n * batch, it)
+        try:
+            plan = L.Plan(p, g, k, batch, **opts)
+        except L.RonkPanic as e:
+            if opts:
+                continue
+            report("mont", "plan_create", hex(p), g, k, batch, str(e)); continue
+        if plan.path() != 2:
+            report("mont", "path", hex(p), g, k, plan.path())
+        want = np.concatenate([orc.fft(p, g, x[b * n:(b + 1) * n]) for b in range(batch)])
+        y = plan.forward(x)
+        if not np.array_equal(y, want):
+            report("mont", "forward", hex(p), g, k, batch, opts)
+        wanti = np.concatenate([orc.ifft(p, g, x[b * n:(b + 1) * n]) for b in range(batch)])
+        if not np.array_equal(plan.inverse(x), wanti):
+            report("mont", "inverse", hex(p), g, k, batch, opts)
+        dx = dev(x); dy = torch.empty_like(dx)
+        plan.forward_dev(dx.data_ptr(), dy.data_ptr())
+        plan.inverse_dev(dy.data_ptr(), dy.data_ptr())
+        torch.cuda.synchronize()
+        if not np.array_equal(host(dy), x):
+            report("mont", "inverse_dev(forward_dev) in place", hex(p), g, k, batch, opts)
+        plan.close()
+        # products: short ones against the schoolbook definition, longer ones against three oracle transforms
+        d1, d2 = (rng.randrange(40, 3000), rng.randrange(30, 3000)) if rng.random() < 0.6 else (rng.randrange(1, 1 << 17), rng.randrange(1, 1 << 17))
+        m = d1 + d2 - 1
+        N = 1 << max(4, (m - 1).bit_length())
+        if (p - 1) % N == 0:
+            a = edge_values(p, d1, 5 * it); b = edge_values(p, d2, 5 * it + 1)
+            prod = np.empty(m, dtype=np.uint64)
+            L.check(L.lib.ronk_poly_mul(p, g, L.ptr(a), d1, L.ptr(b), d2, L.ptr(prod)))
+            if d1 * d2 <= 9_000_000:
+                ok = np.array_equal(prod, orc.poly_mul(p, a, b))
+            else:
+                pa = np.zeros(N, dtype=np.uint64); pa[:d1] = a
+                pb = np.zeros(N, dtype=np.uint64); pb[:d2] = b
+                ok = np.array_equal(prod, orc.ifft(p, g, orc.vec_mul(p, orc.fft(p, g, pa), orc.fft(p, g, pb)))[:m])
+            if not ok:
+                report("mont", "poly_mul", hex(p), g, d1, d2)
+        if k <= 14:
+            out = np.empty(n, dtype=np.uint64)
+            L.check(L.lib.ronk_dft(p, g, L.ptr(x[:n]), L.ptr(out), n))
+            if not np.array_equal(out, want[:n]):
+                report("mont", "dft", hex(p), g, n)
+    counts["mont"] = it
 
 
 def sec_divrem(deadline):
@@ -506,7 +603,7 @@ def sec_threads(deadline):
     counts["threads"] = total[0]
 
 
-SECTIONS = dict(ntt=sec_ntt, mul=sec_mul, generic=sec_generic, divrem=sec_divrem, lindiv=sec_lindiv, codes=sec_codes, vec=sec_vec,
+SECTIONS = dict(ntt=sec_ntt, mul=sec_mul, generic=sec_generic, mont=sec_mont, divrem=sec_divrem, lindiv=sec_lindiv, codes=sec_codes, vec=sec_vec,
                 lagrange=sec_lagrange, msm=sec_msm, sharded=sec_sharded, threads=sec_threads)
 
 
