@@ -21,7 +21,7 @@ clean:
 .PHONY: all oracle clean
 
 # Sanitizer builds of the host-side code: the oracle under ASan+UBSan, the field header and the
-# tile kernel body + planner (the host emulator) under UBSan (ASan does not follow the emulator's ucontext fibers).
+# tile kernel body + planner (the host emulator; Goldilocks and Montgomery field policies, the R4 round structure) under UBSan (ASan does not follow the emulator's ucontext fibers).
 SAN = -g -O1 -fno-omit-frame-pointer -fno-sanitize-recover=all
 sanitize:
 	@mkdir -p build/san
@@ -40,6 +40,9 @@ sanitize:
 	./build/san/emu_tile 20 1 0 3 | tail -1
 	./build/san/emu_tile dist 16 4 0 0 2 | tail -1
 	./build/san/emu_tile mul 20 300001 7 2 18 | tail -1
+	RONK_EMU_P=0xFFFFFFFC00000001 RONK_EMU_G=10 ./build/san/emu_tile 16 2 1 4 18 | tail -1
+	RONK_EMU_P=0xc0000001 RONK_EMU_G=5 ./build/san/emu_tile 12 3 0 4 | tail -1
+	RONK_R4MID=1 ./build/san/emu_tile 19 1 0 4 18 | tail -1
 	./build/san/emu_scan 18446744069414584321 70001 123456789 3 1 | tail -1
 	./build/san/emu_scan 101 5000 7 3 0 | tail -1
 .PHONY: sanitize
