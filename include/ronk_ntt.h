@@ -229,7 +229,7 @@ int ronk_rs_encode_batch_dev(ronk_plan* plan, const uint64_t* d_msgs, size_t k, 
 /* Low-degree extension: a batch of polynomials given by their values on {omega_K^i} (plan_k: n = K) -> their values on
  * coset_shift * {omega_N^i} (plan_n: n = N >= K, same batch and modulus).  = Message::encode::<N> of lagrange_poly.ifft()
  * (src/polynomial/mod.rs:430-453, src/codes/reed_solomon.rs:42-52), the coefficients multiplied by coset_shift^i first when
- * coset_shift != 1 (Goldilocks only).  d_coeffs: batch x K scratch that receives the coefficients; d_out: batch x N. */
+ * coset_shift != 1 (any field; 0 is RONK_ERR_UNSUPPORTED).  d_coeffs: batch x K scratch that receives the coefficients; d_out: batch x N. */
 int ronk_lde_batch_dev(ronk_plan* plan_k, ronk_plan* plan_n, const uint64_t* d_evals, uint64_t* d_coeffs, uint64_t* d_out,
                        uint64_t coset_shift, void* stream);
 

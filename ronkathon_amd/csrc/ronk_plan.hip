@@ -349,9 +349,10 @@ extern "C" int ronk_rs_encode_batch_dev(ronk_plan* pl, const uint64_t* d_msgs, s
 // K-point domain {omega_K^i} -> their values on shift * {omega_N^i}, N >= K.  In the reference's terms:
 // `Message::encode::<N>` of `lagrange_poly.ifft()` (src/polynomial/mod.rs:430-453, src/codes/reed_solomon.rs:42-52), with the
 // coefficients scaled by shift^i first when a coset is asked for (shift = 1: the plain extension).
-__global__ void __launch_bounds__(256) lde_coset_scale_kernel(u64* __restrict__ c, size_t k, size_t total, u64 shift) {
+template <class Ops>
+__global__ void __launch_bounds__(256) lde_coset_scale_kernel(Ops ops, u64* __restrict__ c, size_t k, size_t total, u64 shift) {
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x)
-    c[t] = gl64::mul(c[t], gl64::pow(shift, (u64)(t % k)));
+    c[t] = ops.mul(c[t], ops.pow(shift, (u64)(t % k)));
 }
 extern "C" int ronk_lde_batch_dev(ronk_plan* plan_k, ronk_plan* plan_n, const uint64_t* d_evals, uint64_t* d_coeffs,
                                   uint64_t* d_out, uint64_t coset_shift, void* st) {
@@ -360,10 +361,11 @@ extern "C" int ronk_lde_batch_dev(ronk_plan* plan_k, ronk_plan* plan_n, const ui
   hipStream_t s = (hipStream_t)st;
   RCHK(transform_dev(plan_k, true, d_evals, nullptr, d_coeffs, s));            // [batch][K] coefficients
   coset_shift %= plan_k->p;
-  if (coset_shift != 1) {
-    if (coset_shift == 0 || plan_k->p != RONK_GOLDILOCKS_P) return RONK_ERR_UNSUPPORTED;
+  if (coset_shift != 1) {   // c_i <- c_i * shift^i (any field: the element-wise operators of field_kernels.h)
+    if (coset_shift == 0) return RONK_ERR_UNSUPPORTED;
     const size_t total = plan_k->n * plan_k->batch;
-    hipLaunchKernelGGL(lde_coset_scale_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_coeffs, (size_t)plan_k->n, total, coset_shift);
+    FIELD_DISPATCH(plan_k->field, { hipLaunchKernelGGL((lde_coset_scale_kernel<decltype(ops)>), dim3(grid_for(total)), dim3(256), 0, s, ops,
+                                                       d_coeffs, (size_t)plan_k->n, total, coset_shift); });
     HIPCHK(hipGetLastError());
   }
   return ronk_rs_encode_batch_dev(plan_n, d_coeffs, plan_k->n, d_out, st);

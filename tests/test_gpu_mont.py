@@ -174,3 +174,51 @@ def test_mont_non_generator_keeps_radix2_path(L, orc):
     x = splitmix_field(5, 1 << 10, p)
     assert np.array_equal(plan.forward(x), orc.fft(p, g, x))
     plan.close()
+
+
+@pytest.mark.parametrize("p,g", PRIMES[:2])
+def test_mont_rs_encode_batch_and_lde(L, orc, p, g):
+    """the batched Reed-Solomon encode (src/codes/reed_solomon.rs:42-52: y_i = message(omega_N^i), compact messages, implicit zero
+    padding) and the plain low-degree extension (ifft on the small domain, encode on the large one) over a Montgomery prime:
+    multi-pass plans read the messages in place through the padding feature, single-pass plans pad first"""
+    import torch
+    torch.zeros(1).cuda()
+    for k2, batch, K in ((13, 7, 5000), (16, 24, 32768), (10, 5, 300), (14, 3, 1)):
+        n = 1 << k2
+        msgs = splitmix_field(k2 * 100 + batch, batch * K, p)
+        dm = torch.from_numpy(msgs.view(np.int64)).cuda()
+        dy = torch.full((batch * n,), -1, dtype=torch.int64, device="cuda")
+        plan = L.Plan(p, g, k2, batch)
+        assert plan.path() == 2
+        plan.rs_encode_batch_dev(dm.data_ptr(), K, dy.data_ptr(), 0)
+        torch.cuda.synchronize()
+        got = dy.cpu().numpy().view(np.uint64)
+        for b in range(batch):
+            pad = np.zeros(n, dtype=np.uint64); pad[:K] = msgs[b * K:(b + 1) * K]
+            assert np.array_equal(got[b * n:(b + 1) * n], orc.fft(p, g, pad)), (k2, b)
+        plan.close()
+    # LDE with shift 1: values on the 2^12-point domain -> values on the 2^14-point domain
+    kk, kn, batch = 12, 14, 6
+    coeffs = splitmix_field(0xE1, batch << kk, p)
+    pk, pn = L.Plan(p, g, kk, batch), L.Plan(p, g, kn, batch)
+    evals = pk.forward(coeffs)
+    de = torch.from_numpy(evals.view(np.int64)).cuda()
+    dc = torch.empty_like(de)
+    dout = torch.empty(batch << kn, dtype=torch.int64, device="cuda")
+    L.check(L.lib.ronk_lde_batch_dev(pk.h, pn.h, de.data_ptr(), dc.data_ptr(), dout.data_ptr(), 1, 0))
+    torch.cuda.synchronize()
+    assert np.array_equal(dc.cpu().numpy().view(np.uint64), coeffs)
+    got = dout.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        pad = np.zeros(1 << kn, dtype=np.uint64); pad[:1 << kk] = coeffs[b << kk:(b + 1) << kk]
+        assert np.array_equal(got[b << kn:(b + 1) << kn], orc.fft(p, g, pad)), b
+    # on a coset: values of the same polynomials at shift * omega_N^i = the transform of c_i * shift^i
+    shift = 7
+    L.check(L.lib.ronk_lde_batch_dev(pk.h, pn.h, de.data_ptr(), dc.data_ptr(), dout.data_ptr(), shift, 0))
+    torch.cuda.synchronize()
+    got = dout.cpu().numpy().view(np.uint64)
+    pw = np.array([pow(shift, i, p) for i in range(1 << kk)], dtype=np.uint64)
+    for b in (0, batch - 1):
+        pad = np.zeros(1 << kn, dtype=np.uint64); pad[:1 << kk] = orc.vec_mul(p, coeffs[b << kk:(b + 1) << kk], pw)
+        assert np.array_equal(got[b << kn:(b + 1) << kn], orc.fft(p, g, pad)), b
+    pk.close(); pn.close()
