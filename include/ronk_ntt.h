@@ -119,7 +119,9 @@ typedef struct ronk_plan_opts {
   int in_flight;                /* -1 auto, 1, 2 */
   int split_log2_rows;          /* two-pass plans (2^13 .. 2^24): log2 of the first pass's rows, 0 = the planner's (balanced)
                                    choice; values that leave a pass outside 2^4 .. 2^12 rows are ignored */
-  int reserved[4];              /* zero */
+  int reserved[4];              /* zero.  reserved[0], when in 13 .. 25: the smallest log2n that is split in THREE passes (the
+                                   planner's default is 23 -- 24 for ONE transform of 2^23 --; the fused multiply asks for two-pass
+                                   plans of a batch of two at 2^23).  The other three stay zero */
 } ronk_plan_opts;
 #define RONK_PLAN_OPTS_DEFAULT { -1, -1, -1, 0, { 0, 0, 0, 0 } }
 int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,

@@ -137,6 +137,7 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // generic first pass, 110 with the (12, 2, 1) shape); batches of 2^23 keep three passes (measured in round 2).
     int three_from = (log2n == 23 && batch == 1) ? 24 : 23;
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
+    if (opts && opts->reserved[0] >= 13 && opts->reserved[0] <= 25) three_from = opts->reserved[0];   // (include/ronk_ntt.h)
     rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
     if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
     for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
@@ -787,8 +788,20 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     // 2^21 all four within 1 %.  Default: the forward pair keeps the two-level tables at 2^22, the inverse runs the cached
     // plan as it is.
     const int ftw = fwd_twf != -2 ? fwd_twf : (k == 22 ? 18 : -1), itw = inv_twf != -2 ? inv_twf : -1;
-    if (!e->pl2) RCHK(k >= 20 ? ronk_plan_create_tuned(&e->pl2, p, g, (u32)k, 2, pl->device, 2, ftw)
-                              : ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
+    static const bool fused23 = [] { const char* e_ = getenv("RONK_MUL_FUSED23"); return !e_ || atoi(e_) != 0; }();
+    if (!e->pl2) {
+      if (k >= 20) {
+        // N = 2^23 (round 5): the pair as a TWO-pass plan (2^12 x 2^11, which the planner gives only to a single transform of
+        // that size) so that its row pass -- 2^11 rows, 4-column tiles -- feeds the fused middle like at 2^21 / 2^22
+        ronk_plan_opts o = RONK_PLAN_OPTS_DEFAULT;
+        o.tile_log2_columns = 2;
+        o.twiddle_matrix_log2_max = ftw;
+        if (k == 23 && fused23 && !pl->mont_tiled) o.reserved[0] = 24;
+        RCHK(ronk_plan_create_opts(&e->pl2, p, g, (u32)k, 2, pl->device, &o));
+      } else {
+        RCHK(ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
+      }
+    }
     if (itw >= 0 && !e->pli) RCHK(ronk_plan_create_tuned(&e->pli, p, g, (u32)k, 1, pl->device, -1, itw));
     const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
     // Fused middle (ntt_mul.h): forward row pass of both operands + pointwise product + inverse column pass in ONE launch --
@@ -800,14 +813,15 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     // Measured (round 4, same box, us per product): 2^22 158.6 -> 132.6, 2^21 88.0 -> 80.6, but 2^20 63.1 -> 68.1 -- there a
     // pass has 256 tiles of four wavefronts, one wavefront per SIMD, and three transforms in sequence inside a workgroup are
     // three times one wavefront's dependent instruction stream; the four-launch form spreads them over twice the tiles.
-    if (fused_on && (k == 21 || k == 22) && !pl->mont_tiled) {   // (the fused middle is instantiated for Goldilocks)
+    if (fused_on && (k == 21 || k == 22 || (k == 23 && fused23)) && !pl->mont_tiled) {   // (the fused middle is instantiated for Goldilocks)
       if (!e->plf) {
         // the inverse whose COLUMN pass has the rows of the pair plan's ROW pass: the balanced split for even k, the other
         // split of an odd one (2^21: pair plan 2^11 x 2^10, inverse 2^10 x 2^11)
         ronk_plan_opts o = RONK_PLAN_OPTS_DEFAULT;
         o.tile_log2_columns = 2;
         o.twiddle_matrix_log2_max = inv_twf != -2 ? inv_twf : 18;
-        o.split_log2_rows = k / 2;
+        o.split_log2_rows = k / 2;          // 2^21: 2^10 x 2^11, 2^22: 2^11 x 2^11, 2^23: 2^11 x 2^12
+        if (k == 23) o.reserved[0] = 24;    // two passes
         RCHK(ronk_plan_create_opts(&e->plf, p, g, (u32)k, 1, pl->device, &o));
       }
       const CompiledPlan& F = e->pl2->fwd;

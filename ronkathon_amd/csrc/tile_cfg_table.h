@@ -21,8 +21,8 @@
 // The same shapes with FEATURES (TileCfg::FEAT, ntt_tile.h): X(LOGR, LOGC, KIND, FEAT).  1 = zero-padded input (the forward
 // transforms of a polynomial multiply, a batched Reed-Solomon encode), 2 = second operand multiplied in on load (the inverse
 // transform of a multiply, first pass), 4 = truncated output (its last pass).  NTT sizes 2^20 .. 2^22 of the multiply; the
-// 1024 x 2^16 encode.
+// 1024 x 2^16 encode.  (12, 2, 1, 1) / (12, 2, 2, 4): the first and the last launch of the fused multiply at N = 2^23 (round 5).
 #define RONK_CFG_TABLE_FEAT(X)                                                                \
-  X(10, 2, 1, 1) X(11, 2, 1, 1) X(11, 2, 3, 1) X(8, 4, 3, 1)                                  \
+  X(10, 2, 1, 1) X(11, 2, 1, 1) X(11, 2, 3, 1) X(8, 4, 3, 1) X(12, 2, 1, 1)                   \
   X(10, 2, 1, 2) X(11, 2, 1, 2) X(11, 3, 1, 2) X(11, 2, 3, 2) X(11, 3, 3, 2)                  \
-  X(10, 2, 2, 4) X(10, 3, 2, 4) X(11, 3, 2, 4) X(11, 2, 2, 4)
+  X(10, 2, 2, 4) X(10, 3, 2, 4) X(11, 3, 2, 4) X(11, 2, 2, 4) X(12, 2, 2, 4)

@@ -93,10 +93,11 @@ def test_tuned_tile_widths(emu, k, logc):
 
 @pytest.mark.parametrize("k,d,d2,logc,twf", [(20, 1 << 19, 1 << 19, 2, 18), (20, 300001, 7, 2, 20), (20, 1, 1 << 20, 2, 18),
                                              (22, 1 << 21, 1 << 21, 2, 18), (22, (1 << 21) + 5, (1 << 21) - 4, 2, 22),
-                                             (21, 1 << 20, 1 << 20, 2, 18), (21, 700001, 900000, 2, 21)])
+                                             (21, 1 << 20, 1 << 20, 2, 18), (21, 700001, 900000, 2, 21),
+                                             (23, (1 << 22) + 1, (1 << 22) - 104, 2, 18)])
 def test_fused_multiply_middle(emu, k, d, d2, logc, twf):
     """ntt_mul.h: the multiply's forward row pass of both operands + product + inverse column pass as ONE tile body (what
-    ronk_plan.hip conv_dev launches at 2^20 / 2^22), every product coefficient against the oracle; ragged operand lengths,
+    ronk_plan.hip conv_dev launches at 2^21 / 2^22 / 2^23), every product coefficient against the oracle; ragged operand lengths,
     both inverse twiddle forms (two-level tables / full matrix)"""
     run(emu, "mul", k, d, d2, logc, twf)
 
