@@ -333,7 +333,7 @@ def test_linear_division_kernels_on_fibers(emu_scan, direct):
     run(emu_scan, GP, 700001, 987654321987, 3, direct, 5)       # 342 chunks: two sums per lane for the low chunks
 
 
-@pytest.mark.parametrize("args", [(20, 1, 0, 4), (20, 1, 1, 3), (20, 1, 0, 2), (19, 2, 1, 4, 18), (18, 1, 0, 4, 18), (21, 1, 0, 2, 21)])
+@pytest.mark.parametrize("args", [(20, 1, 1, 3), (19, 2, 1, 4, 18), (18, 1, 0, 4, 18), (21, 1, 0, 2, 21)])
 def test_r4_round_structure(emu, args):
     """TileCfg::R4 (tile_kernels_r4.hip, opt-in RONK_R4MID=1): passes of 2^9 / 2^10 rows as [16 . 4] . [8 | 16] -- a wave-uniform
     shift layer omega_64^(a k1) after the first round, ONE table twiddle after the 4-point round -- column passes with both
