@@ -31,7 +31,9 @@ RONK_HD void mul_mid_opaque(u32& t) {
 // fa: the forward plan's ROW pass (KIND 2 shape, batch of two: polynomial b1 = 0 is a, 1 is b; in = its scratch)
 // ia: the inverse plan's COLUMN pass (KIND 1 or 3 shape; out = the inverse plan's scratch; `in` is not read)
 // bid in [0, tiles): the same tile number on both sides (same tile width: LOGC)
-template <int LOGR, int LOGC, int KINDI, class Barrier>
+// FLD: the field policy (field_policy.h) -- Goldilocks, or a Montgomery prime (round 5: the product of two canonical values is
+// mul_plain = mmul(mmul(x, y), R^2); fa.fc / ia.fc carry the prime)
+template <int LOGR, int LOGC, int KINDI, class FLD = GlField, class Barrier>
 RONK_HD void mul_mid_body(const TileArgs& fa, const TileArgs& ia, u64* lds, u32 tid, u32 bid, Barrier&& barrier) {
   static_assert(LOGR >= 9 && LOGR <= 12, "three-round passes");
   typedef TileCfg<LOGC, 2, false, false, FEAT_KEEP> CF;
@@ -45,8 +47,8 @@ RONK_HD void mul_mid_body(const TileArgs& fa, const TileArgs& ia, u64* lds, u32 
   mul_mid_opaque(t1);
   {
     const TileCtx cx = tile_ctx<LOGR, CF>(fa, t1, bid);
-    tile_load<LOGR, false, 0, CF>(cx, lds, t1, x, barrier);
-    tile_compute<LOGR, false, 0, CF>(cx, lds, t1, x, barrier);
+    tile_load<LOGR, false, 0, CF, FLD>(cx, lds, t1, x, barrier);
+    tile_compute<LOGR, false, 0, CF, FLD>(cx, lds, t1, x, barrier);
   }
 #pragma unroll
   for (int r = 0; r < 16; r++) ya[keep_row_digit(LOGR, r)] = x[r];
@@ -54,16 +56,19 @@ RONK_HD void mul_mid_body(const TileArgs& fa, const TileArgs& ia, u64* lds, u32 
   mul_mid_opaque(t2);
   {
     const TileCtx cx = tile_ctx<LOGR, CF>(fa, t2, bid + fa.tiles);   // b1 = 1
-    tile_load<LOGR, false, 0, CF>(cx, lds, t2, x, barrier);
-    tile_compute<LOGR, false, 0, CF>(cx, lds, t2, x, barrier);
+    tile_load<LOGR, false, 0, CF, FLD>(cx, lds, t2, x, barrier);
+    tile_compute<LOGR, false, 0, CF, FLD>(cx, lds, t2, x, barrier);
   }
+  {
+    const FLD f(fa.fc);
 #pragma unroll
-  for (int r = 0; r < 16; r++) y[keep_row_digit(LOGR, r)] = gl64::mul(ya[keep_row_digit(LOGR, r)], x[r]);
+    for (int r = 0; r < 16; r++) y[keep_row_digit(LOGR, r)] = f.mul_plain(ya[keep_row_digit(LOGR, r)], x[r]);
+  }
   barrier();
   mul_mid_opaque(t3);
   {
     const TileCtx cx = tile_ctx<LOGR, CI>(ia, t3, bid);
-    tile_compute<LOGR, true, 0, CI>(cx, lds, t3, y, barrier);
+    tile_compute<LOGR, true, 0, CI, FLD>(cx, lds, t3, y, barrier);
   }
 }
 

@@ -796,7 +796,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
         ronk_plan_opts o = RONK_PLAN_OPTS_DEFAULT;
         o.tile_log2_columns = 2;
         o.twiddle_matrix_log2_max = ftw;
-        if (k == 23 && fused23 && !pl->mont_tiled) o.reserved[0] = 24;
+        if (k == 23 && fused23) o.reserved[0] = 24;
         RCHK(ronk_plan_create_opts(&e->pl2, p, g, (u32)k, 2, pl->device, &o));
       } else {
         RCHK(ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
@@ -813,7 +813,8 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     // Measured (round 4, same box, us per product): 2^22 158.6 -> 132.6, 2^21 88.0 -> 80.6, but 2^20 63.1 -> 68.1 -- there a
     // pass has 256 tiles of four wavefronts, one wavefront per SIMD, and three transforms in sequence inside a workgroup are
     // three times one wavefront's dependent instruction stream; the four-launch form spreads them over twice the tiles.
-    if (fused_on && (k == 21 || k == 22 || (k == 23 && fused23)) && !pl->mont_tiled) {   // (the fused middle is instantiated for Goldilocks)
+    // (instantiated for Goldilocks -- tile_kernels_mul.hip -- and for Montgomery primes -- tile_kernels_mont_mul.hip)
+    if (fused_on && (k == 21 || k == 22 || (k == 23 && fused23))) {
       if (!e->plf) {
         // the inverse whose COLUMN pass has the rows of the pair plan's ROW pass: the balanced split for even k, the other
         // split of an odd one (2^21: pair plan 2^11 x 2^10, inverse 2^10 x 2^11)
@@ -835,11 +836,14 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
         //  pl2->d_tmp and plf->d_tmp are used directly, without stream_mu / scratch_acquire / scratch_release: both plans are
         //  private to this cache entry, and every use of the entry is serialised by g_cache_mu (held here) + e->done -- that
         //  pair is the ONLY guard of these two scratch buffers.)
-        if (mul_mid_matches(fa, ia, fp.logr, (int)fa.logc, kindi) && mul_mid_available(fp.logr, (int)fa.logc, kindi)) {
+        const bool mont = pl->mont_tiled;
+        if (mul_mid_matches(fa, ia, fp.logr, (int)fa.logc, kindi) &&
+            (mont ? mul_mid_available_mont(fp.logr, (int)fa.logc, kindi) : mul_mid_available(fp.logr, (int)fa.logc, kindi))) {
           HIPCHK(hipStreamWaitEvent(s, e->done, 0));
           RCHK(F.launch(0, d_a, nullptr, nullptr, e->pl2->d_tmp, s, (u64)d, ~(u64)0, stride, 0, 0, 0, (u64)d2));
           bool found = false;
-          hipError_t he = launch_mul_mid(fp.logr, kindi, fa, ia, fa.tiles, fp.block, fp.lds_bytes, s, &found);
+          hipError_t he = mont ? launch_mul_mid_mont(fp.logr, kindi, fa, ia, fa.tiles, fp.block, fp.lds_bytes, s, &found)
+                               : launch_mul_mid(fp.logr, kindi, fa, ia, fa.tiles, fp.block, fp.lds_bytes, s, &found);
           if (he != hipSuccess) return hip_fail(he, "launch_mul_mid");
           if (found) {
             RCHK(I.launch(1, nullptr, nullptr, d_out, e->plf->d_tmp, s, ~(u64)0, (u64)m));

@@ -16,4 +16,8 @@ hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32
 bool mul_mid_available(int logr, int logc, int kindi);
 hipError_t launch_mul_mid(int logr, int kindi, const TileArgs& fa, const TileArgs& ia, u32 grid, u32 block, size_t lds_bytes,
                           hipStream_t stream, bool* found);
+// the same over a Montgomery prime (tile_kernels_mont_mul.hip; fa.fc / ia.fc carry it)
+bool mul_mid_available_mont(int logr, int logc, int kindi);
+hipError_t launch_mul_mid_mont(int logr, int kindi, const TileArgs& fa, const TileArgs& ia, u32 grid, u32 block, size_t lds_bytes,
+                               hipStream_t stream, bool* found);
 }

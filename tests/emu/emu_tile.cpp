@@ -267,7 +267,10 @@ static MidArgs g_mid;
 static void mid_fiber(int tid) {
   const MidArgs& m = g_mid;
 #define EMU_MID_CASE(LR, LC, KD) \
-  if (m.logr == LR && m.logc == LC && m.kindi == KD) mul_mid_body<LR, LC, KD>(*m.fa, *m.ia, m.lds, (u32)tid, m.bid, fiber_barrier);
+  if (m.logr == LR && m.logc == LC && m.kindi == KD) { \
+    if (g_mont) mul_mid_body<LR, LC, KD, MontField>(*m.fa, *m.ia, m.lds, (u32)tid, m.bid, fiber_barrier); \
+    else mul_mid_body<LR, LC, KD>(*m.fa, *m.ia, m.lds, (u32)tid, m.bid, fiber_barrier); \
+  }
   EMU_MID_CASE(10, 2, 1) EMU_MID_CASE(10, 2, 3) EMU_MID_CASE(11, 2, 1) EMU_MID_CASE(11, 2, 3) EMU_MID_CASE(10, 3, 1) EMU_MID_CASE(11, 3, 1)
 #undef EMU_MID_CASE
   g_done[tid] = 1;
@@ -310,12 +313,12 @@ static TileArgs bind_pass(const PlanDesc& pd, size_t idx, const u64* in, u64* ou
 static int mul_main(int log2n, u64 d, u64 d2, int logc, int inv_twf) {
   const u64 n = (u64)1 << log2n, m = d + d2 - 1;
   if (m > n) { printf("operands too long\n"); return 2; }
-  PlanDesc F = build_plan(log2n, 2, false, logc, 18), I = build_plan(log2n, 1, true, logc, inv_twf, 25, false, log2n / 2);
+  PlanDesc F = build_plan(log2n, 2, false, logc, 18, 25, false, 0, g_hf), I = build_plan(log2n, 1, true, logc, inv_twf, 25, false, log2n / 2, g_hf);
   std::vector<u64> ab(2 * n, 0x1111), ftmp(2 * n, 0xDEADBEEFull), itmp(n, 0xDEADBEEFull), out(n, 0xDEADBEEFull), ref(m);
   u64 s = 0x5EED0C00ull + log2n;
-  for (u64 i = 0; i < d; i++) { do ab[i] = splitmix(s); while (ab[i] >= gl64::P); }
-  for (u64 i = 0; i < d2; i++) { do ab[n + i] = splitmix(s); while (ab[n + i] >= gl64::P); }
-  ab[0] = gl64::P - 1; ab[n + d2 - 1] = gl64::P - 1;
+  for (u64 i = 0; i < d; i++) ab[i] = rnd_elem(s);
+  for (u64 i = 0; i < d2; i++) ab[n + i] = rnd_elem(s);
+  ab[0] = g_p - 1; ab[n + d2 - 1] = g_p - 1;
   std::vector<u64> lds;
   {   // F1: column pass of the batch of two, padding limits d / d2
     TileArgs a = bind_pass(F, 0, ab.data(), nullptr, ftmp.data());
@@ -349,9 +352,9 @@ static int mul_main(int log2n, u64 d, u64 d2, int logc, int inv_twf) {
   // tests/test_oracle_golden.py) -- three oracle transforms
   std::vector<u64> pa(n, 0), pb(n, 0), fa_(n), fb_(n), pr(n);
   memcpy(pa.data(), ab.data(), d * 8); memcpy(pb.data(), ab.data() + n, d2 * 8);
-  if (orc_fft(gl64::P, 7, pa.data(), fa_.data(), n) || orc_fft(gl64::P, 7, pb.data(), fb_.data(), n)) return 1;
-  for (u64 i = 0; i < n; i++) fa_[i] = orc_mul(gl64::P, fa_[i], fb_[i]);
-  if (orc_ifft(gl64::P, 7, fa_.data(), pr.data(), n)) return 1;
+  if (orc_fft(g_p, g_g, pa.data(), fa_.data(), n) || orc_fft(g_p, g_g, pb.data(), fb_.data(), n)) return 1;
+  for (u64 i = 0; i < n; i++) fa_[i] = orc_mul(g_p, fa_[i], fb_[i]);
+  if (orc_ifft(g_p, g_g, fa_.data(), pr.data(), n)) return 1;
   for (u64 i = 0; i < n; i++) {
     if (i >= m) { if (out[i] != 0xDEADBEEFull) { printf("store beyond the product at %llu\n", (unsigned long long)i); return 1; } continue; }
     if (out[i] != pr[i]) { printf("MUL MISMATCH at %llu: got %llu want %llu\n", (unsigned long long)i, (unsigned long long)out[i], (unsigned long long)pr[i]); return 1; }

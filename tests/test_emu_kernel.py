@@ -63,6 +63,14 @@ def test_montgomery_primes_on_the_tile_kernels(emu, p, g):
         assert "feat:column" in out and "feat:row" in out
 
 
+def test_montgomery_fused_multiply_middle(emu):
+    """ntt_mul.h over a Montgomery prime (tile_kernels_mont_mul.hip): row pass of both operands, product of canonical values as
+    two Montgomery products, inverse column pass; both inverse twiddle forms, ragged lengths"""
+    p, g = MONT_PRIMES[0]
+    run(emu, "mul", 22, 2097157, 2097148, 2, 18, env=mont_env(p, g))
+    run(emu, "mul", 21, 700001, 900000, 2, 21, env=mont_env(p, g))
+
+
 def test_montgomery_dist_phases(emu):
     """the four-step phase builders take the field as well (plan.h build_dist_phase1 / 2 with a HostField)"""
     p, g = MONT_PRIMES[0]
