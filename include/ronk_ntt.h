@@ -258,6 +258,24 @@ int ronk_curve_msm(const ronk_curve* curve, const uint64_t* points, size_t n_poi
 int ronk_msm_bn254(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out[8]);
 int ronk_msm_bn254_dev(const uint64_t* d_points, const uint64_t* d_scalars, size_t n, uint64_t out[8], void* stream);
 
+/* kzg::open on the same curve (src/kzg/setup.rs:63-78): `poly.div([-eval_point, ONE])` over the SCALAR field of BN254,
+ * r = 21888242871839275222246405745257275088548364400416034343698204186575808495617, then `commit(quotient, g1_srs)`.
+ * coeffs: n x 4 words (4 x 64-bit little-endian limbs, standard form; taken mod r), ascending degree.  z: 4 words.
+ * ronk_poly_div_linear_bn254_dev: the division alone -- quotient_and_remainder with a monic linear divisor
+ * (src/polynomial/mod.rs:170-225): d_quot receives n entries, the top one ZERO (the reference's D-long quotient), d_rem
+ * (device, 4 words, may be NULL) the remainder's constant term poly(z).  A suffix scan over 256-bit elements
+ * (csrc/fr_scan_kernels.h, csrc/bn254_fr.h); synchronises `stream` (the multiplier tables are per call).
+ * ronk_kzg_open_bn254(_dev): the division followed by ronk_msm_bn254_dev over (srs, quotient) -- the opening proof -- and
+ * poly(z) in out_value (may be NULL).  srs: n x 8 words (points as for ronk_msm_bn254); n_srs < n is the reference's
+ * assert (RONK_ERR_INDEX); the _dev form takes device-resident coefficients / SRS and an n x 4-word device buffer for
+ * the quotient. */
+int ronk_poly_div_linear_bn254_dev(const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t* d_quot, uint64_t* d_rem,
+                                   void* stream);
+int ronk_kzg_open_bn254_dev(const uint64_t* d_coeffs, size_t n, const uint64_t z[4], const uint64_t* d_srs, uint64_t* d_quot,
+                            uint64_t out_point[8], uint64_t out_value[4], void* stream);
+int ronk_kzg_open_bn254(const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t* srs, size_t n_srs,
+                        uint64_t out_point[8], uint64_t out_value[4]);
+
 /* ---- multi-GPU four-step building blocks (one process per GPU; the exchange between the two
  *      phases is an RCCL all-to-all issued by the host side, see ronkathon_amd/dist.py) ----
  * n = 2^log2n split as R x C with R = 2^(log2n - log2n/2) rows and C = 2^(log2n/2) columns;

@@ -81,3 +81,23 @@ def multiples(n, start=G):
         out.append(cur)
         cur = add(cur, start)
     return out
+
+
+def fr_div_linear(coeffs, z):
+    """`poly.div([-z, ONE])` over the scalar field F_r (src/kzg/setup.rs:70-74 through quotient_and_remainder,
+    src/polynomial/mod.rs:170-225, with a monic linear divisor): the D-long quotient (top entry ZERO) and the remainder's
+    constant term poly(z).  Synthetic division: q[j-1] = c[j] + z q[j]."""
+    n = len(coeffs)
+    q = [0] * n
+    acc = 0
+    for j in range(n - 1, 0, -1):
+        acc = (int(coeffs[j]) + z * acc) % R
+        q[j - 1] = acc
+    return q, (int(coeffs[0]) + z * acc) % R if n else 0
+
+
+def kzg_open(coeffs, z, srs):
+    """`kzg::open` (src/kzg/setup.rs:63-78): commit(quotient of poly by (x - z), srs)"""
+    assert len(srs) >= len(coeffs)
+    q, value = fr_div_linear(coeffs, z % R)
+    return msm(srs, q), value

@@ -100,6 +100,9 @@ _SIG = {
     "ronk_curve_msm": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "ronk_msm_bn254": (_int, [_vp, _vp, _sz, _vp]),
     "ronk_msm_bn254_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "ronk_poly_div_linear_bn254_dev": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    "ronk_kzg_open_bn254_dev": (_int, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ronk_kzg_open_bn254": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp]),
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
     "ronk_dist_plan_destroy": (_int, [_vp]),
     "ronk_dist_plan_create_chunked": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int, _int]),

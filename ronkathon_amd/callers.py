@@ -99,3 +99,23 @@ def msm_bn254(points, scalars):
     x = sum(int(out[i]) << (64 * i) for i in range(4))
     y = sum(int(out[4 + i]) << (64 * i) for i in range(4))
     return None if x == 0 and y == 0 else (x, y)
+
+
+def kzg_open_bn254(coeffs, z, srs):
+    """`kzg::open` (kzg/setup.rs:63-78) over BN254: the polynomial (integer coefficients, taken mod the group order r) divided by
+    (x - z), the quotient committed against `srs` ((x, y) pairs or None).  Returns (proof point or None, poly(z))."""
+    n = len(coeffs)
+    cw = np.zeros((n, 4), dtype=np.uint64)
+    for i, c in enumerate(coeffs):
+        cw[i] = _limbs4(int(c))
+    pw = np.zeros((len(srs), 8), dtype=np.uint64)
+    for i, pt in enumerate(srs):
+        if pt is not None:
+            pw[i, :4] = _limbs4(pt[0]); pw[i, 4:] = _limbs4(pt[1])
+    zw = np.array(_limbs4(int(z)), dtype=np.uint64)
+    out = np.zeros(8, dtype=np.uint64)
+    val = np.zeros(4, dtype=np.uint64)
+    L.check(L.lib.ronk_kzg_open_bn254(L.ptr(cw), n, L.ptr(zw), L.ptr(pw), len(srs), L.ptr(out), L.ptr(val)))
+    x = sum(int(out[i]) << (64 * i) for i in range(4))
+    y = sum(int(out[4 + i]) << (64 * i) for i in range(4))
+    return (None if x == 0 and y == 0 else (x, y)), sum(int(val[i]) << (64 * i) for i in range(4))

@@ -2,6 +2,7 @@
 // BN254 G1 (reference fold: src/kzg/setup.rs:48-60).  Kernels: msm_kernels.h; arithmetic: bn254.h.
 #include "runtime.h"
 #include "msm_kernels.h"
+#include "fr_scan_kernels.h"
 
 namespace {
 
@@ -188,4 +189,78 @@ extern "C" int ronk_msm_bn254(const uint64_t* points, const uint64_t* scalars, s
   HIPCHK(hipMemcpy(dp.p, points, n * 64, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
   return msm_run(dp.u(), ds.u(), n, out, 0);
+}
+
+// ------------------------------------------------------------------------------ kzg::open over BN254 (src/kzg/setup.rs:63-78)
+namespace {
+// per-device workspace of the scalar-field division: the two multiplier tables, the chunk sums and carries
+struct FrWork {
+  GrowBuf tabs, H, G, rem;
+  std::mutex mu;
+};
+FrWork g_fr_work[64];
+
+int fr_div_linear_run(const uint64_t* d_coeffs, size_t n, const uint64_t* z, uint64_t* d_quot, uint64_t* d_rem, hipStream_t s) {
+  using namespace bn254;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return RONK_ERR_UNSUPPORTED;
+  FrWork& w = g_fr_work[dev];
+  std::lock_guard<std::mutex> lk(w.mu);
+  const size_t nchunks = (n + FR_CHUNK - 1) / FR_CHUNK;
+  RCHK(w.tabs.alloc(2 * sizeof(FrScanTab)));
+  RCHK(w.H.alloc(nchunks * 32 + 32));
+  RCHK(w.G.alloc(nchunks * 32 + 32));
+  RCHK(w.rem.alloc(32));
+  FrScanTab tabs[2];
+  const Fr zc = fr_canon(fr_load(z));                       // eval_point mod r
+  fr_build_tab(zc, &tabs[0]);
+  fr_build_tab(fr_from_mont_host(tabs[0].muchunk), &tabs[1]);   // ratio Y = z^1024 for the chunk sums
+  // (the previous call on this device may still be reading the tables: stream-ordered copy from a pageable buffer is
+  //  synchronous with respect to the host, and kernels of earlier calls on OTHER streams are waited for)
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemcpyAsync(w.tabs.p, tabs, sizeof tabs, hipMemcpyHostToDevice, s));
+  const FrScanTab* dt = (const FrScanTab*)w.tabs.p;
+  uint64_t* rem = d_rem ? d_rem : (uint64_t*)w.rem.p;
+  hipLaunchKernelGGL(fr_chunk_sum_kernel, dim3((u32)nchunks), dim3(256), 0, s, d_coeffs, n, dt, (uint64_t*)w.H.p);
+  hipLaunchKernelGGL(fr_carry_kernel, dim3(1), dim3(256), 0, s, (const uint64_t*)w.H.p, nchunks, dt + 1, (uint64_t*)w.G.p, rem);
+  hipLaunchKernelGGL(fr_apply_kernel, dim3((u32)nchunks), dim3(256), 0, s, d_coeffs, n, dt, (const uint64_t*)w.G.p, d_quot);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));                          // the workspace is per device, the tables per call
+  return RONK_OK;
+}
+}  // namespace
+
+// poly / (x - z) over BN254's scalar field: d_coeffs, d_quot: n x 4 words (standard form; inputs are taken mod r); d_rem: 4 words
+// on the device (may be NULL).  The quotient's top entry is ZERO (n entries like the reference's D-long quotient).
+extern "C" int ronk_poly_div_linear_bn254_dev(const uint64_t* d_coeffs, size_t n, const uint64_t* z, uint64_t* d_quot,
+                                              uint64_t* d_rem, void* stream) {
+  if (!d_coeffs || !z || !d_quot || n == 0) return RONK_ERR_INVALID;
+  if (n > ((size_t)1 << 30)) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  return fr_div_linear_run(d_coeffs, n, z, d_quot, d_rem, (hipStream_t)stream);
+}
+
+// kzg::open: the quotient committed against the SRS, and poly(z)
+extern "C" int ronk_kzg_open_bn254_dev(const uint64_t* d_coeffs, size_t n, const uint64_t* z, const uint64_t* d_srs,
+                                       uint64_t* d_quot, uint64_t* out_point, uint64_t* out_value, void* stream) {
+  if (!d_coeffs || !z || !d_srs || !d_quot || !out_point || n == 0) return RONK_ERR_INVALID;
+  if (n > ((size_t)1 << 30)) return RONK_ERR_UNSUPPORTED;
+  RCHK(need_device());
+  DevBuf drem;
+  RCHK(drem.alloc(32));
+  RCHK(fr_div_linear_run(d_coeffs, n, z, d_quot, drem.u(), (hipStream_t)stream));
+  if (out_value) HIPCHK(hipMemcpy(out_value, drem.p, 32, hipMemcpyDeviceToHost));
+  return msm_run(d_srs, d_quot, n, out_point, (hipStream_t)stream);
+}
+extern "C" int ronk_kzg_open_bn254(const uint64_t* coeffs, size_t n, const uint64_t* z, const uint64_t* srs, size_t n_srs,
+                                   uint64_t* out_point, uint64_t* out_value) {
+  if (!coeffs || !z || !srs || !out_point || n == 0) return RONK_ERR_INVALID;
+  if (n_srs < n) return RONK_ERR_INDEX;                      // assert!(g1_srs.len() >= coeffs.len()), setup.rs:53
+  RCHK(need_device());
+  DevBuf dc, dsrs, dq;
+  RCHK(dc.alloc(n * 32)); RCHK(dsrs.alloc(n * 64)); RCHK(dq.alloc(n * 32));
+  HIPCHK(hipMemcpy(dc.p, coeffs, n * 32, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dsrs.p, srs, n * 64, hipMemcpyHostToDevice));
+  return ronk_kzg_open_bn254_dev(dc.u(), n, z, dsrs.u(), dq.u(), out_point, out_value, 0);
 }

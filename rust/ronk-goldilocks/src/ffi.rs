@@ -76,6 +76,20 @@ extern "C" {
   pub fn ronk_msm_bn254(points: *const u64, scalars: *const u64, n: usize, out: *mut u64) -> c_int;
   /// the same with device-resident points and scalars (the result comes back to the host: 8 limbs)
   pub fn ronk_msm_bn254_dev(d_points: *const u64, d_scalars: *const u64, n: usize, out: *mut u64, stream: *mut c_void) -> c_int;
+  /// `poly.div([-z, ONE])` over BN254's scalar field on device-resident coefficients (n x 4 words): quotient (n entries, top
+  /// ZERO) and the remainder's constant term poly(z) (4 device words, may be null) -- the first half of `kzg::open`,
+  /// src/kzg/setup.rs:63-78
+  pub fn ronk_poly_div_linear_bn254_dev(
+    d_coeffs: *const u64, n: usize, z: *const u64, d_quot: *mut u64, d_rem: *mut u64, stream: *mut c_void,
+  ) -> c_int;
+  /// `kzg::open` over BN254: the division, then `commit(quotient, srs)`; `out_value` (may be null) receives poly(z)
+  pub fn ronk_kzg_open_bn254_dev(
+    d_coeffs: *const u64, n: usize, z: *const u64, d_srs: *const u64, d_quot: *mut u64, out_point: *mut u64, out_value: *mut u64,
+    stream: *mut c_void,
+  ) -> c_int;
+  pub fn ronk_kzg_open_bn254(
+    coeffs: *const u64, n: usize, z: *const u64, srs: *const u64, n_srs: usize, out_point: *mut u64, out_value: *mut u64,
+  ) -> c_int;
 
   // ---- plans and device-resident forms (device.rs: `Plan`, `DevicePoly`): coefficients stay in HBM between calls
   pub fn ronk_plan_create(out: *mut *mut RonkPlan, p: u64, g: u64, log2n: u32, batch: u64, device: c_int) -> c_int;

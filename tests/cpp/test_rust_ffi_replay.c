@@ -281,6 +281,18 @@ static void replay_placement(int ndev) {
     uint64_t *dp = dev_from_host(pts, 32), *ds = dev_from_host(sc, 16);
     EXPECT(ronk_msm_bn254(pts, sc, 4, o1) == 0, "ronk_msm_bn254");
     EXPECT(ronk_msm_bn254_dev(dp, ds, 4, o2, NULL) == 0 && !memcmp(o1, o2, 64), "commit_dev == commit");
+    /* bn254::open / open_dev / div_linear_dev: p(x) = 1 + 2x + 3x^2 + 4x^3 over F_r at z = 2, SRS = four copies of G:
+       quotient [24, 11, 4, 0], p(2) = 49, proof = commit(quotient) = (24 + 11 + 4) G = 39 G = the same MSM with scalar 39 */
+    uint64_t z[4] = {2, 0, 0, 0}, op[8], ov[4], od[8], ovd[4], q[16], rem[4], want[8], s39[4] = {39, 0, 0, 0};
+    EXPECT(ronk_kzg_open_bn254(sc, 4, z, pts, 4, op, ov) == 0 && ov[0] == 49 && !ov[1] && !ov[2] && !ov[3], "bn254::open value");
+    EXPECT(ronk_msm_bn254(pts, s39, 1, want) == 0 && !memcmp(op, want, 64), "bn254::open proof == 39 G");
+    uint64_t *dq = dev_from_host(sc, 16), *drem = dev_from_host(z, 4);
+    EXPECT(ronk_kzg_open_bn254_dev(ds, 4, z, dp, dq, od, ovd, NULL) == 0 && !memcmp(od, op, 64) && ovd[0] == 49, "bn254::open_dev");
+    EXPECT(ronk_poly_div_linear_bn254_dev(ds, 4, z, dq, drem, NULL) == 0, "bn254::div_linear_dev");
+    dev_to_host(q, dq, 16); dev_to_host(rem, drem, 4);
+    EXPECT(q[0] == 24 && q[4] == 11 && q[8] == 4 && q[12] == 0 && rem[0] == 49, "div_linear_dev quotient / remainder");
+    EXPECT(ronk_kzg_open_bn254(sc, 4, z, pts, 3, op, ov) == RONK_ERR_INDEX, "SRS shorter than the polynomial -> panic");
+    ronk_dev_free(dq); ronk_dev_free(drem);
     ronk_dev_free(dp); ronk_dev_free(ds); }
   EXPECT(ronk_trim_workspace() == 0, "ronk_trim_workspace");
   free(x); free(ref); free(got); free(blk);

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "../../ronkathon_amd/csrc/bn254.h"
+#include "../../ronkathon_amd/csrc/bn254_fr.h"
 #include "../../ronkathon_amd/csrc/msm_common.h"
 
 using namespace bn254;
@@ -96,5 +97,24 @@ int h_msm_pipeline(const u64* points, const u64* scalars, u32 n, u32 c, u64* out
         if (((b + 1) >> kk) & 1) rows[(size_t)w * c + kk] = xyzz_add(rows[(size_t)w * c + kk], buckets[(size_t)w * sh.NB + b]);
   ronk::msm_host_tail(sh, rows.data(), out);
   return bad;
+}
+}
+
+// ---- the scalar field (bn254_fr.h): standard form in / out; the second operand of a product goes through Montgomery form
+// exactly as the kernels use it (fr_mul(x, wR) = x * w)
+extern "C" {
+void h_fr_mul(const u64* a, const u64* b, u64* out) { fr_store(out, fr_mul(fr_load(a), fr_to_mont(fr_canon(fr_load(b))))); }
+void h_fr_add(const u64* a, const u64* b, u64* out) { fr_store(out, fr_add(fr_load(a), fr_load(b))); }
+void h_fr_sub(const u64* a, const u64* b, u64* out) { fr_store(out, fr_sub(fr_load(a), fr_load(b))); }
+void h_fr_canon(const u64* a, u64* out) { fr_store(out, fr_canon(fr_load(a))); }
+// powers z^(4 k), k = 0 .. 255 and z^1024 as the scan's multiplier table builds them (Montgomery x Montgomery products),
+// returned in standard form: out = 257 x 4 words
+void h_fr_powers(const u64* z, u64* out) {
+  const Fr mu = fr_to_mont(fr_canon(fr_load(z)));
+  Fr m4 = fr_const_one_mont();
+  for (int i = 0; i < 4; i++) m4 = fr_mul(m4, mu);
+  Fr x = fr_const_one_mont(), one = fr_zero();
+  one.l[0] = 1;
+  for (int k = 0; k <= 256; k++) { fr_store(out + 4 * k, fr_mul(x, one)); x = fr_mul(x, m4); }
 }
 }

@@ -15,7 +15,7 @@ SO = os.path.join(ROOT, "build", "libbn254_host.so")
 @pytest.fixture(scope="module")
 def H():
     src = os.path.join(ROOT, "tests", "emu", "bn254_host.cpp")
-    deps = [src] + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("bn254.h", "bn254_consts.h", "msm_common.h")]
+    deps = [src] + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("bn254.h", "bn254_fr.h", "bn254_consts.h", "msm_common.h")]
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, src])
@@ -100,3 +100,28 @@ def test_msm_pipeline_on_host(H):
         out = (C.c_uint64 * 8)()
         assert H.h_msm_pipeline(pw, sw, n, c, out) == 0, c
         assert rdpt(out) == o.msm(pts, ks), c
+
+
+def test_scalar_field_ops(H):
+    """csrc/bn254_fr.h (the field of kzg::open's division, src/kzg/setup.rs:63-78, on BN254): Montgomery product with one
+    operand in Montgomery form, add / sub, canonicalisation of arbitrary 256-bit inputs, and the power table of the suffix scan"""
+    from oracle import bn254 as o
+    rng = random.Random(2540)
+    edge = [0, 1, 2, o.R - 1, o.R - 2, (1 << 253) - 1, (1 << 253), 0xFFFFFFFF, 1 << 32, (1 << 224) - 1]
+    vals = edge + [rng.randrange(o.R) for _ in range(200)]
+    out = (C.c_uint64 * 4)()
+    for i, a in enumerate(vals):
+        b = vals[(7 * i + 3) % len(vals)]
+        H.h_fr_mul(w4(a), w4(b), out); assert rd(out) == a * b % o.R, (a, b)
+        H.h_fr_add(w4(a), w4(b), out); assert rd(out) == (a + b) % o.R
+        H.h_fr_sub(w4(a), w4(b), out); assert rd(out) == (a - b) % o.R
+    for v in (o.R, o.R + 1, 2 * o.R, 2**256 - 1, 5 * o.R + 7, 0, o.R - 1):
+        H.h_fr_canon(w4(v), out); assert rd(out) == v % o.R, v
+        H.h_fr_mul(w4(v), w4(3), out); assert rd(out) == v * 3 % o.R        # first operand: ANY 256-bit integer
+    pw = (C.c_uint64 * (4 * 257))()
+    for z in (0, 1, 2, o.R - 1, rng.randrange(o.R), 2**256 - 5):
+        H.h_fr_powers(w4(z), pw)
+        for k in (0, 1, 2, 3, 17, 128, 255, 256):
+            assert rd(pw, 4 * k) == pow(z % o.R, 4 * k, o.R), (z, k)
+    q, v = o.fr_div_linear([3, 0, 5, 7], 2)
+    assert q == [(0 + 2 * (5 + 2 * 7)) % o.R, 5 + 2 * 7, 7, 0] and v == 3 + 2 * q[0]

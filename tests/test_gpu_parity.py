@@ -1320,6 +1320,67 @@ def test_large_plans_whole_vector(R, orc, k):
     plan.close()
 
 
+def test_kzg_open_over_bn254(R, orc):
+    """kzg::open on a production curve (src/kzg/setup.rs:63-78): `poly.div([-z, ONE])` over BN254's scalar field
+    (csrc/fr_scan_kernels.h) followed by `commit(quotient, srs)` (the bucket-method MSM).  The quotient and poly(z) against the
+    oracle's synthetic division on Python integers for lengths around every chunk boundary (1024 coefficients per workgroup,
+    1024 chunks per carry block), non-canonical inputs included; the opening proof against the oracle's fold; and the KZG
+    identity itself with an SRS of known secret: C - v G == (tau - z) pi."""
+    import torch
+    from oracle import bn254 as ob
+    from ronkathon_amd import _lib as L
+    from ronkathon_amd import callers
+    rng = np.random.default_rng(77)
+    torch.zeros(1).cuda()
+
+    def words(vals):
+        w = np.zeros((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            w[i] = [(int(v) >> (64 * j)) & (2**64 - 1) for j in range(4)]
+        return w
+
+    def ints(w):
+        return [sum(int(w[i, j]) << (64 * j) for j in range(4)) for i in range(w.shape[0])]
+    for n in (1, 2, 3, 5, 1023, 1024, 1025, 4097, 70001, (1 << 20) + 1025 + 3):
+        cs = [int(x) for x in rng.integers(0, 2**62, size=n)]
+        cs = [(c * 0x9E3779B97F4A7C15F39CC0605CEDC835 + i) % ob.R for i, c in enumerate(cs)]
+        if n > 2:
+            cs[0] = ob.R - 1; cs[1] = 0; cs[-1] = 2**256 - 1        # a non-canonical input: taken mod r
+        z = (0x123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % ob.R) if n % 2 else ob.R - 1
+        dc = torch.from_numpy(words(cs).view(np.int64)).cuda()
+        dq = torch.full((n, 4), -1, dtype=torch.int64, device="cuda")
+        drem = torch.zeros(4, dtype=torch.int64, device="cuda")
+        zw = np.array([(z >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64)
+        L.check(L.lib.ronk_poly_div_linear_bn254_dev(dc.data_ptr(), n, L.ptr(zw), dq.data_ptr(), drem.data_ptr(), 0))
+        torch.cuda.synchronize()
+        q, v = ob.fr_div_linear([c % ob.R for c in cs], z)
+        got = ints(dq.cpu().numpy().view(np.uint64))
+        assert got == q, n
+        assert ints(drem.cpu().numpy().view(np.uint64).reshape(1, 4))[0] == v, n
+    # the whole opening against the oracle's fold
+    n = 300
+    srs = ob.multiples(n)
+    cs = [int(x) % ob.R for x in rng.integers(0, 2**63, size=n)]
+    cs[7] = ob.R - 1
+    z = 0xDEADBEEF12345
+    proof, value = callers.kzg_open_bn254(cs, z, srs)
+    want_pt, want_v = ob.kzg_open(cs, z, srs)
+    assert proof == want_pt and value == want_v
+    # the KZG identity with an SRS of known secret tau: commit(p) - p(z) G == (tau - z) * open(p, z)
+    tau = 0x1F2E3D4C5B6A79887766554433221100FFEEDDCCBBAA99 % ob.R
+    n = 64
+    srs = [ob.mul(pow(tau, i, ob.R), ob.G) for i in range(n)]
+    cs = [int(x) % ob.R for x in rng.integers(0, 2**63, size=n)]
+    proof, value = callers.kzg_open_bn254(cs, z, srs)
+    commit = callers.msm_bn254(srs, cs)
+    lhs = ob.add(commit, ob.neg(ob.mul(value, ob.G)))
+    assert lhs == ob.mul((tau - z) % ob.R, proof)
+    assert value == sum(c * pow(z, i, ob.R) for i, c in enumerate(cs)) % ob.R
+    with pytest.raises(R.RonkPanic) as e:                       # assert!(g1_srs.len() >= coeffs.len()), setup.rs:53
+        callers.kzg_open_bn254(cs, z, srs[:10])
+    assert e.value.code == -6
+
+
 def test_r4_round_structure_opt_in():
     """RONK_R4MID=1 (read once per process: a subprocess): the 2^9 / 2^10-row passes as [16 . 4] . [8 | 16] with a wave-uniform
     shift layer (tile_kernels_r4.hip) -- forward and inverse against the oracle at sizes whose plans contain such passes, one
