@@ -1,5 +1,6 @@
 """Builds tests/cpp/test_host_mirror.cpp (C++ host mirror of the reference interface,
 ronkathon_amd/host/ronkathon.hpp, over the C ABI) and runs it on the GPU."""
+import hashlib
 import os
 import subprocess
 
@@ -9,11 +10,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_host_mirror.bin")
 
 
+def _src_sha(*paths):
+    h = hashlib.sha256()
+    for p_ in paths:
+        with open(p_, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _current(exe, *srcs):
+    """a built test binary travels with the snapshot to the GPU box (like the .so files): it is used there only if it was built
+    from the sources as they are now (their hash sits beside it), otherwise rebuilt -- a stale binary once failed the GPU suite
+    on an expectation that had been corrected in the source"""
+    try:
+        with open(exe + ".sha") as f:
+            return os.path.exists(exe) and f.read().strip() == _src_sha(*srcs)
+    except OSError:
+        return False
+
+
+def _stamp(exe, *srcs):
+    with open(exe + ".sha", "w") as f:
+        f.write(_src_sha(*srcs))
+
+
 def build():
     src = os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp")
+    hdr = os.path.join(ROOT, "ronkathon_amd", "host", "ronkathon.hpp")
     lib = os.path.join(ROOT, "ronkathon_amd")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", EXE, src, "-L" + lib, "-lronk_ntt", "-Wl,-rpath," + lib,
                            "-Wl,-rpath-link,/opt/rocm/lib"])
+    _stamp(EXE, src, hdr)
     return EXE
 
 
@@ -24,7 +51,8 @@ def test_cpp_host_mirror_compiles():
 
 @pytest.mark.gpu
 def test_cpp_host_mirror_on_gpu():
-    exe = EXE if os.path.exists(EXE) else build()
+    src = os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp")
+    exe = EXE if _current(EXE, src, os.path.join(ROOT, "ronkathon_amd", "host", "ronkathon.hpp")) else build()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
@@ -38,6 +66,7 @@ def build_replay():
     lib, orc = os.path.join(ROOT, "ronkathon_amd"), os.path.join(ROOT, "oracle")
     subprocess.check_call(["gcc", "-O1", "-std=c11", "-o", REPLAY, src, "-L" + lib, "-lronk_ntt", "-L" + orc, "-lronk_oracle",
                            "-Wl,-rpath," + lib, "-Wl,-rpath," + orc, "-Wl,-rpath-link,/opt/rocm/lib"])
+    _stamp(REPLAY, src, os.path.join(ROOT, "include", "ronk_ntt.h"))
     return REPLAY
 
 
@@ -111,6 +140,6 @@ def test_rust_ffi_replay_compiles_and_shim_sources_match_the_header():
 
 @pytest.mark.gpu
 def test_rust_ffi_replay_on_gpu():
-    exe = REPLAY if os.path.exists(REPLAY) else build_replay()
+    exe = REPLAY if _current(REPLAY, os.path.join(ROOT, "tests", "cpp", "test_rust_ffi_replay.c"), os.path.join(ROOT, "include", "ronk_ntt.h")) else build_replay()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
