@@ -257,6 +257,16 @@ inline G1Affine commit(const std::vector<Limbs>& coeffs, const std::vector<G1Aff
                        coeffs.size(), reinterpret_cast<uint64_t*>(&out)));
   return out;
 }
+// kzg::open (src/kzg/setup.rs:63-78) on the same curve: poly.div([-eval_point, ONE]) over BN254's scalar field, then commit of the
+// quotient; also hands back poly(eval_point).  Same assert on the SRS length as commit.
+struct Opening { G1Affine proof; Limbs value; };
+inline Opening open(const std::vector<Limbs>& coeffs, const Limbs& eval_point, const std::vector<G1Affine>& g1_srs) {
+  Opening o;
+  check(ronk_kzg_open_bn254(reinterpret_cast<const uint64_t*>(coeffs.data()), coeffs.size(), eval_point.data(),
+                            reinterpret_cast<const uint64_t*>(g1_srs.data()), g1_srs.size(), reinterpret_cast<uint64_t*>(&o.proof),
+                            o.value.data()));
+  return o;
+}
 }  // namespace bn254
 
 // ---- heap- / device-resident polynomials, plans, the sharded transform ------------------------------------------------

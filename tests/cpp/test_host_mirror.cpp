@@ -100,6 +100,12 @@ int main() {
     // 2G: the EIP-196 test vector
     const G1Affine two = commit({Limbs{2, 0, 0, 0}}, {g});
     CHECK(two.x == (Limbs{0xd3c208c16d87cfd3ull, 0xd97816a916871ca8ull, 0x9b85045b68181585ull, 0x030644e72e131a02ull}));
+    // kzg::open over BN254: p(x) = 1 + 2x + 3x^2 + 4x^3 at z = 2 against four copies of G: quotient [24, 11, 4, 0] -> proof 39 G, p(2) = 49
+    const Opening op = open({Limbs{1, 0, 0, 0}, Limbs{2, 0, 0, 0}, Limbs{3, 0, 0, 0}, Limbs{4, 0, 0, 0}}, Limbs{2, 0, 0, 0}, {g, g, g, g});
+    CHECK(op.proof == commit({Limbs{39, 0, 0, 0}}, {g}) && op.value == (Limbs{49, 0, 0, 0}));
+    bool threw = false;
+    try { (void)open({Limbs{1, 0, 0, 0}, Limbs{2, 0, 0, 0}}, Limbs{2, 0, 0, 0}, {g}); } catch (const Panic& e) { threw = e.code == RONK_ERR_INDEX; }
+    CHECK(threw);
   }
   // device-resident polynomials, plans with two lanes, the sharded transform (ronkathon::device, the C++ twin of
   // rust/ronk-goldilocks/src/device.rs): properties only -- this test has no oracle; tests/test_gpu_parity.py and the FFI
