@@ -500,6 +500,16 @@ def sec_msm(deadline):
         want = ob.mul(want_k, ob.G) if want_k else None
         if callers.msm_bn254(pts, ks) != want:
             report("msm", "bn254", n, it)
+        # kzg::open over the same curve: the quotient of a random polynomial over F_r by (x - z), committed against multiples of G
+        # -- with SRS[i] = (idx_i + 1) G the proof is (sum_i q_i (idx_i + 1)) G and the value poly(z), both from Python integers
+        if n <= 20000 and all(i >= 0 for i in idx):
+            cs = [rng.choice([rng.randrange(ob.R), rng.randrange(2**256), 0, ob.R - 1]) for _ in range(n)]
+            z = rng.choice([rng.randrange(ob.R), 0, 1, ob.R - 1, rng.randrange(2**256)])
+            proof, value = callers.kzg_open_bn254(cs, z, pts)
+            q, v = ob.fr_div_linear([c % ob.R for c in cs], z % ob.R)
+            wk = sum(qi * (i + 1) for qi, i in zip(q, idx)) % ob.R
+            if value != v or proof != (ob.mul(wk, ob.G) if wk else None):
+                report("msm", "kzg_open_bn254", n, it)
     counts["msm"] = it
 
 
