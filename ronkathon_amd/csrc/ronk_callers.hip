@@ -131,10 +131,21 @@ struct WsLease {
         ws_reap(true);
         e = hipMalloc(&w->p, need);
       }
+      // The initial fills are ordered on the ACQUIRING stream: hipMemset runs on the null stream and returns before it has
+      // executed, so a kernel launched right afterwards on a NON-BLOCKING stream could read the look-back arrays before they
+      // were filled -- and take garbage for a published chunk sum (found by the four-thread fuzz sweep, round 5: one evaluate
+      // in ~5 000 threaded cases, always on a caller-created stream and a fresh slot).  A later user on another stream gets
+      // the slot only behind its completion event (or the device drain of the first cross-stream use), i.e. behind the fills.
+      // (While `st` is capturing, the legacy fills stay: they must not become nodes of the caller's graph; the one-launch
+      // scans, the only readers of the look-back arrays, are not used under capture.)
+      hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap0) != hipSuccess) { (void)hipGetLastError(); cap0 = hipStreamCaptureStatusNone; }
+      const bool on_st = cap0 == hipStreamCaptureStatusNone;
       if (e == hipSuccess) e = hipMalloc((void**)&w->ctl, 64);
-      if (e == hipSuccess) e = hipMemset(w->ctl, 0, 64);
+      if (e == hipSuccess) e = on_st ? hipMemsetAsync(w->ctl, 0, 64, st) : hipMemset(w->ctl, 0, 64);
       if (e == hipSuccess) e = hipMalloc((void**)&w->lb, (size_t)2 * LB_WORDS * 8);
-      if (e == hipSuccess) e = hipMemset(w->lb, 0xFF, (size_t)2 * LB_WORDS * 8);   // LB_EMPTY everywhere
+      if (e == hipSuccess) e = on_st ? hipMemsetAsync(w->lb, 0xFF, (size_t)2 * LB_WORDS * 8, st)
+                                     : hipMemset(w->lb, 0xFF, (size_t)2 * LB_WORDS * 8);   // LB_EMPTY everywhere
       if (e == hipSuccess) e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
       if (e != hipSuccess) { if (w->p) (void)hipFree(w->p); if (w->ctl) (void)hipFree(w->ctl); if (w->lb) (void)hipFree(w->lb); delete w; return hip_fail(e, "workspace"); }
       w->bytes = need; w->device = dev;

@@ -806,8 +806,8 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     const u64 stride = (u64)(d_b - d_a);   // element stride, modulo 2^64 (a negative distance wraps back in the address arithmetic)
     // Fused middle (ntt_mul.h): forward row pass of both operands + pointwise product + inverse column pass in ONE launch --
     // three launches per product, NTT(a) / NTT(b) never written.  Needs the same tile width on both sides (a dedicated
-    // inverse plan with the pair plan's 4-column tiles) and two-pass plans of 2^10 / 2^11-row passes; fused for NTT sizes 2^21
-    // and 2^22 only (2^20 measured slower, below).  RONK_MUL_FUSED=0: the
+    // inverse plan with the pair plan's 4-column tiles) and two-pass plans of 2^10 / 2^11-row passes; fused for NTT sizes 2^21,
+    // 2^22 and (round 5) 2^23 (2^20 measured slower, below).  RONK_MUL_FUSED=0: the
     // four-launch form (A/B); RONK_MUL_INV_TWF picks the inverse's twiddle form as before (default there: two-level tables).
     static const bool fused_on = [] { const char* e_ = getenv("RONK_MUL_FUSED"); return !e_ || atoi(e_) != 0; }();
     // Measured (round 4, same box, us per product): 2^22 158.6 -> 132.6, 2^21 88.0 -> 80.6, but 2^20 63.1 -> 68.1 -- there a
