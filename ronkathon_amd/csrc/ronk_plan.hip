@@ -142,6 +142,9 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
     for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
       if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
+    // the tables were uploaded by null-stream copies; the plan may be used from any (non-blocking) stream the moment this
+    // returns, so the null stream is drained here once (a legacy copy may return before its DMA has finished)
+    if (!rc && hipStreamSynchronize(0) != hipSuccess) rc = RONK_ERR_HIP;
   } else {
     pl->w_f = h_powmod(pl->g, (p - 1) / n, p);
     pl->w_i = h_powmod(pl->w_f, p - 2, p);                     // root.inverse().unwrap(), mod.rs:433
