@@ -258,6 +258,7 @@ extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log
     if (!rc) rc = k.p2.compile(build_dist_phase2((int)log2n, inverse != 0, g, ndev, 4, 0, chunks));
     if (!rc && (k.p1.pd.passes.empty() || k.p2.pd.passes.empty())) rc = RONK_ERR_UNSUPPORTED;
     hipError_t e = hipSuccess;
+    if (!rc) e = hipStreamSynchronize(0);   // the table uploads (null-stream copies) before the plan's non-blocking streams use them
     if (!rc) e = hipMalloc((void**)&k.tmp, per * 8);
     if (!rc && e == hipSuccess) e = hipMalloc((void**)&k.send, per * 8);
     if (!rc && e == hipSuccess) e = hipMalloc((void**)&k.recv, per * 8);
