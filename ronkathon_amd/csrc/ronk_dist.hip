@@ -45,6 +45,7 @@ extern "C" int ronk_dist_plan_create_chunked(ronk_dist_plan** out, uint32_t log2
   if (!rc) rc = pl->p2.compile(build_dist_phase2((int)log2n, inverse != 0, rank, world, 4, 0, chunks));
   if (!rc) {
     hipError_t e = hipMalloc((void**)&pl->d_tmp, (sh.n / sh.W) * 8);
+    if (e == hipSuccess) e = hipStreamSynchronize(0);   // table uploads (null-stream copies) before any non-blocking stream uses them
     if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(scratch)");
   }
   if (rc) { ronk_dist_plan_destroy(pl); return rc; }
