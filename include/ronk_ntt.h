@@ -312,8 +312,11 @@ int ronk_dft_dev(uint64_t p, uint64_t g, const uint64_t* d_in, uint64_t* d_out, 
 /* Polynomial::<Lagrange<F>>::evaluate (polynomial/mod.rs:382-415); d_out = ONE element; d_status may be NULL */
 int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uint64_t* d_nodes, size_t n, uint64_t x, uint64_t* d_out,
                            int* d_status, void* stream);
-/* quotient_and_remainder (polynomial/mod.rs:170-225) by the long-division kernel (any divisor); *d_status (required)
- * receives 0 or the RONK_ERR_* code of the reference's panic; d_rem may alias d_a */
+/* quotient_and_remainder (polynomial/mod.rs:170-225), any prime, any divisor; *d_status (required) receives 0 or the
+ * RONK_ERR_* code of the reference's panic; d_rem may alias d_a.  The long-division kernel follows the reference's loop
+ * (one workgroup, d * d2 steps).  Goldilocks, d2 >= 64 and d - d2 + 1 >= 2048: the operands' degrees are read back first
+ * (the ONE exception to "no synchronisation per call": one stream synchronisation, 24 bytes) and, for a full-length divisor,
+ * the O(n log n) Newton form on the NTT path runs, as behind ronk_poly_divrem.  A capturing stream keeps the long division. */
 int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2, uint64_t* d_quot,
                          uint64_t* d_rem, int* d_status, void* stream);
 /* Message::decode (src/codes/reed_solomon.rs:54-106); d_status may be NULL */

@@ -550,10 +550,29 @@ static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b,
   return RONK_OK;                                   // the lease's destructor leaves an event behind the last kernel
 }
 
-// quotient_and_remainder on device-resident operands: the long-division kernel that follows the reference's loop
-// (any prime, any divisor).  d_quot / d_rem receive d coefficients each (d_rem may alias d_a); *d_status (device int, required) receives 0 or the RONK_ERR_* code of the reference's panic.
-// The O(n log n) Newton form needs the operands' degrees on the host, so it is reached through ronk_poly_divrem
-// (host pointers) and, for linear divisors, through ronk_poly_div_linear_dev.
+// number of significant coefficients (degree + 1, 0 for the zero polynomial) of two coefficient vectors, and the divisor's
+// leading coefficient: out[0] = n(a), out[1] = n(b) (both zeroed by the caller), then out[2] = b[n(b) - 1]
+__global__ void __launch_bounds__(256) dv_degree_kernel(const u64* __restrict__ a, size_t d, const u64* __restrict__ b, size_t d2,
+                                                        unsigned long long* __restrict__ out) {
+  unsigned long long na = 0, nb = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < d; i += (size_t)gridDim.x * blockDim.x) {
+    if (a[i] != 0) na = i + 1;
+    if (i < d2 && b[i] != 0) nb = i + 1;
+  }
+  if (na) atomicMax(&out[0], na);
+  if (nb) atomicMax(&out[1], nb);
+}
+__global__ void dv_lead_kernel(const u64* __restrict__ b, unsigned long long* __restrict__ out) {
+  out[2] = out[1] ? b[out[1] - 1] : 0;
+}
+
+// quotient_and_remainder on device-resident operands.  d_quot / d_rem receive d coefficients each (d_rem may alias d_a);
+// *d_status (device int, required) receives 0 or the RONK_ERR_* code of the reference's panic.
+// Any prime, any divisor: the long-division kernel that follows the reference's loop, asynchronous on `stream`.
+// Goldilocks with a divisor of >= 64 coefficients and a quotient of >= 2048 (where the single-block long division would run
+// for seconds to minutes): the operands' degrees and the divisor's leading coefficient are read back first -- ONE stream
+// synchronisation, 24 bytes -- and the O(n log n) Newton form on the NTT path runs, as behind ronk_poly_divrem.  A capturing
+// stream cannot be synchronised, so under capture the long-division kernel is kept.
 extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2,
                                     uint64_t* d_quot, uint64_t* d_rem, int* d_status, void* stream) {
   if (!d_a || !d_b || !d_quot || !d_rem || !d_status || d == 0 || d2 == 0) return RONK_ERR_INVALID;
@@ -561,6 +580,32 @@ extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, c
   FieldCtx f;
   RCHK(make_field(p, &f));
   hipStream_t s = (hipStream_t)stream;
+  if (f.kind == F_GL && d >= d2 && d2 >= 64 && d - d2 + 1 >= 2048 && d <= ((size_t)1 << 27)) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone) {
+      unsigned long long probe[3] = {0, 0, 0};
+      {
+        WsLease ws;
+        RCHK(ws.acquire(64, s));
+        unsigned long long* dp = (unsigned long long*)ws.u();
+        HIPCHK(hipMemsetAsync(dp, 0, 24, s));
+        hipLaunchKernelGGL(dv_degree_kernel, dim3(grid_for(d)), dim3(256), 0, s, d_a, d, d_b, d2, dp);
+        hipLaunchKernelGGL(dv_lead_kernel, dim3(1), dim3(1), 0, s, d_b, dp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(probe, dp, 24, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      const size_t n = (size_t)probe[0], m = (size_t)probe[1];
+      // the same window as the host-pointer form: a full-length divisor (a ragged one is the reference's panic, reported by
+      // the long-division kernel), a quotient long enough for the O(n log n) form to win
+      if (n > 0 && m == d2 && n >= m && (n - m + 1) >= 2048 && m >= 64) {
+        const u64 lead_inv = h_powmod((u64)probe[2] % p, p - 2, p);   // rhs.leading_coefficient().inverse().unwrap(), mod.rs:181,196
+        HIPCHK(hipMemsetAsync(d_status, 0, 4, s));
+        return newton_divrem_dev(d_a, d, n - 1, d_b, d2, m - 1, lead_inv, d_quot, d_rem, s);
+      }
+    }
+  }
   if (d_rem != d_a) HIPCHK(hipMemcpyAsync(d_rem, d_a, d * 8, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemsetAsync(d_status, 0, 4, s));
   const u32 T = d2 >= 1024 ? 1024 : d2 > 256 ? 512 : 256;

@@ -273,7 +273,8 @@ impl DevicePoly {
     (quot, r)
   }
 
-  /// `self / rhs`, `self % rhs` for any divisor (quotient_and_remainder, mod.rs:170-225): both with `len` coefficients
+  /// `self / rhs`, `self % rhs` for any divisor (quotient_and_remainder, mod.rs:170-225): both with `len` coefficients.
+  /// Large operands (divisor >= 64 coefficients, quotient >= 2048) run the O(n log n) Newton form inside the library.
   pub fn div_rem(&self, rhs: &DevicePoly) -> (DevicePoly, DevicePoly) {
     self.same_device(rhs);
     let _g = OnDevice::new(self.device);

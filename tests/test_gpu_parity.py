@@ -711,6 +711,73 @@ def test_fast_general_division_newton_vs_oracle(R, orc):
     assert int(q[a.size - b.size]) == top and not q[a.size - b.size + 1:].any()
 
 
+def test_device_resident_general_division_takes_the_newton_form(R, orc):
+    """ronk_poly_divrem_dev (what the shim's DevicePoly::div_rem calls): for a Goldilocks divisor of >= 64 coefficients and a
+    quotient of >= 2048 it reads the degrees back and runs the Newton form -- the single-block long division would need
+    d * d2 steps (minutes at 2^20 / 2^19).  Same cases, same oracle as the host-pointer form above, plus d_rem aliasing d_a and
+    the status word."""
+    import time
+
+    import torch
+    from ronkathon_amd import _lib as L
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+    def host(t):
+        return t.cpu().numpy().view(np.uint64)
+
+    def z(v, k):
+        return np.concatenate([v, np.zeros(k, dtype=np.uint64)])
+
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+
+    def divrem(a, b, alias=False, stream=None):
+        da, db = dev(a), dev(b)
+        dq = torch.full((a.size,), -1, dtype=torch.int64, device="cuda")
+        dr = da if alias else torch.full((a.size,), -1, dtype=torch.int64, device="cuda")
+        status.fill_(77)
+        torch.cuda.synchronize()
+        L.check(L.lib.ronk_poly_divrem_dev(GP, da.data_ptr(), a.size, db.data_ptr(), b.size, dq.data_ptr(), dr.data_ptr(),
+                                           status.data_ptr(), stream.cuda_stream if stream is not None else None))
+        torch.cuda.synchronize()
+        return host(dq), host(dr), int(status.item())
+
+    cases = [
+        (splitmix_field(1, 40000), splitmix_field(2, 9000)),                       # Newton
+        (splitmix_field(3, 30000), z(splitmix_field(4, 3000), 500)),               # ragged divisor: long division, early stop
+        (z(splitmix_field(5, 20000), 1234), splitmix_field(6, 700)),               # dividend with leading zeros: Newton
+        (z(splitmix_field(7, 6000), 4000), z(splitmix_field(8, 101), 7899)),       # short dividend: long division, ONE step
+        (splitmix_field(9, 8192), splitmix_field(10, 4096)),                       # Newton, quotient of 4097
+        (splitmix_field(12, 2200), splitmix_field(13, 64)),                        # just inside the window
+        (splitmix_field(14, 2100), splitmix_field(15, 63)),                        # just outside (divisor too short)
+        (np.zeros(5000, dtype=np.uint64), splitmix_field(16, 100)),                # zero dividend
+    ]
+    for i, (a, b) in enumerate(cases):
+        try:
+            oq, o_r = orc.poly_divrem(GP, a, b)
+            code = 0
+        except orc.OraclePanic as e:
+            oq = o_r = None
+            code = e.code
+        for alias, stream in ((False, None), (True, st)):
+            q, r, got = divrem(a, b, alias, stream)
+            assert got == code, (i, got, code)
+            if code == 0:
+                assert np.array_equal(q, oq) and np.array_equal(r, o_r), (i, alias)
+    # 2^20 / 2^19 on the device: a == q b + r at random points, in well under a second
+    a, b = splitmix_field(21, 1 << 20), splitmix_field(22, 1 << 19)
+    t0 = time.perf_counter()
+    q, r, got = divrem(a, b)
+    assert got == 0 and time.perf_counter() - t0 < 20.0
+    assert not r[b.size - 1:].any()
+    for pt in (5, 0xABCDEF0123456789 % GP):
+        lhs = orc.poly_eval(GP, a, pt)
+        rhs = orc.add(GP, orc.mul(GP, orc.poly_eval(GP, q, pt), orc.poly_eval(GP, b, pt)), orc.poly_eval(GP, r, pt))
+        assert lhs == rhs
+
+
 def test_scan_paths_fused_and_three_kernel(R, orc):
     """evaluate / division by a linear factor: the fused kernels (one / two launches, up to 2^23 coefficients for the
     division) and the three-kernel form with the serial carry scan beyond that -- remainder == evaluation == oracle,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer probe: device time per call of the callers that ride on the NTT path -- general division (Newton inversion on the
-NTT path, ronk_poly_divrem_dev) and the O(K log K) Reed-Solomon decode (ronk_rs_decode_dev) -- device-resident data.
+NTT path, reached through ronk_poly_divrem_dev for large Goldilocks operands) and the O(K log K) Reed-Solomon decode (ronk_rs_decode_dev) -- device-resident data.
 usage: python tools/callers_time.py"""
 import os
 import sys
