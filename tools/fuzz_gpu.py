@@ -311,6 +311,30 @@ def sec_divrem(deadline):
             report("divrem", "rc", p, d, d2, rc)
         elif not (np.array_equal(q, want[0]) and np.array_equal(r, want[1])):
             report("divrem", "values", p, d, d2, shape)
+        # the device-resident entry on the same operands (long division, or Newton after the degree probe), now and then on a
+        # caller stream and with the remainder written over the dividend
+        if d >= d2:
+            import torch
+            da = torch.from_numpy(a.view(np.int64)).cuda(); db = torch.from_numpy(b.view(np.int64)).cuda()
+            alias = rng.random() < 0.3
+            dq = torch.full((d,), -1, dtype=torch.int64, device="cuda")
+            dr = da if alias else torch.full((d,), -1, dtype=torch.int64, device="cuda")
+            dst = torch.full((1,), 55, dtype=torch.int32, device="cuda")
+            st = torch.cuda.Stream() if rng.random() < 0.5 else None
+            torch.cuda.synchronize()
+            rc2 = L.lib.ronk_poly_divrem_dev(p, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), dst.data_ptr(),
+                                             st.cuda_stream if st is not None else None)
+            torch.cuda.synchronize()
+            code = int(dst.item())
+            if rc2 != 0:
+                report("divrem", "dev rc", p, d, d2, rc2)
+            elif isinstance(want, Exception):
+                if code == 0:
+                    report("divrem", "dev accepted what the oracle refuses", p, d, d2, shape)
+            elif code != 0:
+                report("divrem", "dev status", p, d, d2, code)
+            elif not (np.array_equal(dq.cpu().numpy().view(np.uint64), want[0]) and np.array_equal(dr.cpu().numpy().view(np.uint64), want[1])):
+                report("divrem", "dev values", p, d, d2, shape, alias)
     counts["divrem"] = it
 
 
