@@ -142,15 +142,20 @@ __global__ void __launch_bounds__(256) poly_mul_schoolbook_kernel(Ops ops, const
 // the loop guard compares the remainder's TRIMMED length with the divisor's UNTRIMMED length d2,
 // the update walks all d2 divisor coefficients, a zero divisor or an out-of-range update is the
 // reference's panic (status -6), a zero leading inverse cannot occur for a non-zero divisor.
-// work: rem[] (d entries, starts as the dividend), quot[] zeroed here.
+// work: rem[] (d entries, filled here from the dividend a[], which may BE rem), quot[] and *status zeroed here -- the whole call is
+// this one launch: a captured hipGraph of it holds no memset / memcpy node (a memset node in front of a memcpy node of more than
+// 16 KiB came back as 0xFCFCFCFC from the second replay on, ROCm 7.0.2: profiles/r05_capture_division.txt).
 template <class Ops>
-__global__ void __launch_bounds__(1024) poly_divrem_kernel(Ops ops, u64* __restrict__ rem, size_t d,
+__global__ void __launch_bounds__(1024) poly_divrem_kernel(Ops ops, const u64* a, u64* rem, size_t d,
                                                             const u64* __restrict__ b, size_t d2,
                                                             u64* __restrict__ quot, int* status) {
   __shared__ unsigned long long s_top;   // 1 + highest non-zero index found by the scan (0 = none)
   __shared__ u64 s_s;
   const int T = blockDim.x, tid = threadIdx.x;
+  if (tid == 0) *status = 0;             // (the only later writer is this same lane)
   for (size_t i = tid; i < d; i += T) quot[i] = 0;
+  if (a != rem)
+    for (size_t i = tid; i < d; i += T) rem[i] = a[i];
   // divisor degree / leading coefficient
   if (tid == 0) s_top = 0;
   __syncthreads();

@@ -606,11 +606,9 @@ extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, c
       }
     }
   }
-  if (d_rem != d_a) HIPCHK(hipMemcpyAsync(d_rem, d_a, d * 8, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(d_status, 0, 4, s));
   const u32 T = d2 >= 1024 ? 1024 : d2 > 256 ? 512 : 256;
-  FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_divrem_kernel<decltype(ops)>), dim3(1), dim3(T), 0, s, ops, d_rem, d, d_b, d2,
-                                        d_quot, d_status); });
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_divrem_kernel<decltype(ops)>), dim3(1), dim3(T), 0, s, ops, d_a, d_rem, d, d_b, d2,
+                                        d_quot, d_status); });   // (copies the dividend and clears the status itself)
   HIPCHK(hipGetLastError());
   return RONK_OK;
 }
@@ -658,7 +656,7 @@ extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const u
   HIPCHK(hipMemcpy(db.p, b, d2 * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dst.p, 0, 4));
   const u32 T = d2 >= 1024 ? 1024 : d2 > 256 ? 512 : 256;
-  FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_divrem_kernel<decltype(ops)>), dim3(1), dim3(T), 0, 0, ops, drem.u(), d,
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((poly_divrem_kernel<decltype(ops)>), dim3(1), dim3(T), 0, 0, ops, (const u64*)drem.u(), drem.u(), d,
                                         db.u(), d2, dq.u(), (int*)dst.p); });
   HIPCHK(hipGetLastError());
   int status = 0;

@@ -931,6 +931,38 @@ def test_hipgraph_capture_of_dev_entry_points(R, orc):
     plan.close()
 
 
+def test_hipgraph_capture_of_device_division(R, orc):
+    """ronk_poly_divrem_dev inside a stream capture: a shape that would take the Newton form (degree probe = one stream
+    synchronisation, impossible while capturing) keeps the long-division kernel, so the call stays capturable; replays equal the
+    oracle, and the same call outside the capture (Newton) gives the same values"""
+    import torch
+    from ronkathon_amd import _lib as L
+    d, d2 = 2300, 100
+    a, b = splitmix_field(771, d), splitmix_field(772, d2)
+    da = torch.from_numpy(a.view(np.int64)).cuda(); db = torch.from_numpy(b.view(np.int64)).cuda()
+    dq = torch.zeros(d, dtype=torch.int64, device="cuda"); dr = torch.zeros(d, dtype=torch.int64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    L.check(L.lib.ronk_poly_divrem_dev(GP, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), s.cuda_stream))
+    s.synchronize()
+    oq, o_r = orc.poly_divrem(GP, a, b)
+    assert int(status.item()) == 0 and np.array_equal(dq.cpu().numpy().view(np.uint64), oq) and np.array_equal(dr.cpu().numpy().view(np.uint64), o_r)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(L.lib.ronk_poly_divrem_dev(GP, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), st))
+    for rep in range(2):
+        dq.fill_(-1); dr.fill_(-1); status.fill_(9)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        assert np.array_equal(dq.cpu().numpy().view(np.uint64), oq) and np.array_equal(dr.cpu().numpy().view(np.uint64), o_r)
+        a = splitmix_field(773 + rep, d)
+        da.copy_(torch.from_numpy(a.view(np.int64)))
+        oq, o_r = orc.poly_divrem(GP, a, b)
+    del g
+
+
 def test_plan_cache_eviction_and_threads(R, orc):
     """more distinct one-shot sizes than cache entries, then concurrent callers (the reference's
     `cargo test` runs tests on parallel threads; the library must be re-entrant)"""
