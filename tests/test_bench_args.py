@@ -45,3 +45,20 @@ def test_free_port_and_default_gpus():
     assert 1024 < port < 65536
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'args.gpus = int(os.environ.get("WORLD_SIZE", "1"))' in src
+
+
+def test_committed_counter_files_match_the_kernel_sources():
+    """bench.py prints `roofline.traffic` / `valu` only from counter files taken on the kernel sources as they are now (their
+    hash is stored beside the counters): an edit to one of those sources without a refresh on the GPU (tools/profile_refresh.sh)
+    would silently turn the driver's line into `traffic: null`, so the CPU suite says it first.  Also: the regime the default
+    line reports carries the two kernels of a 2^22 step with traffic between 2x and 3x the algorithmic bytes."""
+    import json
+    for key, wl in (("ntt22", None), ("ntt22_1stream", None), ("ntt22_mont", None), ("batch16", "batch16"), ("open22", "open22"), ("eval22", "eval22")):
+        d, why = bench.load_if_current("profiles/latest_pmc_%s.json" % key, wl)
+        assert d is not None, (key, why)
+    with open(os.path.join(ROOT, "profiles", "latest_census.json")) as f:
+        assert json.load(f).get("kernel_source_hash") == bench.kernel_source_hash()
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_args_c.json")))
+    alg = line["roofline"]["algorithmic_bytes_per_step"]
+    assert alg == 16 * (1 << 22) and 2.0 * alg < line["roofline"]["traffic"] < 3.0 * alg
+    assert line["roofline"]["frac"] == line["roofline"]["achieved"] / line["roofline"]["peak"]
