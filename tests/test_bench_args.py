@@ -62,3 +62,26 @@ def test_committed_counter_files_match_the_kernel_sources():
     alg = line["roofline"]["algorithmic_bytes_per_step"]
     assert alg == 16 * (1 << 22) and 2.0 * alg < line["roofline"]["traffic"] < 3.0 * alg
     assert line["roofline"]["frac"] == line["roofline"]["achieved"] / line["roofline"]["peak"]
+
+
+def test_every_cited_profile_file_exists():
+    """DESIGN.md / README.md / HISTORY.md / profiles/README.md name their evidence as `rNN_*` / `latest_*` / `profiles/...`: every
+    such name (brace lists and globs expanded) is a file under profiles/"""
+    import glob
+    import re
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "HISTORY.md", "INTEGRATION.md", os.path.join("profiles", "README.md")):
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in re.finditer(r"`([^`\s]+)`", text):
+            t = m.group(1)
+            if t.startswith("profiles/"):
+                name = t
+            elif re.match(r"^(r0\d_|latest_)[\w.\-{},*]+$", t):
+                name = "profiles/" + t
+            else:
+                continue
+            b = re.search(r"\{([^}]*)\}", name)
+            for nm in ([name[:b.start()] + alt + name[b.end():] for alt in b.group(1).split(",")] if b else [name]):
+                if not glob.glob(os.path.join(ROOT, nm)):
+                    missing.append((doc, nm))
+    assert not missing, missing
