@@ -137,3 +137,28 @@ def test_argument_errors_of_the_round_3_entry_points_need_no_device():
     opts = L.PlanOpts()
     assert (opts.tile_log2_columns, opts.twiddle_matrix_log2_max, opts.in_flight, opts.split_log2_rows, list(opts.reserved)) == (-1, -1, -1, 0, [0] * 4)
     assert C.sizeof(L.PlanOpts) == 32                                                                  # 8 ints, as in the header
+
+
+def test_product_does_not_reach_the_oracle():
+    """the oracle is test infrastructure: no source of the product (the package, the C ABI header, the Rust crate, the library's
+    link line) names it, and the built library has no dependency on libronk_oracle.so"""
+    import subprocess
+    hits = []
+    for top in ("ronkathon_amd", "include", os.path.join("rust", "ronk-goldilocks", "src")):
+        for dirpath, _dirs, files in os.walk(os.path.join(ROOT, top)):
+            if "__pycache__" in dirpath:
+                continue
+            for fn in files:
+                if fn.endswith((".so", ".pyc", ".o")):
+                    continue
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                for needle in ("import oracle", "from oracle", "ronk_oracle", "orc_"):
+                    if re.search(r"\b" + re.escape(needle), text):
+                        hits.append((os.path.relpath(os.path.join(dirpath, fn), ROOT), needle))
+    assert not hits, hits
+    from ronkathon_amd import _lib as L
+    needed = subprocess.run(["readelf", "-d", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "NEEDED" in needed and "oracle" not in needed
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    link = [ln for ln in mk.splitlines() if "-shared" in ln]
+    assert link and all("oracle" not in ln for ln in link)
