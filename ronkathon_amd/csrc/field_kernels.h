@@ -12,6 +12,7 @@
 
 #include "gl64.h"
 #include "mont64.h"
+#include "longdiv_kernel.h"
 
 namespace ronk {
 
@@ -138,68 +139,8 @@ __global__ void __launch_bounds__(256) poly_mul_schoolbook_kernel(Ops ops, const
   }
 }
 
-// quotient_and_remainder (polynomial/mod.rs:170-225), one workgroup, followed step by step:
-// the loop guard compares the remainder's TRIMMED length with the divisor's UNTRIMMED length d2,
-// the update walks all d2 divisor coefficients, a zero divisor or an out-of-range update is the
-// reference's panic (status -6), a zero leading inverse cannot occur for a non-zero divisor.
-// work: rem[] (d entries, filled here from the dividend a[], which may BE rem), quot[] and *status zeroed here -- the whole call is
-// this one launch: a captured hipGraph of it holds no memset / memcpy node (a memset node in front of a memcpy node of more than
-// 16 KiB came back as 0xFCFCFCFC from the second replay on, ROCm 7.0.2: profiles/r05_capture_division.txt).
-template <class Ops>
-__global__ void __launch_bounds__(1024) poly_divrem_kernel(Ops ops, const u64* a, u64* rem, size_t d,
-                                                            const u64* __restrict__ b, size_t d2,
-                                                            u64* __restrict__ quot, int* status) {
-  __shared__ unsigned long long s_top;   // 1 + highest non-zero index found by the scan (0 = none)
-  __shared__ u64 s_s;
-  const int T = blockDim.x, tid = threadIdx.x;
-  if (tid == 0) *status = 0;             // (the only later writer is this same lane)
-  for (size_t i = tid; i < d; i += T) quot[i] = 0;
-  if (a != rem)
-    for (size_t i = tid; i < d; i += T) rem[i] = a[i];
-  // divisor degree / leading coefficient
-  if (tid == 0) s_top = 0;
-  __syncthreads();
-  long long mine = -1;
-  for (size_t i = tid; i < d2; i += T) if (b[i] != 0) mine = (long long)i;
-  if (mine >= 0) atomicMax(&s_top, (unsigned long long)(mine + 1));
-  __syncthreads();
-  const long long rhs_degree = (long long)s_top - 1;
-  __syncthreads();
-  u64 cinv = 0;
-  if (rhs_degree >= 0) cinv = ops.pow(b[rhs_degree], ops.order() - 2);
-  size_t plen = d;
-  for (;;) {
-    // p_degree = rposition(!= 0) over the current (trimmed) remainder
-    if (tid == 0) s_top = 0;
-    __syncthreads();
-    mine = -1;
-    for (size_t i = tid; i < plen; i += T) if (rem[i] != 0) mine = (long long)i;
-    if (mine >= 0) atomicMax(&s_top, (unsigned long long)(mine + 1));
-    __syncthreads();
-    const long long p_degree = (long long)s_top - 1;
-    __syncthreads();
-    if (!(p_degree >= 0 && plen >= d2)) break;       // while nonzero-count > 0 && len >= rhs.len()
-    if (rhs_degree < 0) { if (tid == 0) *status = -6; break; }  // rposition(..).unwrap() on zero divisor
-    if (p_degree < rhs_degree) break;
-    const size_t diff = (size_t)(p_degree - rhs_degree);
-    if (diff + d2 > plen) { if (tid == 0) *status = -6; break; }  // p_coeffs[diff + i] out of bounds
-    if (tid == 0) { s_s = ops.mul(rem[p_degree], cinv); quot[diff] = s_s; }
-    __syncthreads();
-    const u64 s = s_s;
-    for (size_t i = tid; i < d2; i += T) rem[diff + i] = ops.sub(rem[diff + i], ops.mul(b[i], s));
-    __syncthreads();
-    // trim_zeros: the new length is one past the highest non-zero entry (found by the next scan);
-    // entries above it are already zero, so only the guard `plen >= d2` needs the trimmed value
-    if (tid == 0) s_top = 0;
-    __syncthreads();
-    mine = -1;
-    for (size_t i = tid; i < plen; i += T) if (rem[i] != 0) mine = (long long)i;
-    if (mine >= 0) atomicMax(&s_top, (unsigned long long)(mine + 1));
-    __syncthreads();
-    plen = (size_t)s_top;
-    __syncthreads();
-  }
-}
+// quotient_and_remainder (polynomial/mod.rs:170-225), the long-division kernel: longdiv_kernel.h (its body also runs on host
+// fibers in the CPU suite)
 
 // ---- the same evaluate for the node tables Lagrange::new builds (polynomial/mod.rs:358-365: nodes[i] = omega^i, omega of
 // order n), in O(n): prod_{m != j} (x_j - x_m) = n * x_j^(n-1) = n / x_j and prod_i (x - x_i) = x^n - 1, so

@@ -341,6 +341,37 @@ def test_linear_division_kernels_on_fibers(emu_scan, direct):
     run(emu_scan, GP, 700001, 987654321987, 3, direct, 5)       # 342 chunks: two sums per lane for the low chunks
 
 
+# ---- the long-division kernel (ronkathon_amd/csrc/longdiv_kernel.h) on fibers: tests/emu/emu_longdiv.cpp
+LONGDIV_EXE = os.path.join(ROOT, "build", "emu_longdiv")
+
+
+@pytest.fixture(scope="module")
+def emu_longdiv():
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "emu", "emu_longdiv.cpp")
+    deps = [src] + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("longdiv_kernel.h", "gl64.h")] + \
+           [os.path.join(ROOT, "oracle", "ronk_oracle.c")]
+    if not os.path.exists(LONGDIV_EXE) or any(os.path.getmtime(d) > os.path.getmtime(LONGDIV_EXE) for d in deps):
+        obj = os.path.join(ROOT, "build", "orc_emu_longdiv.o")
+        subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", LONGDIV_EXE, src, obj])
+    return LONGDIV_EXE
+
+
+def test_long_division_kernel_on_fibers(emu_longdiv):
+    """quotient_and_remainder (src/polynomial/mod.rs:170-225) as the one-workgroup kernel runs it -- the dividend copied and the
+    status cleared inside the launch -- against orc_poly_divrem, value for value and panic for panic: random shapes with ragged
+    divisors (trailing zeros: the reference's early stop or index panic), the zero divisor, zero and all-(p-1) dividends,
+    divisors longer than the dividend, in place and out of place; Goldilocks, F_101, F_17, F_2 and a 64-bit prime on the
+    generic operations; 1, 64, 256 and 1024 work-items"""
+    for p, cases, maxd, items, seed in ((0xFFFFFFFF00000001, 400, 200, 64, 3), (101, 400, 200, 64, 3), (17, 400, 200, 64, 3),
+                                        (2, 400, 200, 64, 3), (0xFFFFFFFFFFFFFFC5, 400, 200, 64, 3),
+                                        (0xFFFFFFFF00000001, 12, 1500, 256, 9), (101, 200, 50, 1, 4), (17, 40, 90, 1024, 5)):
+        out = subprocess.run([emu_longdiv, hex(p), str(cases), str(maxd), str(items), str(seed)], capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0 and out.stdout.startswith("OK"), (p, out.stdout[-300:])
+
+
 @pytest.mark.parametrize("args", [(20, 1, 1, 3), (19, 2, 1, 4, 18), (18, 1, 0, 4, 18), (21, 1, 0, 2, 21)])
 def test_r4_round_structure(emu, args):
     """TileCfg::R4 (tile_kernels_r4.hip, opt-in RONK_R4MID=1): passes of 2^9 / 2^10 rows as [16 . 4] . [8 | 16] -- a wave-uniform
