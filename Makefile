@@ -21,7 +21,7 @@ clean:
 .PHONY: all oracle clean
 
 # Sanitizer builds of the host-side code: the oracle under ASan+UBSan, the field header and the
-# tile kernel body + planner (the host emulator; Goldilocks and Montgomery field policies, the R4 round structure) under UBSan (ASan does not follow the emulator's ucontext fibers).
+# tile kernel body + planner (the host emulator; Goldilocks and Montgomery field policies, the R4 round structure; the scan and long-division bodies) under UBSan (ASan does not follow the emulator's ucontext fibers).
 SAN = -g -O1 -fno-omit-frame-pointer -fno-sanitize-recover=all
 sanitize:
 	@mkdir -p build/san
@@ -30,6 +30,7 @@ sanitize:
 	gcc -O1 -c -o build/san/orc.o oracle/ronk_oracle.c
 	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_tile tests/emu/emu_tile.cpp build/san/orc.o
 	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_scan tests/emu/emu_scan.cpp build/san/orc.o
+	g++ $(SAN) -std=c++17 -fsanitize=undefined -o build/san/emu_longdiv tests/emu/emu_longdiv.cpp build/san/orc.o
 	g++ $(SAN) -std=c++17 -fsanitize=address,undefined -o build/san/bn254_san tests/emu/bn254_san.cpp
 	./build/san/oracle_san
 	./build/san/bn254_san
@@ -45,4 +46,6 @@ sanitize:
 	RONK_R4MID=1 ./build/san/emu_tile 19 1 0 4 18 | tail -1
 	./build/san/emu_scan 18446744069414584321 70001 123456789 3 1 | tail -1
 	./build/san/emu_scan 101 5000 7 3 0 | tail -1
+	./build/san/emu_longdiv 18446744069414584321 120 300 64 3 | tail -1
+	./build/san/emu_longdiv 101 120 300 64 3 | tail -1
 .PHONY: sanitize
