@@ -10,7 +10,7 @@
 // node of more than 16 KiB came back as 0xFCFCFCFC from the second replay on, ROCm 7.0.2: profiles/r05_capture_division.txt).
 //
 // The body is written against a small context (work-item id, workgroup size, barrier, two shared words, a shared max) so that
-// the CPU suite runs the very same code on fibers against the oracle's orc_poly_divrem (tests/emu/emu_longdiv.cpp); the kernel
+// the CPU suite runs the very same code on fibers against the CPU restatement of the reference (tests/emu/emu_longdiv.cpp); the kernel
 // is at the end of the file.
 #pragma once
 #include <stddef.h>
