@@ -1,5 +1,7 @@
 """Pin the CPU oracle on every golden vector the reference's own tests hold for the path
 (SURVEY.md section 8c), plus first-principles Goldilocks vectors.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,6 +226,43 @@ def test_goldilocks_derived(glvec):
             assert orc.mul(GP, a, b) == e["mul"][i][j]
         if a:
             assert orc.inverse(GP, a) == e["inv"][i]
+
+
+def test_generic_prime64_derived():
+    """the oracle on the generic odd 64-bit primes of the Montgomery tile path (round 5), pinned like Goldilocks: vectors computed
+    from the definitions with Python integers (tests/golden/make_prime64_vectors.py; no oracle, no library).  The GPU suite then
+    compares the library with the oracle over these same fields (tests/test_gpu_mont.py)."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prime64_derived.json")) as f:
+        fields = json.load(f)["fields"]
+    assert [(e["p"], e["g"]) for e in fields] == [(0xFFFFFFFC00000001, 10), (0x3A00000000000001, 3), (0xC0000001, 5),
+                                                   (0xFFFFFFFF00000001, 343)]
+    for e in fields:
+        p, g = e["p"], e["g"]
+        assert orc.is_prime(p)
+        for k, w in e["roots"].items():
+            assert orc.primitive_root_of_unity(p, g, 1 << int(k)) == w
+        for k, ni in e["n_inverse"].items():
+            assert orc.inverse(p, (1 << int(k)) % p) == ni
+        assert orc.fft(p, g, [1, 2, 3, 4]).tolist() == e["dft_1234"]
+        for case in e["dft_random"]:
+            assert orc.dft(p, g, case["in"]).tolist() == case["out"]
+            assert orc.fft(p, g, case["in"]).tolist() == case["out"]
+            assert orc.ifft(p, g, case["out"]).tolist() == case["in"]
+        for case in e["mul_random"]:
+            assert orc.poly_mul(p, case["a"], case["b"]).tolist() == case["out"]
+        for case in e["divrem_random"]:
+            q, r = orc.poly_divrem(p, case["a"], case["b"])
+            assert q.tolist() == case["quot"] and r.tolist() == case["rem"]
+        ed = e["field_edge"]
+        vals = ed["values"]
+        for i, a in enumerate(vals):
+            for j, b in enumerate(vals):
+                assert orc.add(p, a, b) == ed["add"][i][j]
+                assert orc.sub(p, a, b) == ed["sub"][i][j]
+                assert orc.mul(p, a, b) == ed["mul"][i][j]
+            if a:
+                assert orc.inverse(p, a) == ed["inv"][i]
 
 
 def test_self_consistency_large():
