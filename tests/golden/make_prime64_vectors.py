@@ -16,6 +16,7 @@ PRIMES = [
     (0x3A00000000000001, 3),       # 29 * 2^57 + 1
     (0xC0000001, 5),               # 3 * 2^30 + 1
     (0xFFFFFFFF00000001, 343),     # Goldilocks with another generator (7^3)
+    (0xFFFFFFFF00000001, 7),       # Goldilocks itself: the callers' vectors below (evaluate, Lagrange evaluate, Reed-Solomon)
 ]
 
 
@@ -111,6 +112,36 @@ def main():
                 b[-1] = 1
             q, r = divrem(a, b, p)
             e["divrem_random"].append({"a": a, "b": b, "quot": q, "rem": r})
+        # the callers on the same fields, from their definitions: evaluate = sum c_i x^i (src/polynomial/mod.rs:133-139);
+        # Lagrange evaluate = the value at x of THE polynomial of degree < n through (nodes[j], c[j]) (mod.rs:382-415 computes it
+        # barycentrically; off the nodes the value is the same field element), here by solving for it with the inverse DFT;
+        # Message::encode::<N> = values at omega_N^i of the zero-padded message (src/codes/reed_solomon.rs:42-52), decode = the
+        # message back from its first K coordinates (:54-106)
+        e["evaluate"] = []
+        for d in (1, 2, 9, 40):
+            c = take(gen, d, p)
+            for x in (0, 1, p - 1, take(gen, 1, p)[0]):
+                e["evaluate"].append({"c": c, "x": x, "out": sum(ci * pow(x, i, p) for i, ci in enumerate(c)) % p})
+        e["lagrange_evaluate"] = []
+        for n in (2, 4, 16):
+            w = pow(g, (p - 1) // n, p)
+            nodes = [pow(w, i, p) for i in range(n)]
+            vals = take(gen, n, p)
+            # coefficients of the interpolant: c = (1/n) * DFT with omega^-1 of the values
+            winv, ninv = pow(w, p - 2, p), pow(n, p - 2, p)
+            coef = [sum(vals[j] * pow(winv, i * j, p) for j in range(n)) * ninv % p for i in range(n)]
+            for x in take(gen, 3, p):
+                if x in nodes:
+                    continue
+                e["lagrange_evaluate"].append({"values": vals, "nodes": nodes, "x": x,
+                                               "out": sum(ci * pow(x, i, p) for i, ci in enumerate(coef)) % p})
+        e["reed_solomon"] = []
+        for k, n in ((1, 2), (3, 8), (5, 8), (16, 64)):
+            msg = take(gen, k, p)
+            w = pow(g, (p - 1) // n, p)
+            xs = [pow(w, i, p) for i in range(n)]
+            ys = [sum(mi * pow(x, i, p) for i, mi in enumerate(msg)) % p for x in xs]
+            e["reed_solomon"].append({"msg": msg, "n": n, "xs": xs, "ys": ys})
         edge = sorted({0, 1, 2, p - 1, p - 2, p >> 1, (p >> 1) + 1, 0xFFFFFFFF % p, 0x100000000 % p, (1 << 63) % p})
         e["field_edge"] = {
             "values": edge,

@@ -236,7 +236,7 @@ def test_generic_prime64_derived():
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prime64_derived.json")) as f:
         fields = json.load(f)["fields"]
     assert [(e["p"], e["g"]) for e in fields] == [(0xFFFFFFFC00000001, 10), (0x3A00000000000001, 3), (0xC0000001, 5),
-                                                   (0xFFFFFFFF00000001, 343)]
+                                                   (0xFFFFFFFF00000001, 343), (0xFFFFFFFF00000001, 7)]
     for e in fields:
         p, g = e["p"], e["g"]
         assert orc.is_prime(p)
@@ -254,6 +254,15 @@ def test_generic_prime64_derived():
         for case in e["divrem_random"]:
             q, r = orc.poly_divrem(p, case["a"], case["b"])
             assert q.tolist() == case["quot"] and r.tolist() == case["rem"]
+        for case in e["evaluate"]:
+            assert orc.poly_eval(p, case["c"], case["x"]) == case["out"]
+        for case in e["lagrange_evaluate"]:
+            assert orc.lagrange_nodes(p, g, len(case["nodes"])).tolist() == case["nodes"]
+            assert orc.lagrange_eval(p, case["values"], case["nodes"], case["x"]) == case["out"]
+        for case in e["reed_solomon"]:
+            xs, ys = orc.rs_encode(p, g, case["msg"], case["n"])
+            assert xs.tolist() == case["xs"] and ys.tolist() == case["ys"]
+            assert orc.rs_decode(p, xs, ys, len(case["msg"])).tolist() == case["msg"]
         ed = e["field_edge"]
         vals = ed["values"]
         for i, a in enumerate(vals):
