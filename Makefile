@@ -4,7 +4,7 @@ ARCH ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude
 CSRC = ronkathon_amd/csrc
 LIB = ronkathon_amd/libronk_ntt.so
-OBJS = build/tile_kernels_r4.o build/tile_kernels_mont.o build/tile_kernels_mont_feat.o build/tile_kernels_mont_mul.o build/tile_kernels.o build/tile_kernels_cfg.o build/tile_kernels_half.o build/tile_kernels_feat.o build/tile_kernels_mul.o build/small_kernels.o build/ronk_core.o build/ronk_plan.o build/ronk_callers.o build/ronk_dist.o build/ronk_msm.o
+OBJS = build/tile_kernels_wl.o build/tile_kernels_r4.o build/tile_kernels_mont.o build/tile_kernels_mont_feat.o build/tile_kernels_mont_mul.o build/tile_kernels.o build/tile_kernels_cfg.o build/tile_kernels_half.o build/tile_kernels_feat.o build/tile_kernels_mul.o build/small_kernels.o build/ronk_core.o build/ronk_plan.o build/ronk_callers.o build/ronk_dist.o build/ronk_msm.o
 HDRS = $(wildcard $(CSRC)/*.h) include/ronk_ntt.h
 
 all: $(LIB) oracle

@@ -58,6 +58,7 @@ extern "C" {
 #define RONK_ERR_UNSUPPORTED (-9)   /* size outside what the kernels cover (stated per function) */
 #define RONK_ERR_NO_DEVICE (-10)    /* no HIP device: the library never computes on the CPU */
 #define RONK_ERR_NOT_ON_CURVE (-11) /* assert!(point.is_on_curve(), "Point is not on curve"), src/curve/mod.rs:79 */
+#define RONK_ERR_NOT_RESIDUE (-13)  /* assert!(self.euler_criterion(), "Element is not a quadratic residue"), prime/mod.rs:179 */
 #define RONK_ERR_RCCL (-12)         /* librccl.so could not be loaded or an RCCL call failed; ronk_last_hip_error() has the text */
 
 const char* ronk_strerror(int code);
@@ -84,6 +85,16 @@ int ronk_vec_mul(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out
 int ronk_vec_neg(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
 int ronk_vec_inv(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
 int ronk_vec_pow(uint64_t p, const uint64_t* a, uint64_t e, uint64_t* out, size_t n);
+/* FieldExt (src/algebra/field/mod.rs:79-84) over arrays.
+ * euler_criterion (prime/mod.rs:142-172): out[i] = 1 when a[i]^((p-1)/2) == 1, else 0 (ZERO is no residue by this test).
+ * sqrt (prime/mod.rs:174-226, Tonelli-Shanks): (r0[i], r1[i]) = the two roots of a[i], SMALLER FIRST as the reference returns
+ * them; ZERO -> (0, 0); a non-residue is the reference's assert -> RONK_ERR_NOT_RESIDUE (the _dev form raises *d_status, which
+ * may be NULL, and stores (0, 0) there).  p must be an odd prime (over F_2 the reference's search for a non-residue does not
+ * terminate: RONK_ERR_UNSUPPORTED).  d_r0 may alias d_a. */
+int ronk_vec_euler(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
+int ronk_vec_sqrt(uint64_t p, const uint64_t* a, uint64_t* r0, uint64_t* r1, size_t n);
+int ronk_vec_euler_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_out, size_t n, void* stream);
+int ronk_vec_sqrt_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_r0, uint64_t* d_r1, size_t n, int* d_status, void* stream);
 int ronk_vec_add_dev(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int ronk_vec_sub_dev(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int ronk_vec_mul_dev(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);

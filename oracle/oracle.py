@@ -23,6 +23,7 @@ PANICS = {
     -5: "generator not found",
     -6: "index out of bounds / unwrap on None",
     -11: "Point is not on curve",
+    -13: "Element is not a quadratic residue",
 }
 
 
@@ -62,6 +63,10 @@ def _load():
         "orc_vec_neg": (None, [u64, pu, pu, sz]),
         "orc_vec_inv": (C.c_int, [u64, pu, pu, sz]),
         "orc_vec_pow": (None, [u64, pu, u64, pu, sz]),
+        "orc_euler_criterion": (C.c_int, [u64, u64]),
+        "orc_sqrt": (C.c_int, [u64, u64, pu, pu]),
+        "orc_vec_euler": (None, [u64, pu, pu, sz]),
+        "orc_vec_sqrt": (C.c_int, [u64, pu, pu, pu, sz]),
         "orc_lagrange_nodes": (C.c_int, [u64, u64, pu, sz]),
         "orc_dft": (C.c_int, [u64, u64, pu, pu, sz]),
         "orc_fft": (C.c_int, [u64, u64, pu, pu, sz]),
@@ -165,6 +170,30 @@ def vec_pow(p, a, e):
     a = _arr(a); out = np.empty_like(a)
     _lib.orc_vec_pow(p, _p(a), e, _p(out), a.size)
     return out
+
+
+# ---- FieldExt (field/mod.rs:79-84, prime/mod.rs:142-226) ----
+def euler_criterion(p, a):
+    return bool(_lib.orc_euler_criterion(p, int(a)))
+
+
+def sqrt(p, a):
+    """(smaller root, larger root); OraclePanic(-13) for a non-residue"""
+    r0, r1 = C.c_uint64(0), C.c_uint64(0)
+    _chk(_lib.orc_sqrt(p, int(a), C.byref(r0), C.byref(r1)))
+    return int(r0.value), int(r1.value)
+
+
+def vec_euler(p, a):
+    a = _arr(a); out = np.empty_like(a)
+    _lib.orc_vec_euler(p, _p(a), _p(out), a.size)
+    return out
+
+
+def vec_sqrt(p, a):
+    a = _arr(a); r0 = np.empty_like(a); r1 = np.empty_like(a)
+    _chk(_lib.orc_vec_sqrt(p, _p(a), _p(r0), _p(r1), a.size))
+    return r0, r1
 
 
 # ---- polynomial ----

@@ -158,6 +158,49 @@ void orc_vec_pow(uint64_t p, const uint64_t* a, uint64_t e, uint64_t* out, size_
   for (size_t i = 0; i < n; i++) out[i] = orc_pow(p, a[i], e);
 }
 
+/* ------------------------------------------------------------- FieldExt (field/mod.rs:79-84) */
+
+/* prime/mod.rs:172: self.pow((P - 1) / 2).value == 1 */
+int orc_euler_criterion(uint64_t p, uint64_t a) { return orc_pow(p, a, (p - 1) / 2) == 1; }
+
+/* prime/mod.rs:174-226, Tonelli-Shanks as written: ZERO -> (0, 0); a non-residue trips the assert; the pair is returned
+ * smaller root first (`if -r < r { (-r, r) } else { (r, -r) }`).  P = 2 never leaves the reference's search for a
+ * non-residue (every element passes the criterion there): reported as ORC_PANIC_NOT_RESIDUE too. */
+int orc_sqrt(uint64_t p, uint64_t a, uint64_t* r0, uint64_t* r1) {
+  if (a == 0) { *r0 = *r1 = 0; return ORC_OK; }
+  if (p == 2 || !orc_euler_criterion(p, a)) return ORC_PANIC_NOT_RESIDUE;
+  /* P - 1 = q * 2^s, q odd (the loop of lines 183-195 stops at the first power of two that does not divide P - 1) */
+  uint64_t q = p - 1, s = 0;
+  while ((q & 1) == 0) { q >>= 1; s++; }
+  uint64_t z = orc_new(p, 2);
+  while (orc_euler_criterion(p, z)) z = orc_add(p, z, 1);
+  uint64_t m = s, c = orc_pow(p, z, q), t = orc_pow(p, a, q), r = orc_pow(p, a, (q + 1) / 2);
+  for (;;) {
+    if (t == 1) {
+      const uint64_t nr = orc_neg(p, r);
+      if (nr < r) { *r0 = nr; *r1 = r; } else { *r0 = r; *r1 = nr; }
+      return ORC_OK;
+    }
+    uint64_t i = 1, t_pow = orc_mul(p, t, t);
+    while (t_pow != 1) { t_pow = orc_mul(p, t_pow, t_pow); i++; }
+    const uint64_t b = orc_pow(p, c, (uint64_t)1 << (m - i - 1));
+    m = i;
+    c = orc_mul(p, b, b);
+    t = orc_mul(p, t, c);
+    r = orc_mul(p, r, b);
+  }
+}
+void orc_vec_euler(uint64_t p, const uint64_t* a, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) out[i] = (uint64_t)orc_euler_criterion(p, a[i]);
+}
+int orc_vec_sqrt(uint64_t p, const uint64_t* a, uint64_t* r0, uint64_t* r1, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    int rc = orc_sqrt(p, a[i], &r0[i], &r1[i]);
+    if (rc) return rc;
+  }
+  return ORC_OK;
+}
+
 /* ------------------------------------------------------------- polynomial */
 
 /* polynomial/mod.rs:358-365: nodes[i] = w^i, w = primitive_root_of_unity(n) */

@@ -34,6 +34,7 @@ extern "C" {
 #define ORC_PANIC_NOT_PRIME (-4)    /* is_prime panic, prime/mod.rs:92-100 */
 #define ORC_PANIC_NO_GENERATOR (-5) /* find_primitive_element panic, prime/mod.rs:122 */
 #define ORC_PANIC_INDEX (-6)        /* slice index out of bounds / unwrap on None */
+#define ORC_PANIC_NOT_RESIDUE (-13) /* assert!(self.euler_criterion(), "Element is not a quadratic residue"), prime/mod.rs:179 */
 #define ORC_PANIC_NOT_ON_CURVE (-11) /* assert!(point.is_on_curve(), "Point is not on curve"), curve/mod.rs:79 */
 
 /* ---- prime field: src/algebra/field/prime/{mod,arithmetic}.rs ---- */
@@ -57,6 +58,11 @@ void orc_vec_mul(uint64_t p, const uint64_t* a, const uint64_t* b, uint64_t* out
 void orc_vec_neg(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
 int orc_vec_inv(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
 void orc_vec_pow(uint64_t p, const uint64_t* a, uint64_t e, uint64_t* out, size_t n);
+/* FieldExt (field/mod.rs:79-84) */
+int orc_euler_criterion(uint64_t p, uint64_t a);                              /* prime/mod.rs:172 */
+int orc_sqrt(uint64_t p, uint64_t a, uint64_t* r0, uint64_t* r1);             /* prime/mod.rs:174-226 */
+void orc_vec_euler(uint64_t p, const uint64_t* a, uint64_t* out, size_t n);
+int orc_vec_sqrt(uint64_t p, const uint64_t* a, uint64_t* r0, uint64_t* r1, size_t n);
 
 /* ---- polynomial: src/polynomial/{mod,arithmetic}.rs ---- */
 int orc_lagrange_nodes(uint64_t p, uint64_t g, uint64_t* nodes, size_t n);              /* mod.rs:358-365 */

@@ -28,6 +28,7 @@ OK, ERR_NO_ROOT, ERR_ZERO_INVERSE, ERR_NOT_POW2, ERR_NOT_PRIME = 0, -1, -2, -3, 
 ERR_NO_GENERATOR, ERR_INDEX, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = -5, -6, -7, -8, -9, -10
 ERR_NOT_ON_CURVE = -11
 ERR_RCCL = -12
+ERR_NOT_RESIDUE = -13
 EXCHANGE_MESH, EXCHANGE_RCCL = 0, 1
 
 
@@ -63,6 +64,10 @@ _SIG = {
     "ronk_vec_neg": (_int, [_u64, _vp, _vp, _sz]),
     "ronk_vec_inv": (_int, [_u64, _vp, _vp, _sz]),
     "ronk_vec_pow": (_int, [_u64, _vp, _u64, _vp, _sz]),
+    "ronk_vec_euler": (_int, [_u64, _vp, _vp, _sz]),
+    "ronk_vec_sqrt": (_int, [_u64, _vp, _vp, _vp, _sz]),
+    "ronk_vec_euler_dev": (_int, [_u64, _vp, _vp, _sz, _vp]),
+    "ronk_vec_sqrt_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ronk_vec_add_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
     "ronk_vec_sub_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),
     "ronk_vec_mul_dev": (_int, [_u64, _vp, _vp, _vp, _sz, _vp]),

@@ -94,6 +94,44 @@ __global__ void __launch_bounds__(256) vec_pow_kernel(Ops ops, const u64* __rest
   }
 }
 
+// FieldExt::euler_criterion (field/mod.rs:79-84, prime/mod.rs:172): out[i] = (a[i]^((p-1)/2) == 1)
+template <class Ops>
+__global__ void __launch_bounds__(256) vec_euler_kernel(Ops ops, const u64* __restrict__ a, u64* __restrict__ out, size_t n) {
+  const u64 e = (ops.order() - 1) / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ops.pow(a[i], e) == 1 ? 1 : 0;
+}
+
+// FieldExt::sqrt (prime/mod.rs:174-226), Tonelli-Shanks per element with the constants of the prime from the host
+// (p - 1 = q 2^s, c0 = z^q for the first non-residue z >= 2): ZERO -> (0, 0); a non-residue raises *flag (the reference's
+// assert); the pair is stored smaller root first, as the reference returns it.
+template <class Ops>
+__global__ void __launch_bounds__(256) vec_sqrt_kernel(Ops ops, const u64* __restrict__ a, u64* __restrict__ r0, u64* __restrict__ r1,
+                                                        size_t n, u64 q, u32 s, u64 c0, int* flag) {
+  const u64 half = (ops.order() - 1) / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const u64 x = a[i];
+    if (x == 0) { r0[i] = 0; r1[i] = 0; continue; }
+    if (ops.pow(x, half) != 1) { if (flag) *flag = 1; r0[i] = 0; r1[i] = 0; continue; }
+    u32 m = s;
+    u64 c = c0, t = ops.pow(x, q), r = ops.pow(x, (q + 1) / 2);
+    while (t != 1) {
+      u32 j = 1;
+      u64 tp = ops.mul(t, t);
+      while (tp != 1) { tp = ops.mul(tp, tp); j++; }
+      u64 b = c;
+      for (u32 k = 0; k + j + 1 < m; k++) b = ops.mul(b, b);   // c^(2^(m - j - 1))
+      m = j;
+      c = ops.mul(b, b);
+      t = ops.mul(t, c);
+      r = ops.mul(r, b);
+    }
+    const u64 nr = ops.neg(r);
+    r0[i] = nr < r ? nr : r;
+    r1[i] = nr < r ? r : nr;
+  }
+}
+
 // t[i] = w^i (Lagrange::new's nodes, polynomial/mod.rs:363)
 template <class Ops>
 __global__ void __launch_bounds__(256) power_table_kernel(Ops ops, u64 w, u64* __restrict__ t, size_t n) {

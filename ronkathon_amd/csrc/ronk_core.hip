@@ -33,6 +33,7 @@ extern "C" const char* ronk_strerror(int code) {
     case RONK_ERR_NO_DEVICE: return "no HIP device (libronk_ntt has no CPU path)";
     case RONK_ERR_NOT_ON_CURVE: return "Point is not on curve";
     case RONK_ERR_RCCL: return "RCCL error";
+    case RONK_ERR_NOT_RESIDUE: return "Element is not a quadratic residue";
     default: return "unknown error";
   }
 }
@@ -225,6 +226,66 @@ extern "C" int ronk_vec_pow(uint64_t p, const uint64_t* a, uint64_t e, uint64_t*
 extern "C" int ronk_vec_inv(uint64_t p, const uint64_t* a, uint64_t* out, size_t n) {
   if (p < 2) return RONK_ERR_INVALID;
   return vec_pow_host(p, a, p - 2, out, n, true);
+}
+
+// FieldExt (src/algebra/field/mod.rs:79-84; prime/mod.rs:142-226) over arrays.  The constants of the prime -- p - 1 = q 2^s and
+// c0 = z^q for the first z >= 2 that fails the criterion, exactly the reference's search -- are host integers.
+static int sqrt_consts(u64 p, u64* q, u32* s, u64* c0) {
+  if (p == 2) return RONK_ERR_UNSUPPORTED;   // the reference's non-residue search never ends over F_2
+  u64 qq = p - 1; u32 ss = 0;
+  while ((qq & 1) == 0) { qq >>= 1; ss++; }
+  u64 z = 2 % p;
+  while (h_powmod(z, (p - 1) / 2, p) == 1) z = (z + 1) % p;
+  *q = qq; *s = ss; *c0 = h_powmod(z, qq, p);
+  return RONK_OK;
+}
+extern "C" int ronk_vec_euler_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_out, size_t n, void* st) {
+  if (!d_a || !d_out) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  if (n) FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_euler_kernel<decltype(ops)>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)st,
+                                               ops, d_a, d_out, n); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_vec_sqrt_dev(uint64_t p, const uint64_t* d_a, uint64_t* d_r0, uint64_t* d_r1, size_t n, int* d_status, void* st) {
+  if (!d_a || !d_r0 || !d_r1) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  RCHK(ronk_check_prime(p));
+  u64 q, c0; u32 s;
+  RCHK(sqrt_consts(p, &q, &s, &c0));
+  if (n) FIELD_DISPATCH(f, { hipLaunchKernelGGL((vec_sqrt_kernel<decltype(ops)>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)st,
+                                               ops, d_a, d_r0, d_r1, n, q, s, c0, d_status); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
+extern "C" int ronk_vec_euler(uint64_t p, const uint64_t* a, uint64_t* out, size_t n) {
+  if (!a || !out) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  DevBuf da;
+  RCHK(da.alloc(n * 8));
+  HIPCHK(hipMemcpy(da.p, a, n * 8, hipMemcpyHostToDevice));
+  RCHK(ronk_vec_euler_dev(p, da.u(), da.u(), n, nullptr));
+  HIPCHK(hipMemcpy(out, da.p, n * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
+}
+extern "C" int ronk_vec_sqrt(uint64_t p, const uint64_t* a, uint64_t* r0, uint64_t* r1, size_t n) {
+  if (!a || !r0 || !r1) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  DevBuf da, db, dflag;
+  RCHK(da.alloc(n * 8)); RCHK(db.alloc(n * 8)); RCHK(dflag.alloc(4));
+  HIPCHK(hipMemcpy(da.p, a, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dflag.p, 0, 4));
+  RCHK(ronk_vec_sqrt_dev(p, da.u(), da.u(), db.u(), n, (int*)dflag.p, nullptr));
+  int hflag = 0;
+  HIPCHK(hipMemcpy(&hflag, dflag.p, 4, hipMemcpyDeviceToHost));
+  if (hflag) return RONK_ERR_NOT_RESIDUE;
+  HIPCHK(hipMemcpy(r0, da.p, n * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(r1, db.p, n * 8, hipMemcpyDeviceToHost));
+  return RONK_OK;
 }
 
 // ------------------------------------------------------------------------------ device helpers

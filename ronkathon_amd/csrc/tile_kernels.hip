@@ -55,6 +55,14 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
         if (found) return e;
         continue;
       }
+      // 2^11-row x 4-column passes: wave-local exchange + half image (ntt_tile_wl.h).  RONK_WL = 0 off, 1 both passes, 2 column
+      // pass only, 3 row pass only; RONK_WL_WPE = 8 / 6 waves per SIMD the kernel is built for.
+      static const int wl_mode = [] { const char* e_ = getenv("RONK_WL"); return e_ ? atoi(e_) : 0; }();
+      static const int wl_wpe = [] { const char* e_ = getenv("RONK_WL_WPE"); return e_ ? atoi(e_) : 8; }();
+      if (wl_mode && kind < 4 && logr == 11 && a.logc == 2 && (wl_mode == 1 || (wl_mode == 2 && kind != 2) || (wl_mode == 3 && kind == 2))) {
+        hipError_t e = launch_tile_wl(logr, inverse, kind, wl_wpe, a, grid, s, &found);
+        if (found) return e;
+      }
       if (kind < 4 && use_half(a, logr, grid, block, kind)) {
         hipError_t e = launch_tile_cfg_half(logr, inverse, kind, a, grid, block, lds, s, &found);
         if (found) return e;

@@ -7,6 +7,9 @@
 namespace ronk {
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
                        hipStream_t stream);
+// ntt_tile_wl.h (tile_kernels_wl.hip): 2^11-row x 4-column passes with a wave-local exchange and half the LDS image; wpe = waves
+// per SIMD the kernel is built for (8 or 6); *found = the pass has that shape
+hipError_t launch_tile_wl(int logr, bool inverse, int kind, int wpe, const TileArgs& a, u32 grid, hipStream_t stream, bool* found);
 // the latency form of a pass (ntt_small.h: 4 coefficients per work-item), 2^4 .. 2^10 rows
 hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
                         hipStream_t stream);

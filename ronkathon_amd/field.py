@@ -70,6 +70,38 @@ class _Element:
     def primitive_root_of_unity(cls, n):
         return cls(L.out_scalar(L.lib.ronk_root_of_unity, cls.ORDER, cls._G, int(n)))  # panics: n must divide p^q - 1
 
+    # --- FieldExt trait (field/mod.rs:79-84; prime/mod.rs:142-226)
+    def euler_criterion(self):                   # self.pow((P - 1) / 2).value == 1
+        return self.pow((self.ORDER - 1) // 2).value == 1
+
+    def sqrt(self):
+        """Tonelli-Shanks as the reference writes it: (smaller root, larger root); ZERO -> (0, 0); a non-residue is the
+        reference's assert.  (Over F_2 the reference's search for a non-residue never ends: reported as unsupported.)"""
+        cls, P = type(self), self.ORDER
+        if self.value == 0:
+            return (cls(0), cls(0))
+        if P == 2:
+            raise L.RonkPanic(L.ERR_UNSUPPORTED)
+        if not self.euler_criterion():
+            raise L.RonkPanic(L.ERR_NOT_RESIDUE)
+        q, s = P - 1, 0
+        while q % 2 == 0:
+            q //= 2; s += 1
+        z = cls(2)
+        while z.euler_criterion():
+            z = z + cls(1)
+        m, c, t, r = s, z.pow(q), self.pow(q), self.pow((q + 1) // 2)
+        while True:
+            if t.value == 1:
+                nr = -r
+                return (nr, r) if nr.value < r.value else (r, nr)
+            i, t_pow = 1, t.pow(2)
+            while t_pow.value != 1:
+                t_pow = t_pow.pow(2); i += 1
+            b = c.pow(2 ** (m - i - 1))
+            m, c = i, b.pow(2)
+            t, r = t * c, r * b
+
     # --- operator impls (prime/arithmetic.rs:3-71)
     def _coerce(self, o):
         return o if isinstance(o, type(self)) else type(self)(o)
@@ -129,6 +161,20 @@ class _Element:
         a = L.arr(a); out = np.empty_like(a)
         L.check(L.lib.ronk_vec_pow(cls.ORDER, L.ptr(a), int(e), L.ptr(out), a.size))
         return out
+
+    @classmethod
+    def vec_euler(cls, a):
+        """FieldExt::euler_criterion over an array: 1 where a[i] is a non-zero square, else 0"""
+        a = L.arr(a); out = np.empty_like(a)
+        L.check(L.lib.ronk_vec_euler(cls.ORDER, L.ptr(a), L.ptr(out), a.size))
+        return out
+
+    @classmethod
+    def vec_sqrt(cls, a):
+        """FieldExt::sqrt over an array: (smaller roots, larger roots); a non-residue anywhere is the reference's assert"""
+        a = L.arr(a); r0 = np.empty_like(a); r1 = np.empty_like(a)
+        L.check(L.lib.ronk_vec_sqrt(cls.ORDER, L.ptr(a), L.ptr(r0), L.ptr(r1), a.size))
+        return r0, r1
 
 
 PlutoBaseField = PrimeField(101)     # prime/mod.rs:26

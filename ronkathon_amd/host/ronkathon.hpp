@@ -65,6 +65,40 @@ struct PrimeField {
     auto i = b.inverse(); if (!i) throw Panic(RONK_ERR_ZERO_INVERSE); return a * *i;
   }
   PrimeField operator-() const { return ZERO() - *this; }
+  // FieldExt (field/mod.rs:79-84; prime/mod.rs:142-226)
+  bool euler_criterion() const { return pow((P - 1) / 2).value == 1; }
+  // Tonelli-Shanks as the reference writes it: (smaller root, larger root); ZERO -> (0, 0); a non-residue is its assert
+  std::pair<PrimeField, PrimeField> sqrt() const {
+    if (value == 0) return {ZERO(), ZERO()};
+    if (P == 2) throw Panic(RONK_ERR_UNSUPPORTED);           // the reference's search for a non-residue never ends over F_2
+    if (!euler_criterion()) throw Panic(RONK_ERR_NOT_RESIDUE);
+    uint64_t q = P - 1, s = 0;
+    while ((q & 1) == 0) { q >>= 1; s++; }
+    PrimeField z = new_(2);
+    while (z.euler_criterion()) z = z + ONE();
+    uint64_t m = s;
+    PrimeField c = z.pow(q), t = pow(q), r = pow((q + 1) / 2);
+    for (;;) {
+      if (t.value == 1) { PrimeField nr = -r; return nr.value < r.value ? std::make_pair(nr, r) : std::make_pair(r, nr); }
+      uint64_t i = 1;
+      PrimeField t_pow = t.pow(2);
+      while (t_pow.value != 1) { t_pow = t_pow.pow(2); i++; }
+      PrimeField b = c.pow((uint64_t)1 << (m - i - 1));
+      m = i; c = b.pow(2); t = t * c; r = r * b;
+    }
+  }
+  // the same over arrays, on the GPU (ronk_vec_euler / ronk_vec_sqrt)
+  static std::vector<uint64_t> vec_euler(const std::vector<PrimeField>& a) {
+    std::vector<uint64_t> out(a.size());
+    check(ronk_vec_euler(P, reinterpret_cast<const uint64_t*>(a.data()), out.data(), a.size()));
+    return out;
+  }
+  static std::pair<std::vector<PrimeField>, std::vector<PrimeField>> vec_sqrt(const std::vector<PrimeField>& a) {
+    std::vector<PrimeField> r0(a.size()), r1(a.size());
+    check(ronk_vec_sqrt(P, reinterpret_cast<const uint64_t*>(a.data()), reinterpret_cast<uint64_t*>(r0.data()),
+                        reinterpret_cast<uint64_t*>(r1.data()), a.size()));
+    return {r0, r1};
+  }
   friend bool operator==(PrimeField a, PrimeField b) { return a.value == b.value; }
   friend bool operator!=(PrimeField a, PrimeField b) { return a.value != b.value; }
 };

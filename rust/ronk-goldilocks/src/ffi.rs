@@ -106,6 +106,11 @@ extern "C" {
   pub fn ronk_plan_path(plan: *const RonkPlan) -> c_int;
   /// `PrimeField::new`'s `is_prime` assertion (src/algebra/field/prime/mod.rs:48-51) as a deterministic Miller-Rabin
   pub fn ronk_check_prime(p: u64) -> c_int;
+  /// `FieldExt::euler_criterion` over an array (src/algebra/field/prime/mod.rs:142-172): out[i] = 1 for a non-zero square
+  pub fn ronk_vec_euler(p: u64, a: *const u64, out: *mut u64, n: usize) -> c_int;
+  /// `FieldExt::sqrt` over an array (src/algebra/field/prime/mod.rs:174-226): (smaller root, larger root) per element; a
+  /// non-residue is the reference's assert ("Element is not a quadratic residue")
+  pub fn ronk_vec_sqrt(p: u64, a: *const u64, r0: *mut u64, r1: *mut u64, n: usize) -> c_int;
   pub fn ronk_plan_destroy(plan: *mut RonkPlan) -> c_int;
   /// host pointers through the plan's pinned staging ring (`nodes` may be null)
   pub fn ronk_ntt_forward(plan: *mut RonkPlan, input: *const u64, output: *mut u64, nodes: *mut u64) -> c_int;

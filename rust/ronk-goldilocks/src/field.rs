@@ -15,7 +15,7 @@ use rand::{
   Rng,
 };
 use ronkathon::algebra::{
-  field::{Field, FiniteField},
+  field::{Field, FieldExt, FiniteField},
   Finite,
 };
 
@@ -61,6 +61,72 @@ impl Field for Goldilocks {
       power >>= 1;
     }
     acc
+  }
+}
+
+// ---- FieldExt (src/algebra/field/mod.rs:79-84; PrimeField's impl: prime/mod.rs:142-226)
+/// `PrimeField::euler_criterion` for any 64-bit implementor: `self.pow((P - 1) / 2) == ONE`
+pub(crate) fn euler_criterion_of<F: FiniteField>(x: F) -> bool { x.pow((F::ORDER - 1) / 2) == F::ONE }
+
+/// `PrimeField::sqrt` (Tonelli-Shanks, prime/mod.rs:174-226) statement by statement for any 64-bit implementor whose
+/// `PartialOrd` compares canonical residues: ZERO -> (ZERO, ZERO); a non-residue panics with the reference's message; the
+/// pair comes back smaller root first.
+pub(crate) fn sqrt_of<F: FiniteField + PartialOrd>(x: F) -> Option<(F, F)> {
+  if x == F::ZERO {
+    return Some((F::ZERO, F::ZERO));
+  }
+  assert!(euler_criterion_of(x), "Element is not a quadratic residue");
+  // P - 1 = q * 2^s, q odd
+  let (mut q, mut s) = (F::ORDER - 1, 0u32);
+  while q % 2 == 0 {
+    q /= 2;
+    s += 1;
+  }
+  // the first z >= 2 that is not a quadratic residue
+  let mut z = F::ONE + F::ONE;
+  while euler_criterion_of(z) {
+    z += F::ONE;
+  }
+  let (mut m, mut c, mut t, mut r) = (s, z.pow(q), x.pow(q), x.pow((q + 1) / 2));
+  loop {
+    if t == F::ONE {
+      return if -r < r { Some((-r, r)) } else { Some((r, -r)) };
+    }
+    let (mut i, mut t_pow) = (1u32, t.pow(2));
+    while t_pow != F::ONE {
+      t_pow = t_pow.pow(2);
+      i += 1;
+    }
+    let b = c.pow(2_usize.pow(m - i - 1));
+    m = i;
+    c = b.pow(2);
+    t *= c;
+    r *= b;
+  }
+}
+
+impl FieldExt for Goldilocks {
+  fn sqrt(&self) -> Option<(Self, Self)> { sqrt_of(*self) }
+
+  fn euler_criterion(&self) -> bool { euler_criterion_of(*self) }
+}
+
+impl Goldilocks {
+  /// `euler_criterion` of every element on the GPU (`ronk_vec_euler`): 1 for a non-zero square, else 0
+  pub fn euler_criterion_many(a: &[Self]) -> Vec<bool> {
+    let mut out = vec![0u64; a.len()];
+    crate::ffi::check(unsafe { crate::ffi::ronk_vec_euler(P, a.as_ptr() as *const u64, out.as_mut_ptr(), a.len()) });
+    out.into_iter().map(|v| v == 1).collect()
+  }
+
+  /// `sqrt` of every element on the GPU (`ronk_vec_sqrt`): (smaller root, larger root); panics like the reference when an
+  /// element is no residue
+  pub fn sqrt_many(a: &[Self]) -> Vec<(Self, Self)> {
+    let (mut r0, mut r1) = (vec![Self(0); a.len()], vec![Self(0); a.len()]);
+    crate::ffi::check(unsafe {
+      crate::ffi::ronk_vec_sqrt(P, a.as_ptr() as *const u64, r0.as_mut_ptr() as *mut u64, r1.as_mut_ptr() as *mut u64, a.len())
+    });
+    r0.into_iter().zip(r1).collect()
   }
 }
 

@@ -26,7 +26,7 @@ use rand::{
 };
 use ronkathon::{
   algebra::{
-    field::{Field, FiniteField},
+    field::{Field, FieldExt, FiniteField},
     Finite,
   },
   polynomial::{Lagrange, Monomial, Polynomial},
@@ -80,6 +80,30 @@ impl<const P: u64, const G: u64> Field for Prime64<P, G> {
 
 impl<const P: u64, const G: u64> FiniteField for Prime64<P, G> {
   const PRIMITIVE_ELEMENT: Self = Self(G % P);
+}
+
+/// `FieldExt` (src/algebra/field/mod.rs:79-84) as `PrimeField<P>` implements it (prime/mod.rs:142-226): field.rs holds the
+/// statement-by-statement Tonelli-Shanks shared with `Goldilocks`
+impl<const P: u64, const G: u64> FieldExt for Prime64<P, G> {
+  fn sqrt(&self) -> Option<(Self, Self)> { crate::field::sqrt_of(*self) }
+
+  fn euler_criterion(&self) -> bool { crate::field::euler_criterion_of(*self) }
+}
+
+impl<const P: u64, const G: u64> Prime64<P, G> {
+  /// `sqrt` of every element on the GPU (`ronk_vec_sqrt`, Montgomery arithmetic): (smaller root, larger root)
+  pub fn sqrt_many(a: &[Self]) -> Vec<(Self, Self)> {
+    let (mut r0, mut r1) = (vec![Self(0); a.len()], vec![Self(0); a.len()]);
+    check(unsafe { ffi::ronk_vec_sqrt(P, a.as_ptr() as *const u64, r0.as_mut_ptr() as *mut u64, r1.as_mut_ptr() as *mut u64, a.len()) });
+    r0.into_iter().zip(r1).collect()
+  }
+
+  /// `euler_criterion` of every element on the GPU (`ronk_vec_euler`)
+  pub fn euler_criterion_many(a: &[Self]) -> Vec<bool> {
+    let mut out = vec![0u64; a.len()];
+    check(unsafe { ffi::ronk_vec_euler(P, a.as_ptr() as *const u64, out.as_mut_ptr(), a.len()) });
+    out.into_iter().map(|v| v == 1).collect()
+  }
 }
 
 impl<const P: u64, const G: u64> Add for Prime64<P, G> {

@@ -53,6 +53,26 @@ int main() {
   CHECK(B::PRIMITIVE_ELEMENT() == B::new_(2) && PlutoScalarField::PRIMITIVE_ELEMENT() == PlutoScalarField::new_(14));
   CHECK(panics([] { PlutoScalarField::primitive_root_of_unity(3); }, RONK_ERR_NO_ROOT));   // not_primitive_root_of_unity
   CHECK(panics([] { PrimeField<100>::new_(0); }, RONK_ERR_NOT_PRIME));                     // non_prime_is_not_finite_field
+  // FieldExt (prime/mod.rs:142-226; rstest cases :392-408): scalar Tonelli-Shanks on the host, arrays on the GPU
+  CHECK(B::new_(4).sqrt() == std::make_pair(B::new_(2), B::new_(99)));
+  CHECK(B::new_(5).sqrt() == std::make_pair(B::new_(45), B::new_(56)));
+  CHECK(B::new_(6).sqrt() == std::make_pair(B::new_(39), B::new_(62)));
+  CHECK(B::new_(0).sqrt() == std::make_pair(B::new_(0), B::new_(0)));
+  CHECK(panics([] { (void)B::new_(2).sqrt(); }, RONK_ERR_NOT_RESIDUE));
+  CHECK(B::new_(4).euler_criterion() && !B::new_(2).euler_criterion());
+  {
+    std::vector<B> sq = {B::new_(4), B::new_(5), B::new_(6), B::new_(0)};
+    auto roots = B::vec_sqrt(sq);
+    CHECK((roots.first == std::vector<B>{B::new_(2), B::new_(45), B::new_(39), B::new_(0)}));
+    CHECK((roots.second == std::vector<B>{B::new_(99), B::new_(56), B::new_(62), B::new_(0)}));
+    CHECK((B::vec_euler({B::new_(4), B::new_(2), B::new_(0)}) == std::vector<uint64_t>{1, 0, 0}));
+    CHECK(panics([] { (void)B::vec_sqrt({B::new_(4), B::new_(2)}); }, RONK_ERR_NOT_RESIDUE));
+    using GF = GoldilocksField;
+    GF x = GF::new_(0x123456789ABCDEFull), y = x * x;
+    auto r = y.sqrt();
+    CHECK(r.first * r.first == y && (r.first == x || r.second == x) && r.first.value < r.second.value);
+    CHECK((GF::vec_sqrt({y}).first[0] == r.first));
+  }
   // the 64-bit field: derived vector and a 2^16 round trip (too big for the stack -> heap)
   using G = GoldilocksField;
   CHECK(G::PRIMITIVE_ELEMENT() == G::new_(7));

@@ -325,6 +325,16 @@ static void replay_prime64(uint64_t P2, uint64_t G2, size_t D, size_t D2) {
     EXPECT(orc_poly_divrem(P2, c, D, b, D2, qr, rr) == 0 && !memcmp(q, qr, D * 8) && !memcmp(r, rr, D * 8), "prime64 divrem values");
     free(q); free(r); free(qr); free(rr);
   }
+  /* Prime64::sqrt_many / euler_criterion_many (FieldExt over arrays): squares of the first coefficients */
+  { size_t m = D < 256 ? D : 256;
+    uint64_t *sq = malloc(m * 8), *r0 = malloc(m * 8), *r1 = malloc(m * 8), *o0 = malloc(m * 8), *o1 = malloc(m * 8);
+    for (size_t i = 0; i < m; i++) sq[i] = orc_mul(P2, c[i], c[i]);
+    EXPECT(ronk_vec_sqrt(P2, sq, r0, r1, m) == 0 && orc_vec_sqrt(P2, sq, o0, o1, m) == 0 && !memcmp(r0, o0, m * 8) && !memcmp(r1, o1, m * 8),
+           "prime64 sqrt_many");
+    EXPECT(ronk_vec_euler(P2, c, r0, m) == 0, "prime64 euler_criterion_many");
+    orc_vec_euler(P2, c, o0, m);
+    EXPECT(!memcmp(r0, o0, m * 8), "prime64 euler values");
+    free(sq); free(r0); free(r1); free(o0); free(o1); }
   /* PrimePlan::new(log2n, 1): ronk_plan_create(&raw, P, G, log2n, 1, -1); path(); forward; inverse; drop */
   unsigned lg = 0; while (((size_t)1 << lg) < D) lg++;
   ronk_plan* pl = NULL;

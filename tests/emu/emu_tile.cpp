@@ -20,6 +20,7 @@
 #include "../../ronkathon_amd/csrc/ntt_small.h"
 #include "../../ronkathon_amd/csrc/ntt_mul.h"
 #include "../../ronkathon_amd/csrc/tile_cfg_table.h"
+#include "../../ronkathon_amd/csrc/ntt_tile_wl.h"
 
 using namespace ronk;
 
@@ -75,6 +76,21 @@ static bool dispatch_cfg(int logr, u32 tid) {
 #undef EMU_MONT_CASE
     return false;
   } else {
+  // the wave-local / half-image bodies of the 2^11-row x 4-column passes (ntt_tile_wl.h; RONK_WL as in the library: 1 both
+  // passes, 2 column pass only, 3 row pass only)
+  static const int wl = getenv("RONK_WL") ? atoi(getenv("RONK_WL")) : 0;
+  if (wl && logr == WL_LOGR && (int)a.logc == WL_LOGC) {
+    for (int kind : {1, 2, 3}) {
+      if (!tile_wl_matches(a, logr, kind)) continue;
+      if (kind == 2 ? wl == 2 : wl == 3) continue;
+      u32* l32 = reinterpret_cast<u32*>(g_fa.lds);
+      if (kind == 1) tile_body_wl_col<INV, 1>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+      else if (kind == 3) tile_body_wl_col<INV, 3>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+      else tile_body_wl_row<INV>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+      g_cfg_used = 30 + kind;
+      return true;
+    }
+  }
   if (half) {
 #define EMU_HALF_CASE(LR, LC, KD)                                                                \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
@@ -426,7 +442,7 @@ int main(int argc, char** argv) {
     printf("pass logr=%d logc=%u tiles=%u nb1=%u nb2=%u grid=%u block=%u lds=%zu kernel=%s\n", p.logr, a.logc, a.tiles,
            a.nb1, a.nb2, p.grid, p.block, p.lds_bytes, g_cfg_used == 1 ? "cfg:column/two-level" : g_cfg_used == 3 ? "cfg:column/matrix" :
            g_cfg_used == 2 ? "cfg:row" : g_cfg_used == 5 ? "cfg:whole" : g_cfg_used == 4 ? "cfg:general" : g_cfg_used == 11 ? "half:column/two-level" : g_cfg_used == 13 ? "half:column/matrix" :
-           g_cfg_used == 12 ? "half:row" : g_cfg_used == 21 ? "r4:column/two-level" : g_cfg_used == 23 ? "r4:column/matrix" : g_cfg_used == 22 ? "r4:row" : g_cfg_used >= 100 ? (g_cfg_used % 100 == 2 ? "feat:row" : g_cfg_used % 100 == 3 ? "feat:column/matrix" : "feat:column/two-level") :
+           g_cfg_used == 12 ? "half:row" : g_cfg_used == 31 ? "wl:column/two-level" : g_cfg_used == 33 ? "wl:column/matrix" : g_cfg_used == 32 ? "wl:row" : g_cfg_used == 21 ? "r4:column/two-level" : g_cfg_used == 23 ? "r4:column/matrix" : g_cfg_used == 22 ? "r4:row" : g_cfg_used >= 100 ? (g_cfg_used % 100 == 2 ? "feat:row" : g_cfg_used % 100 == 3 ? "feat:column/matrix" : "feat:column/two-level") :
            p.small ? "small" : "generic");
   }
   if (in_valid) for (u64 b = 0; b < batch; b++) for (u64 i = (b && in_valid1) ? in_valid1 : in_valid; i < n; i++) in[b * n + i] = 0;  // what the kernel must have seen

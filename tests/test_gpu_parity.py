@@ -62,6 +62,34 @@ def test_field_kats_on_gpu(R, refvec):
         assert np.array_equal(F.vec_mul(nz, F.vec_inv(nz)), np.ones(p - 1, dtype=np.uint64))
 
 
+def test_field_ext_sqrt_on_gpu(R, orc, refvec):
+    """FieldExt::sqrt / euler_criterion over arrays (ronk_vec_sqrt / ronk_vec_euler; reference prime/mod.rs:142-226): the
+    reference's rstest cases and residue list on the GPU, then whole arrays against the oracle's Tonelli-Shanks over F_101,
+    Goldilocks (2-adicity 32: the longest loop) and a Montgomery prime above 2^63; the host mirror's scalar form beside it"""
+    v = refvec["field_sqrt"]
+    F = R.PlutoBaseField
+    r0, r1 = F.vec_sqrt([c[1] for c in v["cases"]])
+    assert r0.tolist() == [c[2] for c in v["cases"]] and r1.tolist() == [c[3] for c in v["cases"]]
+    for p, a, x0, x1 in v["cases"]:
+        assert tuple(int(t) for t in R.PrimeField(p)(a).sqrt()) == (x0, x1)
+    with pytest.raises(R.RonkPanic) as e:
+        F.vec_sqrt([4, 2, 5])
+    assert e.value.code == -13
+    with pytest.raises(R.RonkPanic):
+        F(2).sqrt()
+    assert F.vec_euler(np.arange(101, dtype=np.uint64)).tolist() == [1 if a in v["residues_101"] else 0 for a in range(101)]
+    for p in (101, GP, 0xFFFFFFFC00000001, 29 * 2**57 + 1):
+        Fp = R.PrimeField(p)
+        x = splitmix_field(0x5EED0500 + p % 97, 4096, p)
+        x[0] = 0; x[1] = 1; x[2] = p - 1
+        y = Fp.vec_mul(x, x)
+        r0, r1 = Fp.vec_sqrt(y)
+        o0, o1 = orc.vec_sqrt(p, y)
+        assert np.array_equal(r0, o0) and np.array_equal(r1, o1), p
+        assert np.array_equal(Fp.vec_euler(x), orc.vec_euler(p, x)), p
+        assert tuple(int(t) for t in Fp(int(y[7])).sqrt()) == (int(o0[7]), int(o1[7]))
+
+
 def test_polynomial_kats_on_gpu(R, refvec):
     F = R.PlutoBaseField
     v = refvec

@@ -34,6 +34,30 @@ def test_field_kats(refvec):
         assert orc.div(p, a, 2) == r
 
 
+def test_field_ext_sqrt(refvec):
+    """FieldExt::sqrt / euler_criterion (prime/mod.rs:142-226): the reference's rstest cases, its list of the quadratic
+    residues of GF(101), and the root pair's order / squares over every field of the tests"""
+    v = refvec["field_sqrt"]
+    for p, a, r0, r1 in v["cases"]:
+        assert orc.sqrt(p, a) == (r0, r1)
+    for p, a in v["panics"]:
+        with pytest.raises(OraclePanic) as e:
+            orc.sqrt(p, a)
+        assert e.value.code == -13
+    assert [a for a in range(1, 101) if orc.euler_criterion(101, a)] == v["residues_101"]
+    assert not orc.euler_criterion(101, 0)
+    for p in (17, 101, 127, GP, 0xFFFFFFFC00000001):
+        rng = np.random.default_rng(p % 1000)
+        xs = [int(x) % (p - 1) + 1 for x in rng.integers(1, 2**63, size=64)]
+        for x in xs:
+            y = x * x % p
+            assert orc.sqrt(p, y) == (min(x, p - x), max(x, p - x))
+        ys = np.array([x * x % p for x in xs], dtype=np.uint64)
+        r0, r1 = orc.vec_sqrt(p, ys)
+        assert all(int(a) * int(a) % p == int(y) and int(a) + int(b) == p for a, b, y in zip(r0, r1, ys))
+        assert orc.vec_euler(p, ys).tolist() == [1] * 64
+
+
 def test_prime_and_generator(refvec):
     assert not orc.is_prime(refvec["non_prime_panics"]["p"])
     for p in refvec["generator"]["primes"]:
