@@ -315,6 +315,11 @@ def main():
             sys.exit("bench.py --workload fourstep: --exchange %s needs %s" % (
                 want, {"rccl": "the nccl backend (unset RONK_BENCH_BACKEND)", "host": "RONK_BENCH_BACKEND=gloo",
                        "mesh": "--workload sharded (the one-process in-library form)"}[want]))
+        # fail fast, BEFORE anything is timed: every rank the launcher promised took part in this collective
+        one0_ = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(one0_)
+        assert int(one0_.item()) == args.gpus, "ranks_seen %d != --gpus %d (before timing)" % (int(one0_.item()), args.gpus)
         res = rdist.bench_fourstep(args.log2n or 26, args.steps, args.warmup, chunks=args.chunks or None)
         res["config"]["exchange"] = want
         # what the all-to-all rides on: can this rank's GPU reach the others peer-to-peer (xGMI)?  RCCL falls back to host
@@ -498,6 +503,12 @@ def main():
             dts.append(time.perf_counter() - t0)
         dt = float(np.median(dts))
         nn = 1 << lg
+        # where the time of ONE transform goes when its stages do not overlap (ronk_sharded_time_stages): phase 1, the whole
+        # exchange, phase 2, and the achieved rate per directed link -- so that a first run on a real node can be read without a
+        # second lease (a link rate far below xGMI's, or staged pairs above, says the exchange is not travelling peer-to-peer)
+        stage_runs = [sp.time_stages(ip, op) for _ in range(3)]
+        stages = min(stage_runs, key=lambda d_: d_["phase1_ms"] + d_["exchange_ms"] + d_["phase2_ms"])
+        stages["overlap_gain_ms"] = stages["phase1_ms"] + stages["exchange_ms"] + stages["phase2_ms"] - dt / args.steps * 1e3
         print(json.dumps({"metric": "sharded four-step forward NTTs/s (in-library, single process), degree 2^%d" % lg,
                           "value": args.steps / dt, "unit": "NTT/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": min(dts) / args.steps * 1e3,
@@ -510,6 +521,7 @@ def main():
                                      # runtime refused peer access and copies go through host memory -- the number below would
                                      # then measure THAT, not xGMI
                                      "peer_access": dict(zip(("matrix", "staged_pairs"), sp.peer_access())),
+                                     "stages_serialised": stages,
                                      "ranks_per_gpu": W / float(ndev)},
                           "roofline": {"bound": "hbm", "achieved": 16.0 * nn / ndev / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": 16.0 * nn / ndev / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None}}))

@@ -130,11 +130,13 @@ typedef struct ronk_plan_opts {
   int in_flight;                /* -1 auto, 1, 2 */
   int split_log2_rows;          /* two-pass plans (2^13 .. 2^24): log2 of the first pass's rows, 0 = the planner's (balanced)
                                    choice; values that leave a pass outside 2^4 .. 2^12 rows are ignored */
-  int reserved[4];              /* zero.  reserved[0], when in 13 .. 25: the smallest log2n that is split in THREE passes (the
-                                   planner's default is 23 -- 24 for ONE transform of 2^23 --; the fused multiply asks for two-pass
-                                   plans of a batch of two at 2^23).  The other three stay zero */
+  int three_pass_from_log2;     /* 0 = the planner's choice (23; 24 for ONE transform of 2^23); 13 .. 25: the smallest log2n that is
+                                   split in THREE passes (the fused multiply asks for two-pass plans of a batch of two at 2^23).
+                                   (Round 6: a named field in the place of reserved[0], which carried this knob unnamed -- same
+                                   layout, same size.) */
+  int reserved[3];              /* zero */
 } ronk_plan_opts;
-#define RONK_PLAN_OPTS_DEFAULT { -1, -1, -1, 0, { 0, 0, 0, 0 } }
+#define RONK_PLAN_OPTS_DEFAULT { -1, -1, -1, 0, 0, { 0, 0, 0 } }
 int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, uint32_t log2n, uint64_t batch, int device,
                           const ronk_plan_opts* opts);
 /* 1 or 2: the lanes the plan actually uses (see ronk_plan_opts::in_flight) */
@@ -303,6 +305,12 @@ int ronk_dist_plan_destroy(ronk_dist_plan* plan);
  * chunk j) at d_recv[(g*chunks + j)*(R/world)*Cwc ..).  chunks = 1 is ronk_dist_plan_create. */
 int ronk_dist_plan_create_chunked(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world, int device,
                                   int chunks);
+/* The same over ANY field the single-GPU plans cover (round 6): p an odd prime with 2^log2n | p - 1 and g a primitive element
+ * (a quadratic non-residue suffices; otherwise RONK_ERR_UNSUPPORTED -- the four-step has no radix-2 fallback); omega =
+ * g^((p-1)/n) as in PrimeField<P> (src/algebra/field/mod.rs:70-75, prime/mod.rs:39-52).  The phases run the tile kernels over
+ * Montgomery arithmetic.  ronk_dist_plan_create(_chunked) are the shorthands for (RONK_GOLDILOCKS_P, RONK_GOLDILOCKS_G). */
+int ronk_dist_plan_create_p(ronk_dist_plan** out, uint64_t p, uint64_t g, uint32_t log2n, int inverse, int rank, int world,
+                            int device, int chunks);
 int ronk_dist_phase1_chunk_dev(ronk_dist_plan* plan, int chunk, const uint64_t* d_in, uint64_t* d_send, void* stream);
 /* phase 1: R-point NTTs down the local columns, times omega_n^{c*k1}; output is written as `world`
  * consecutive send blocks, block h = rows k1 in h's range, layout [R/world][C/world] */
@@ -330,6 +338,19 @@ int ronk_lagrange_eval_dev(uint64_t p, const uint64_t* d_c, const uint64_t* d_no
  * the O(n log n) Newton form on the NTT path runs, as behind ronk_poly_divrem.  A capturing stream keeps the long division. */
 int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2, uint64_t* d_quot,
                          uint64_t* d_rem, int* d_status, void* stream);
+/* Round 6: the O(n log n) form serves EVERY odd prime whose p - 1 has the 2-adicity of the product sizes (2^(ceil(log2 d) + 1)
+ * divides p - 1), not only Goldilocks -- behind ronk_poly_divrem and ronk_poly_divrem_dev alike; the products' transform
+ * root is any quadratic non-residue found by the library (a product does not depend on it), so no generator is asked for.
+ * Under stream capture ronk_poly_divrem_dev cannot probe the degrees: it captures the long division while that is a matter
+ * of milliseconds (d2 * (d - d2 + 1) <= 1e9) and returns RONK_ERR_UNSUPPORTED beyond.
+ *
+ * quotient_and_remainder for FULL-LENGTH operands (a[d-1] != 0, b[d2-1] != 0, d >= d2): the same O(n log n) form with nothing
+ * read back -- the divisor's leading coefficient is inverted on the device and the promise is checked there (*d_status =
+ * RONK_ERR_INVALID when a top coefficient is ZERO: the outputs are then meaningless) -- so the call is asynchronous on `stream`
+ * and capturable at any size (warm the workspace with one call outside the capture).  Fields as above, else
+ * RONK_ERR_UNSUPPORTED.  For full-length operands the reference's loop is plain Euclidean division (mod.rs:170-225). */
+int ronk_poly_divrem_full_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2, uint64_t* d_quot,
+                              uint64_t* d_rem, int* d_status, void* stream);
 /* Message::decode (src/codes/reed_solomon.rs:54-106); d_status may be NULL */
 int ronk_rs_decode_dev(uint64_t p, const uint64_t* d_xs, const uint64_t* d_ys, size_t k, uint64_t* d_out, int* d_status,
                        void* stream);
@@ -355,7 +376,15 @@ int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n, int invers
 #define RONK_EXCHANGE_RCCL 1
 int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev, int chunks,
                                 int exchange);
+/* The same over any field ronk_dist_plan_create_p takes (round 6): (p, g) as there; every rank's phases run the tile kernels
+ * over Montgomery arithmetic.  ronk_sharded_plan_create(_ex) are the shorthands for the Goldilocks field. */
+int ronk_sharded_plan_create_p(ronk_sharded_plan** out, uint64_t p, uint64_t g, uint32_t log2n, int inverse, const int* devices,
+                               int ndev, int chunks, int exchange);
 int ronk_sharded_plan_exchange(const ronk_sharded_plan* plan);
+/* Diagnostics (bench.py --workload sharded): ONE transform in three SERIALISED stages -- every rank's phase 1, the whole
+ * exchange, every rank's phase 2 -- all devices drained between them; ms[0..2] = wall milliseconds per stage.  The achieved
+ * rate per directed link is n * 8 / ndev^2 bytes / ms[1].  Same d_out as ronk_ntt_sharded_dev (which overlaps the stages). */
+int ronk_sharded_time_stages(ronk_sharded_plan* plan, const uint64_t* const* d_in, uint64_t* const* d_out, float* ms);
 /* How a block travels between the ranks of a mesh-exchange plan, decided at plan creation and kept (never silent):
  * matrix[g * ndev + h] = RONK_PEER_SAME_DEVICE (ranks g and h share a GPU), RONK_PEER_DIRECT (hipDeviceCanAccessPeer said yes and
  * peer access is enabled: xGMI / PCIe peer-to-peer) or RONK_PEER_STAGED (refused: hipMemcpyPeerAsync stages through host

@@ -111,6 +111,7 @@ _SIG = {
     "ronk_dist_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int]),
     "ronk_dist_plan_destroy": (_int, [_vp]),
     "ronk_dist_plan_create_chunked": (_int, [C.POINTER(_vp), C.c_uint32, _int, _int, _int, _int, _int]),
+    "ronk_dist_plan_create_p": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _int, _int, _int, _int, _int]),
     "ronk_dist_phase1_chunk_dev": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ronk_dist_phase1_dev": (_int, [_vp, _vp, _vp, _vp]),
     "ronk_dist_phase2_dev": (_int, [_vp, _vp, _vp, _vp]),
@@ -120,10 +121,13 @@ _SIG = {
     "ronk_dft_dev": (_int, [_u64, _u64, _vp, _vp, _sz, _vp]),
     "ronk_lagrange_eval_dev": (_int, [_u64, _vp, _vp, _sz, _u64, _vp, _vp, _vp]),
     "ronk_poly_divrem_dev": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "ronk_poly_divrem_full_dev": (_int, [_u64, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ronk_rs_decode_dev": (_int, [_u64, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ronk_curve_msm_dev": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "ronk_sharded_plan_create": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int]),
     "ronk_sharded_plan_create_ex": (_int, [C.POINTER(_vp), C.c_uint32, _int, C.POINTER(_int), _int, _int, _int]),
+    "ronk_sharded_time_stages": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_float)]),
+    "ronk_sharded_plan_create_p": (_int, [C.POINTER(_vp), _u64, _u64, C.c_uint32, _int, C.POINTER(_int), _int, _int, _int]),
     "ronk_sharded_plan_exchange": (_int, [_vp]),
     "ronk_sharded_plan_peer_access": (_int, [_vp, C.POINTER(_int), _int]),
     "ronk_sharded_plan_destroy": (_int, [_vp]),
@@ -178,7 +182,7 @@ def out_scalar(fn, *args):
 class PlanOpts(C.Structure):
     """ronk_plan_opts (include/ronk_ntt.h)"""
     _fields_ = [("tile_log2_columns", _int), ("twiddle_matrix_log2_max", _int), ("in_flight", _int), ("split_log2_rows", _int),
-                ("reserved", _int * 4)]
+                ("three_pass_from_log2", _int), ("reserved", _int * 3)]
 
     def __init__(self, tile_log2_columns=-1, twiddle_matrix_log2_max=-1, in_flight=-1):
         super().__init__(tile_log2_columns, twiddle_matrix_log2_max, in_flight)
@@ -263,11 +267,15 @@ class ShardedPlan:
     xGMI in column chunks).  Rank g = devices[g]; the same ordinal may appear several times (logical ranks sharing a GPU:
     how the single-GPU tests drive this path)."""
 
-    def __init__(self, log2n, devices, inverse=False, chunks=0, exchange=EXCHANGE_MESH):
+    def __init__(self, log2n, devices, inverse=False, chunks=0, exchange=EXCHANGE_MESH, p=None, g=None):
+        """p, g: any odd prime with 2^log2n | p - 1 and a primitive element of it (ronk_sharded_plan_create_p); default Goldilocks"""
         self.h = None
         h = _vp()
         devs = (_int * len(devices))(*devices)
-        check(lib.ronk_sharded_plan_create_ex(C.byref(h), log2n, int(inverse), devs, len(devices), chunks, exchange))
+        if p is None:
+            check(lib.ronk_sharded_plan_create_ex(C.byref(h), log2n, int(inverse), devs, len(devices), chunks, exchange))
+        else:
+            check(lib.ronk_sharded_plan_create_p(C.byref(h), int(p), int(g), log2n, int(inverse), devs, len(devices), chunks, exchange))
         self.exchange = exchange
         self.h, self.n, self.ndev = h, 1 << log2n, len(devices)
         r, c, per, ch = _u64(0), _u64(0), _u64(0), _int(0)
@@ -291,6 +299,18 @@ class ShardedPlan:
         out = np.empty_like(x)
         check(lib.ronk_ntt_sharded(self.h, ptr(x), ptr(out)))
         return out
+
+    def time_stages(self, d_in, d_out):
+        """one transform in three serialised stages (ronk_sharded_time_stages): [phase 1, exchange, phase 2] in ms, and the
+        achieved GB/s per directed link of the exchange"""
+        a = (_vp * self.ndev)(*d_in)
+        b = (_vp * self.ndev)(*d_out)
+        ms = (C.c_float * 3)()
+        check(lib.ronk_sharded_time_stages(self.h, a, b, ms))
+        t = [float(v) for v in ms]
+        per_link = self.n * 8 / (self.ndev ** 2)
+        return {"phase1_ms": t[0], "exchange_ms": t[1], "phase2_ms": t[2],
+                "bytes_per_directed_link": per_link, "GBs_per_directed_link": per_link / (t[1] * 1e-3) / 1e9 if t[1] > 0 else None}
 
     def transform_dev(self, d_in, d_out):
         """device pointers per rank (lists of ints); asynchronous, see sync()"""

@@ -1,30 +1,38 @@
 // ntt_tile_wl.h -- the 2^11-row x 4-column tile passes of the two-pass plans (2^21 .. 2^23: the headline 2^22 among them) with
-// HALF the LDS image and TWO workgroup barriers per pass, so that 3-4 eight-wavefront workgroups are resident per CU (24-32
-// wavefronts) instead of two (16).
+// ONE wave-local and ONE cross-wave LDS exchange per pass: one workgroup barrier per pass (FULL image) instead of three.
 //
-// Why (rounds 4-5): between 245 and 280 VALU per coefficient the 2^22 transform's time is set by how many
-// wavefronts are in an arithmetic phase at once.  ntt_tile.h parks a whole tile in LDS between rounds -- 8.5 KiB per wavefront,
-// 16 wavefronts per CU -- and its half-image form (TileCfg::HALF) pays for 8 per SIMD with two more workgroup barriers per
-// exchange.  Here, with rows j = 128 j1 + 8 j2 + j3 (digits of the rounds 16, 16, 8):
-//   * ONE of the two exchanges of a pass stays inside a wavefront: it needs no workgroup barrier, and run in two 32-bit phases
-//     (low words, then high words) it passes through the wavefront's own 4.3 KiB of the image;
-//   * the other exchange crosses the wavefronts in two 32-bit phases with TWO barriers instead of three: the high words are
-//     written into exactly the cells their writer has just read its low words from (nobody else reads those), so no barrier
-//     separates "low words read" from "high words parked".
-// Column pass (tile_body_wl_col): lanes numbered wavefront = j3, so exchange 1 (behind round 1) is the wave-local one and the
-//   last round's 16 lanes per column hold 16 CONSECUTIVE output rows -- whole 512-byte runs of the tiled scratch per store.
-// Row pass (tile_body_wl_row): lanes numbered as in ntt_tile.h (m = 8 j2 + j3 along the tile: whole 128-byte runs of the tiled
-//   scratch per load), exchange 1 crosses the wavefronts into wavefront = k1 pair, exchange 2 is wave-local through the cells
-//   the wavefront alone has read last (the d2 slab of its k1 pair); its stores are 32-byte row segments whatever the numbering.
+// With rows j = 128 j1 + 8 j2 + j3 (digits of the rounds 16, 16, 8) the 16 partners of an exchange always share a column and
+// one more digit; ntt_tile.h numbers a column's lanes m = 8 j2 + j3 for every round, so both exchanges cross the wavefronts
+// (write / barrier / read / barrier, twice).  Here
+//   column pass (tile_body_wl_col): wavefront = j3 for rounds 1-2, so the exchange behind round 1 stays inside a wavefront (no
+//     barrier: LDS operations of one wavefront execute in order) and is done in the wavefront's own region of the image; the
+//     exchange behind round 2 crosses the wavefronts IN PLACE (own region written, the other regions read); the last round's 16
+//     lanes per column hold 16 CONSECUTIVE output rows -- whole 512-byte runs of the tiled scratch per store instruction;
+//   row pass (tile_body_wl_row): lanes along the tile as in ntt_tile.h (m = 8 j2 + j3: whole 128-byte runs of the tiled scratch
+//     per load), the exchange behind round 1 crosses the wavefronts into wavefront = k1 pair, the exchange behind round 2 stays
+//     inside the wavefront (own region); stores are 32-byte row segments whatever the numbering.
+// A wavefront runs two thirds of its arithmetic between its loads and the one barrier (column pass) or between the one barrier and
+// its stores (row pass) without meeting anybody; the round-1 twiddles of the column pass come from a permuted copy of the round
+// table (plan.h wr_table) so that its 16 lanes per column read ONE 128-byte line per instruction, and the round-2 twiddles are
+// wave-uniform there (scalar loads).
 //
-// LDS image: 4-byte cells, 8 regions x 16 blocks x [16 x 4 columns + 4 pad]: cell = region * 1092 + block * 68 + slot * 4 + c.
-// 68 = 4 (mod 32) and 1092 = 4 (mod 32): in every ds_read_b32 / ds_write_b32 below the 32 lanes of a half-wavefront vary 8
-// values of ONE of (region, block) and the 4 columns -> 32 distinct banks; a varying slot never meets a varying block.
-// 34 944 bytes per workgroup.
+// FULL = true (the product): image of 8-byte cells, 69 888 bytes, two workgroups per CU.  Measured on MI355X (round 6,
+// profiles/r06_wl_ab.txt): two-lane 2^22 regime 22.4 k -> 23.6 k NTT/s on one box (+5 %), one stream 58.5 -> 55.5 us.
+// FULL = false: image of 4-byte cells (34 944 bytes), every exchange in two 32-bit phases -- low words, then high words; the
+// cross-wave exchange with TWO barriers instead of three: the high words are written into exactly the cells their writer has
+// just read its low words from, so nothing separates "low words read" from "high words parked".  Three to four workgroups per
+// CU -- and SLOWER: 2 / 3 / 4 resident workgroups per CU run the two-lane regime at 23.3 k / 22.0 k / 20.9 k NTT/s (same box,
+// same bodies, occupancy bounded by an LDS pad).  More wavefronts in flight cost more on the memory side (in-flight tiles
+// outgrow the 4 MiB L2 of an XCD) than they return on the VALU, which is ~88 % busy over a wavefront's life already
+// (profiles/r06_pmc_base_vs_wl.txt).  Kept as an opt-in for experiments (RONK_WL_HALF=1).
 //
-// Same TileArgs contract and the same results as ntt_tile.h, bit for bit (the arithmetic per coefficient is unchanged):
-// KIND 1 / 3 (column pass, two-level tables / full matrix) and KIND 2 (row pass), full tiles, no features.  Plain C++ over
-// (tid, bid, lds, barrier, wave_sync), so tests/emu runs the very same code on host fibers.
+// LDS image: 8 regions x 16 blocks x [16 slots x 4 columns + 4 pad cells]: cell = region * 1092 + block * 68 + slot * 4 + c.
+// 68 = 4 and 1092 = 4 (mod 32): in every LDS instruction the 32 lanes of a half-wavefront vary 8 values of ONE of (region,
+// block, slot) and the 4 columns -> 32 distinct banks (4-byte cells) / bank pairs (8-byte cells): 0 bank conflicts measured.
+//
+// Same TileArgs contract and the same results as ntt_tile.h, bit for bit (the arithmetic per coefficient is unchanged): KIND 1 /
+// 3 (column pass, two-level tables / full matrix) and KIND 2 (row pass), full tiles, no features; Goldilocks and Montgomery
+// primes (field_policy.h).  Plain C++ over (tid, bid, lds, barrier, wave_sync), so tests/emu runs the same code on host fibers.
 // Reference semantics: Polynomial::fft / ifft, src/polynomial/mod.rs:273-323, :430-484 (omega = g^((p-1)/n), natural order).
 #pragma once
 #include "ntt_tile.h"
@@ -33,61 +41,60 @@ namespace ronk {
 
 constexpr int WL_LOGR = 11, WL_LOGC = 2;
 constexpr u32 WL_BLOCK = 68, WL_REGION = 16 * WL_BLOCK + 4;   // cells; 1092
-constexpr size_t WL_LDS_BYTES = (size_t)8 * WL_REGION * 4;
 constexpr u32 WL_THREADS = 512;
+constexpr size_t wl_lds_bytes(bool full) { return (size_t)8 * WL_REGION * (full ? 8 : 4); }
 
+// the full twiddle matrix may be laid out transposed, [col][k] (plan.h twf_transposed): tf_sc = R, tf_sk = 1
+inline bool tile_wl_twf_transposed(const TileArgs& a) { return a.tw_full && a.tf_sk == 1 && a.tf_sc == (1u << WL_LOGR); }
 inline bool tile_wl_matches(const TileArgs& a, int logr, int kind) {
-  return !a.fc.p && logr == WL_LOGR && (kind == 1 || kind == 2 || kind == 3) && tile_cfg_matches(a, WL_LOGR, WL_LOGC, kind, 0);
+  if (logr != WL_LOGR || !(kind == 1 || kind == 2 || kind == 3)) return false;
+  if (kind == 3 && tile_wl_twf_transposed(a)) {
+    TileArgs b = a;
+    b.tf_sc = 1; b.tf_sk = (u32)a.ncols;   // what tile_cfg_matches knows as the matrix of a column pass
+    return a.logc == (u32)WL_LOGC && a.tf_sb2 == 0 && tile_cfg_matches(b, WL_LOGR, WL_LOGC, 3, 0);
+  }
+  return tile_cfg_matches(a, WL_LOGR, WL_LOGC, kind, 0);
 }
 
-// MF: memory-policy flags of an instantiation (experiments; 0 in the product until measured): 1 = the full twiddle matrix is read
-// with non-temporal loads (every entry is used once per transform, by one lane), 2 = non-temporal stores, 4 = non-temporal
-// loads of the tile itself (row pass: every scratch line is read by exactly one tile).
-constexpr int WL_NT_TWF = 1, WL_NT_ST = 2, WL_NT_LD = 4;
-template <bool NT>
-RONK_HD u64 ld_gb(const u64* base, u32 byte_off) {
-  const u64* q = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(base) + byte_off);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (NT) return __builtin_nontemporal_load(q);
-#endif
-  return *q;
-}
-template <bool NT>
-RONK_HD void st_gb(u64* base, u32 byte_off, u64 v) {
-  u64* q = reinterpret_cast<u64*>(reinterpret_cast<char*>(base) + byte_off);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (NT) { __builtin_nontemporal_store(v, q); return; }
-#endif
-  st_out(q, v);
-}
+// One LDS cell of the image: 8-byte cells (FULL) or the low / high word of a coefficient in a 4-byte cell
+struct WlImage {
+  u32* l32;
+  RONK_HD void put(u32 cell, u64 v) const { reinterpret_cast<u64*>(l32)[cell] = v; }
+  RONK_HD u64 get(u32 cell) const { return reinterpret_cast<u64*>(l32)[cell]; }
+  RONK_HD void put_lo(u32 cell, u64 v) const { l32[cell] = (u32)v; }
+  RONK_HD void put_hi(u32 cell, u64 v) const { l32[cell] = (u32)(v >> 32); }
+  RONK_HD u32 get32(u32 cell) const { return l32[cell]; }
+};
 
 // wave_sync(): orders a wavefront's LDS accesses against its own later ones.  On the device LDS operations of one wavefront
 // execute in order, so it is a compiler fence only; the host emulator (one fiber per lane) passes its barrier.
 
 // ---- column pass: wavefront = j3 ----------------------------------------------------------------------------------
-template <bool INV, int KIND, int MF = 0, class Barrier, class WaveSync>
+template <bool INV, int KIND, bool FULL, class FLD = GlField, class Barrier, class WaveSync>
 RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, Barrier&& barrier, WaveSync&& wave_sync) {
   static_assert(KIND == 1 || KIND == 3, "column pass");
   constexpr int LOGR = WL_LOGR;
   typedef TileCfg<WL_LOGC, KIND> CFG;
+  const WlImage img{l32};
   const u32 c = tid & 3, l = (tid >> 2) & 15, w = wave_uniform(tid >> 6);   // column, lane digit, wavefront (a scalar)
   // rounds 1-2: j3 = w, j2 (then k1) = l.  ntt_tile.h's lane index of the same coefficients: m = 8 j2 + j3
   const u32 m_old = l * 8 + w;
   const TileCtx cx = tile_ctx<LOGR, CFG>(a_in, m_old * 4 + c, bid);
   const TileArgs& a = cx.a;
+  const FLD f(a.fc);
   u64 x[16];
-  {   // x[j1] = row 128 j1 + 8 j2 + j3 (flat rows: what tile_load does for KIND 1 / 3, with the load policy of MF)
+  {   // x[j1] = row 128 j1 + 8 j2 + j3 (flat rows, as tile_load for KIND 1 / 3)
     const u32 j0 = cx.in_lane + m_old * cx.in_sj, step = 128 * cx.in_sj;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = ld_gb<(MF & WL_NT_LD) != 0>(cx.in, j0 + i * step);
+    for (int i = 0; i < 16; i++) x[i] = ld_g<true>(cx.in, j0 + i * step);
   }
 
-  // ---- round 1 (over j1), table twiddle omega_R^{m_old k1}; exchange 1 inside the wavefront's own region:
-  // park (block k1, slot j2), read back as lane k1 = l (block l, slot j2)
-  // The twiddles come from the PERMUTED copy of the round table behind the table itself (plan.h wr_table: entry
-  // R + (w * 16 + k1) * 16 + l = omega_R^{(8 l + w) k1}): the 16 lanes of a column read 16 consecutive entries -- one 128-byte
-  // line per instruction instead of 16 entries 64 k1 bytes apart -- at one per-lane base plus immediates.
-  Dif<16, INV, true>::run(x);
+  // ---- round 1 (over j1), table twiddle omega_R^{m_old k1}; exchange 1 inside the wavefront's own region: park (block k1, slot
+  // j2), read back as lane k1 = l (block l, slot j2).  The twiddles come from the PERMUTED copy of the round table behind the
+  // table itself (plan.h wr_table: entry R + (w * 16 + k1) * 16 + l = omega_R^{(8 l + w) k1}): the 16 lanes of a column read 16
+  // consecutive entries -- one 128-byte line per instruction instead of 16 entries 64 k1 bytes apart -- at one per-lane base
+  // plus immediates.
+  Dif<16, INV, true, FLD>::run(x, f);
   u32 tb[16];
   const u32 reg = w * WL_REGION;
   {
@@ -96,28 +103,34 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1) x[i] = gl64::mul(x[i], ld_tabb(a.wr, tperm + (k1 << 7)));
-      l32[wbase + k1 * WL_BLOCK] = (u32)x[i];
+      if (k1) x[i] = f.mul(x[i], ld_tabb(a.wr, tperm + (k1 << 7)));
+      if constexpr (FULL) img.put(wbase + k1 * WL_BLOCK, x[i]); else img.put_lo(wbase + k1 * WL_BLOCK, x[i]);
     }
     wave_sync();
-    u32 lo[16];
+    if constexpr (FULL) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) lo[j] = l32[rbase + j * 4];
-    wave_sync();
+      for (int j = 0; j < 16; j++) x[j] = img.get(rbase + j * 4);
+    } else {
+      u32 lo[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) l32[wbase + (u32)brev(i, 4) * WL_BLOCK] = (u32)(x[i] >> 32);
-    wave_sync();
+      for (int j = 0; j < 16; j++) lo[j] = img.get32(rbase + j * 4);
+      wave_sync();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = ((u64)l32[rbase + j * 4] << 32) | lo[j];
+      for (int i = 0; i < 16; i++) img.put_hi(wbase + (u32)brev(i, 4) * WL_BLOCK, x[i]);
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = ((u64)img.get32(rbase + j * 4) << 32) | lo[j];
+    }
     wave_sync();
   }
   // ---- round 2 (over j2): lane (k1 = l, j3 = w); twiddle omega_{R/16}^{j3 k2} = omega_R^{16 j3 k2} (the same for the whole
   // wavefront).  Exchange 2 crosses the wavefronts: wavefront p of round 3 owns k2 in {2p, 2p + 1}.
-  //   low words   parked in place (own region: block l, slot k2)          | barrier |  gathered from region j3, slot 2p + g
+  //   FULL        parked in place (own region: block l, slot k2)              | barrier |  gathered from region j3, slot 2p + g
+  //   low words   the same
   //   high words  parked in the cells just read: region k2 >> 1, block l, slot 2w + (k2 & 1)   | barrier |  read from the own
   //               region, slot 2 j3 + g  (the writer of a cell is the one lane that read it: no barrier in between)
   {
-    Dif<16, INV, true>::run(x);
+    Dif<16, INV, true, FLD>::run(x, f);
     tb[0] = 0; tb[1] = w << 7;
 #pragma unroll
     for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
@@ -125,27 +138,34 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k2 = brev(i, 4);
-      if (k2) x[i] = gl64::mul(x[i], ld_tabb(a.wr, tb[k2]));
-      l32[own + k2 * 4] = (u32)x[i];
+      if (k2) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k2]));
+      if constexpr (FULL) img.put(own + k2 * 4, x[i]); else img.put_lo(own + k2 * 4, x[i]);
     }
     barrier();
-    u32 lo[16];
     const u32 gat = l * WL_BLOCK + (2 * w) * 4 + c;
+    if constexpr (FULL) {
 #pragma unroll
-    for (int g = 0; g < 2; g++)
+      for (int g = 0; g < 2; g++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) lo[g * 8 + j] = l32[gat + j * WL_REGION + g * 4];
-    wave_sync();
+        for (int j = 0; j < 8; j++) x[g * 8 + j] = img.get(gat + j * WL_REGION + g * 4);
+    } else {
+      u32 lo[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 k2 = brev(i, 4);
-      l32[gat + (k2 >> 1) * WL_REGION + (k2 & 1) * 4] = (u32)(x[i] >> 32);
+      for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) lo[g * 8 + j] = img.get32(gat + j * WL_REGION + g * 4);
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const u32 k2 = brev(i, 4);
+        img.put_hi(gat + (k2 >> 1) * WL_REGION + (k2 & 1) * 4, x[i]);
+      }
+      barrier();
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[g * 8 + j] = ((u64)img.get32(own + (2 * j + g) * 4) << 32) | lo[g * 8 + j];
     }
-    barrier();
-#pragma unroll
-    for (int g = 0; g < 2; g++)
-#pragma unroll
-      for (int j = 0; j < 8; j++) x[g * 8 + j] = ((u64)l32[own + (2 * j + g) * 4] << 32) | lo[g * 8 + j];
   }
   // ---- round 3 (over j3): wavefront p = w owns k2 in {2p, 2p+1}, lane k1 = l; register g*8 + j3.  Natural output row of
   // register (g, i): k = l + 16 (2 w + g) + 256 brev3(i): the 16 lanes of a column hold 16 consecutive rows.
@@ -154,27 +174,28 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
   const u32 out_sk = cx.out_sk, out_lane = cx.out_lane;
   u64* __restrict__ const outp = cx.out;
   if constexpr (KIND == 3) {
-    const u32 tf_lane = (cx.col * a.tf_sc) << SH, tf_sk = a.tf_sk << SH;
+    // (the strides of the launch, not those tile_ctx folds in: the matrix may be transposed -- [col][k], plan.h twf_transposed --
+    // and then the 16 lanes of a column read 128 consecutive bytes)
+    const u32 tf_lane = (cx.col * a_in.tf_sc) << SH, tf_sk = a_in.tf_sk << SH;
     // The matrix entries travel in chunks of four, two chunks in flight: chunk q + 2 is fetched before the stores of chunk q are
-    // issued (one in-order vmcnt for loads and stores: a load behind a store waits for the store's whole trip), and the
-    // tail needs 16 instead of 32 registers of twiddles beside the 32 of coefficients (the kernel is built for <= 64).
+    // issued (one in-order vmcnt for loads and stores: a load behind a store waits for the store's whole trip).
     // chunk q = (g, h): registers g*8 + 4h .. + 3
     u64 wq[2][4];
     auto fetch = [&](int q, u64* wv) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) wv[i] = ld_gb<(MF & WL_NT_TWF) != 0>(a.tw_full, tf_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * tf_sk);
+      for (int i = 0; i < 4; i++) wv[i] = ld_g<true>(a.tw_full, tf_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * tf_sk);
     };
     fetch(0, wq[0]);
     fetch(1, wq[1]);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       u64* xq = x + 4 * q;
-      if ((q & 1) == 0) Dif<8, INV, true>::run(xq, false);
+      if ((q & 1) == 0) Dif<8, INV, true, FLD>::run(xq, f, false);
 #pragma unroll
-      for (int i = 0; i < 4; i++) xq[i] = gl64::mul(xq[i], wq[q & 1][i]);
+      for (int i = 0; i < 4; i++) xq[i] = f.mul(xq[i], wq[q & 1][i]);
       if (q + 2 < 4) fetch(q + 2, wq[q & 1]);
 #pragma unroll
-      for (int i = 0; i < 4; i++) st_gb<(MF & WL_NT_ST) != 0>(outp, out_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * out_sk, xq[i]);
+      for (int i = 0; i < 4; i++) st_g<true>(outp, out_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * out_sk, xq[i]);
     }
   } else {
     // two-level inter-pass twiddle omega_N^{col * k}: exponents pre-scaled by 8 (byte offsets), add chain over i
@@ -184,7 +205,7 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
     for (int g = 0; g < 2; g++) {
       u64* xg = x + g * 8;
-      Dif<8, INV, true>::run(xg, false);
+      Dif<8, INV, true, FLD>::run(xg, f, false);
       u32 ej[8];
       ej[0] = (twX * (kbase + 16 * g)) << 3;
       const u32 estep = (twX * 256u) << 3;
@@ -193,39 +214,42 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const u32 ee = ej[brev(i, 3)];
-        const u64 tw = gl64::mul(ld_tabb(a.tw_lo, ee & lmask8), ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8));
-        xg[i] = gl64::mul(xg[i], tw);
+        const u64 tw = f.mul(ld_tabb(a.tw_lo, ee & lmask8), ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8));
+        xg[i] = f.mul(xg[i], tw);
       }
 #pragma unroll
-      for (int i = 0; i < 8; i++) st_gb<(MF & WL_NT_ST) != 0>(outp, out_lane + (kbase + 16 * g + 256 * brev(i, 3)) * out_sk, xg[i]);
+      for (int i = 0; i < 8; i++) st_g<true>(outp, out_lane + (kbase + 16 * g + 256 * brev(i, 3)) * out_sk, xg[i]);
     }
   }
 }
 
 // ---- row pass: lanes along the tile as in ntt_tile.h, wavefront = k1 pair from round 2 on -----------------------------
-template <bool INV, int MF = 0, class Barrier, class WaveSync>
+template <bool INV, bool FULL, class FLD = GlField, class Barrier, class WaveSync>
 RONK_HD void tile_body_wl_row(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, Barrier&& barrier, WaveSync&& wave_sync) {
   constexpr int LOGR = WL_LOGR;
   typedef TileCfg<WL_LOGC, 2> CFG;
+  const WlImage img{l32};
   const u32 c = tid & 3, l = (tid >> 2) & 15, w = wave_uniform(tid >> 6);
   const u32 m = tid >> 2;                 // 16 w + l = 8 j2 + j3
   const u32 e = l >> 3, j3 = l & 7;       // j2 = 2 w + e
   const TileCtx cx = tile_ctx<LOGR, CFG>(a_in, tid, bid);
   const TileArgs& a = cx.a;
+  const FLD f(a.fc);
   u64 x[16];
-  {   // x[j1] = row 128 j1 + m of the tiled scratch (blocked rows: what tile_load does for KIND 2, with the load policy of MF)
+  {   // x[j1] = row 128 j1 + m of the tiled scratch (blocked rows, as tile_load for KIND 2)
     const u32 hi = (u32)a.in_sj_hi << 3, jmask = (1u << a.js_log) - 1;
     const u32 j0 = cx.in_lane + (m >> a.js_log) * hi + (m & jmask) * cx.in_sj, step = (128u >> a.js_log) * hi;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = ld_gb<(MF & WL_NT_LD) != 0>(cx.in, j0 + i * step);
+    for (int i = 0; i < 16; i++) x[i] = ld_g<true>(cx.in, j0 + i * step);
   }
 
   // ---- round 1 (over j1), twiddle omega_R^{m k1}.  Exchange 1 crosses the wavefronts: k1 = 2 q + s goes to wavefront q,
   // lane (s, j3), register j2.
-  //   low words   scattered to region q, block 8 s + j3, slot j2 = 2 w + e   | barrier |  read from the own region, block l
+  //   FULL        scattered to region q, block 8 s + j3, slot j2 = 2 w + e   | barrier |  read from the own region, block l
+  //   low words   the same
   //   high words  parked in the cells just read (own region, block l, slot k1)   | barrier |  gathered from region j2 >> 1,
   //               block 8 (j2 & 1) + j3, slot 2 w + e
-  Dif<16, INV, true>::run(x);
+  Dif<16, INV, true, FLD>::run(x, f);
   u32 tb[16];
   tb[0] = 0; tb[1] = m << 3;
 #pragma unroll
@@ -236,51 +260,74 @@ RONK_HD void tile_body_wl_row(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
-      if (k1) x[i] = gl64::mul(x[i], ld_tabb(a.wr, tb[k1]));
-      l32[far + (k1 >> 1) * WL_REGION + (k1 & 1) * (8 * WL_BLOCK)] = (u32)x[i];
+      if (k1) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k1]));
+      const u32 cell = far + (k1 >> 1) * WL_REGION + (k1 & 1) * (8 * WL_BLOCK);
+      if constexpr (FULL) img.put(cell, x[i]); else img.put_lo(cell, x[i]);
     }
     barrier();
-    u32 lo[16];
+    if constexpr (FULL) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) lo[j] = l32[own + j * 4];
-    wave_sync();
+      for (int j = 0; j < 16; j++) x[j] = img.get(own + j * 4);
+    } else {
+      u32 lo[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) l32[own + (u32)brev(i, 4) * 4] = (u32)(x[i] >> 32);
-    barrier();
+      for (int j = 0; j < 16; j++) lo[j] = img.get32(own + j * 4);
+      wave_sync();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = ((u64)l32[far + (j >> 1) * WL_REGION + (j & 1) * (8 * WL_BLOCK)] << 32) | lo[j];
+      for (int i = 0; i < 16; i++) img.put_hi(own + (u32)brev(i, 4) * 4, x[i]);
+      barrier();
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = ((u64)img.get32(far + (j >> 1) * WL_REGION + (j & 1) * (8 * WL_BLOCK)) << 32) | lo[j];
+    }
     wave_sync();
   }
-  // ---- round 2 (over j2): lane (k1 = 2 w + e, j3); twiddle omega_R^{16 j3 k2}.  Exchange 2 stays inside the wavefront, through
-  // the cells it alone has just read (slots 2 w, 2 w + 1 of every block of every region): element (s = e, j3, k2) at region
-  // j3, block k2, slot 2 w + s; lane (s, u) of round 3 reads k2 = 8 g + u, i.e. region j3', block 8 g + u.
+  // ---- round 2 (over j2): lane (k1 = 2 w + e, j3); twiddle omega_R^{16 j3 k2}.  Exchange 2 stays inside the wavefront.
+  //   FULL   after exchange 1 the wavefront's own region is read by nobody else: element (s = e, j3, k2 = 8 g + u) goes to block
+  //          8 s + u, slot 8 g + j3, and lane (s, u) of round 3 reads its block: slot 8 g + j3'
+  //   halves through the cells the wavefront alone has just read (slots 2 w, 2 w + 1 of every block of every region): element
+  //          (s = e, j3, k2) at region j3, block k2, slot 2 w + s; lane (s, u) reads k2 = 8 g + u, i.e. region j3', block 8 g + u
   {
-    Dif<16, INV, true>::run(x);
+    Dif<16, INV, true, FLD>::run(x, f);
     tb[1] = j3 << 7;
 #pragma unroll
     for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
-    const u32 wbase = j3 * WL_REGION + (2 * w + e) * 4 + c;          // + k2 * WL_BLOCK
-    const u32 rbase = j3 * WL_BLOCK + (2 * w + e) * 4 + c;           // u = j3 of the lane: + j3' * WL_REGION + g * 8 * WL_BLOCK
+    if constexpr (FULL) {
+      const u32 wb = w * WL_REGION + e * (8 * WL_BLOCK) + j3 * 4 + c;   // + u * WL_BLOCK + g * 32, k2 = 8 g + u
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 k2 = brev(i, 4);
-      if (k2) x[i] = gl64::mul(x[i], ld_tabb(a.wr, tb[k2]));
-      l32[wbase + k2 * WL_BLOCK] = (u32)x[i];
+      for (int i = 0; i < 16; i++) {
+        const u32 k2 = brev(i, 4);
+        if (k2) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k2]));
+        img.put(wb + (k2 & 7) * WL_BLOCK + (k2 >> 3) * 32, x[i]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[g * 8 + j] = img.get(own + (8 * g + j) * 4);
+    } else {
+      const u32 wbase = j3 * WL_REGION + (2 * w + e) * 4 + c;          // + k2 * WL_BLOCK
+      const u32 rbase = j3 * WL_BLOCK + (2 * w + e) * 4 + c;           // u = j3 of the lane: + j3' * WL_REGION + g * 8 * WL_BLOCK
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const u32 k2 = brev(i, 4);
+        if (k2) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k2]));
+        img.put_lo(wbase + k2 * WL_BLOCK, x[i]);
+      }
+      wave_sync();
+      u32 lo[16];
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) lo[g * 8 + j] = img.get32(rbase + j * WL_REGION + g * (8 * WL_BLOCK));
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 16; i++) img.put_hi(wbase + (u32)brev(i, 4) * WL_BLOCK, x[i]);
+      wave_sync();
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[g * 8 + j] = ((u64)img.get32(rbase + j * WL_REGION + g * (8 * WL_BLOCK)) << 32) | lo[g * 8 + j];
     }
-    wave_sync();
-    u32 lo[16];
-#pragma unroll
-    for (int g = 0; g < 2; g++)
-#pragma unroll
-      for (int j = 0; j < 8; j++) lo[g * 8 + j] = l32[rbase + j * WL_REGION + g * (8 * WL_BLOCK)];
-    wave_sync();
-#pragma unroll
-    for (int i = 0; i < 16; i++) l32[wbase + (u32)brev(i, 4) * WL_BLOCK] = (u32)(x[i] >> 32);
-    wave_sync();
-#pragma unroll
-    for (int g = 0; g < 2; g++)
-#pragma unroll
-      for (int j = 0; j < 8; j++) x[g * 8 + j] = ((u64)l32[rbase + j * WL_REGION + g * (8 * WL_BLOCK)] << 32) | lo[g * 8 + j];
   }
   // ---- round 3 (over j3): lane (s = e, u = l & 7); register g*8 + j3 = element (k1 = 2 w + e, k2 = 8 g + u, j3);
   // natural output row k = k1 + 16 k2 + 256 brev3(i)
@@ -290,9 +337,9 @@ RONK_HD void tile_body_wl_row(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     u64* xg = x + g * 8;
-    Dif<8, INV, false>::run(xg, false);
+    Dif<8, INV, false, FLD>::run(xg, f, false);
 #pragma unroll
-    for (int i = 0; i < 8; i++) st_gb<(MF & WL_NT_ST) != 0>(outp, out_lane + (kbase + 128 * g + 256 * brev(i, 3)) * out_sk, xg[i]);
+    for (int i = 0; i < 8; i++) st_g<true>(outp, out_lane + (kbase + 128 * g + 256 * brev(i, 3)) * out_sk, xg[i]);
   }
 }
 

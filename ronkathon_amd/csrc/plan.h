@@ -200,6 +200,11 @@ struct PlanBuilder {
     p.small = true;
   }
   int twf_max_log = 0;  // build the full twiddle matrix of a pass when it has at most 2^twf_max_log entries
+  // Lay the matrix of a 2^11-row x 4-column column pass out TRANSPOSED, [col][k] instead of [k][col] (round 6): the lanes of
+  // ntt_tile_wl.h's last round hold 16 consecutive k per column, so a load instruction reads four whole 128-byte lines instead
+  // of sixteen 32-byte pieces of lines that four neighbouring tiles share.  Only ntt_tile_wl.h reads this layout at full speed
+  // (tile_wl_matches); everything else falls back to the generic body, so the planner asks for it only where those kernels run.
+  bool twf_transposed = false;
   // TileArgs::scale in table form; 1 stays the "no scale" sentinel.  (Montgomery: should s * 2^64 mod p come out as 1 for a real
   // scale s != 1, the representative p + 1 is used -- the product accepts it, p <= 2^64 - 59, and it is not the sentinel.)
   u64 tab_scale(u64 s) const {
@@ -221,8 +226,9 @@ struct PlanBuilder {
     const u64 nc = dep_c ? a.ncols : 1, nb2 = dep_b2 ? a.nb2 : 1;
     const u64 entries = R * nc * nb2;
     if (twf_max_log <= 0 || entries > ((u64)1 << twf_max_log)) return;
-    // dense layout [k][b2][col] restricted to the dependent indices
-    const u32 sc = dep_c ? 1 : 0, sb2 = dep_b2 ? (u32)nc : 0, sk = (u32)(nc * nb2);
+    // dense layout [k][b2][col] restricted to the dependent indices -- or [col][k] (twf_transposed, above)
+    const bool tr = twf_transposed && p.logr == 11 && a.logc == 2 && dep_c && !dep_b2 && !p.small;
+    const u32 sc = tr ? (u32)R : dep_c ? 1 : 0, sb2 = dep_b2 ? (u32)nc : 0, sk = tr ? 1 : (u32)(nc * nb2);
     const TwTable& t = d.tw[p.tw_id];
     const u64 nmask = a.tw_log >= 64 ? ~(u64)0 : (((u64)1 << a.tw_log) - 1), lmask = ((u64)1 << t.lo_bits) - 1;
     std::vector<u64> T(entries);
@@ -253,10 +259,11 @@ struct PlanBuilder {
 // other split of an odd log2n so that its inverse's column pass has the rows of the forward row pass, ntt_mul.h).
 inline PlanDesc build_plan(int log2n, u64 batch, bool inverse, int max_logc = 4, int twf_max_log = 0,
                            int three_pass_from = 25, bool auto_tiles = false, int split_ka = 0,
-                           const HostField& hf = HostField()) {
+                           const HostField& hf = HostField(), bool twf_transposed = false) {
   PlanBuilder b;
   b.hf = hf;
   b.twf_max_log = twf_max_log;
+  b.twf_transposed = twf_transposed;
   if (const char* e = getenv("RONK_WG_FLOOR_LOG")) { int v = atoi(e); if (v >= 10 && v <= 14) b.multi_pass_floor_log = v; }
   b.d.log2n = log2n; b.d.batch = batch; b.d.inverse = inverse;
   const u64 n = (u64)1 << log2n;

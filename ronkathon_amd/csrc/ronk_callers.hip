@@ -82,7 +82,11 @@ struct WsLease {
       ws_reap(false);
       return;
     }
-    slot->ev_valid = g_ws_multi && hipEventRecord(slot->done, s) == hipSuccess;
+    // (a capturing stream leaves no event: one recorded inside a capture never completes for the pool's queries; the slot stays
+    //  tied to the stream it was last used on -- the captured graph's stream -- and other streams wait for the device instead)
+    hipStreamCaptureStatus capr = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capr) != hipSuccess) { (void)hipGetLastError(); capr = hipStreamCaptureStatusNone; }
+    slot->ev_valid = capr == hipStreamCaptureStatusNone && g_ws_multi && hipEventRecord(slot->done, s) == hipSuccess;
     slot->last = s; slot->used = true; slot->busy = false;
   }
   int acquire(size_t bytes, hipStream_t st) {
@@ -121,6 +125,16 @@ struct WsLease {
       slot = waitable;
     }
     if (!slot) {
+      // A capturing stream may not be handed a FRESH slot: creating one needs hipMalloc and the look-back fills, which either
+      // invalidate a global-mode capture (legacy null-stream calls) or would become nodes of the caller's graph.  The caller
+      // warms the pool with one call of the same shape outside the capture (include/ronk_ntt.h); until then the captured call
+      // is refused, never half-initialised.
+      hipStreamCaptureStatus capn = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &capn) != hipSuccess) { (void)hipGetLastError(); capn = hipStreamCaptureStatusNone; }
+      if (capn != hipStreamCaptureStatusNone) {
+        (void)hip_fail(hipErrorStreamCaptureUnsupported, "workspace: no warm pool slot for a capturing stream (call once outside the capture first)");
+        return RONK_ERR_UNSUPPORTED;
+      }
       WsSlot* w = new WsSlot();
       w->oneoff = oneoff;
       hipError_t e = hipMalloc(&w->p, need);
@@ -136,11 +150,8 @@ struct WsLease {
       // were filled -- and take garbage for a published chunk sum (found by the four-thread fuzz sweep, round 5: one evaluate
       // in ~5 000 threaded cases, always on a caller-created stream and a fresh slot).  A later user on another stream gets
       // the slot only behind its completion event (or the device drain of the first cross-stream use), i.e. behind the fills.
-      // (While `st` is capturing, the legacy fills stay: they must not become nodes of the caller's graph; the one-launch
-      // scans, the only readers of the look-back arrays, are not used under capture.)
-      hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap0) != hipSuccess) { (void)hipGetLastError(); cap0 = hipStreamCaptureStatusNone; }
-      const bool on_st = cap0 == hipStreamCaptureStatusNone;
+      // (A capturing stream never gets here: refused above.)
+      const bool on_st = true;
       if (e == hipSuccess) e = hipMalloc((void**)&w->ctl, 64);
       if (e == hipSuccess) e = on_st ? hipMemsetAsync(w->ctl, 0, 64, st) : hipMemset(w->ctl, 0, 64);
       if (e == hipSuccess) e = hipMalloc((void**)&w->lb, (size_t)2 * LB_WORDS * 8);
@@ -478,7 +489,7 @@ extern "C" int ronk_lagrange_eval(uint64_t p, const uint64_t* c, const uint64_t*
   return RONK_OK;
 }
 
-// ------------------------------------------------------------------------------ fast general division (Goldilocks)
+// ------------------------------------------------------------------------------ fast general division (any NTT-friendly prime)
 // quotient_and_remainder (polynomial/mod.rs:170-225) in O(n log n) on the NTT path, for divisors that are not linear:
 //   Q = rev( rev(a) * inv(rev(b)) mod x^L ),  L = deg a - deg b + 1,   inv by Newton iteration g <- g + g*(1 - f*g),
 // every product through ronk_poly_mul_dev (cached plans).  Used only when the divisor's last coefficient is non-zero
@@ -490,11 +501,25 @@ __global__ void __launch_bounds__(256) dv_reverse_kernel(const u64* __restrict__
   // out[i] = in[top - i] for i < len (coefficients above the source read as ZERO: top - i < 0 never happens, len <= top + 1)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = in[top - i];
 }
-__global__ void __launch_bounds__(256) dv_neg_kernel(const u64* __restrict__ in, u64* __restrict__ out, size_t len) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = gl64::neg(in[i]);
+template <class Ops>
+__global__ void __launch_bounds__(256) dv_neg_kernel(Ops ops, const u64* __restrict__ in, u64* __restrict__ out, size_t len) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = ops.neg(in[i]);
 }
-__global__ void __launch_bounds__(256) dv_fill_kernel(u64* __restrict__ out, size_t len, u64 v0) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) out[i] = i == 0 ? v0 : 0;
+// out = [1 / lead, 0, 0, ...]: the precision-1 start of the Newton iteration, rhs.leading_coefficient().inverse().unwrap()
+// (mod.rs:181, :196), computed HERE so that the call needs nothing from the host.  `lead` / `top_a` point at b[m] / a[n]: when the
+// caller only PROMISED full-length operands (ronk_poly_divrem_full_dev), a zero there is reported through *status.
+template <class Ops>
+__global__ void __launch_bounds__(256) dv_fill_inv_kernel(Ops ops, u64* __restrict__ out, size_t len, const u64* __restrict__ lead,
+                                                          const u64* __restrict__ top_a, int* status) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+    if (i == 0) {
+      const u64 l = *lead;
+      if (status) *status = (l == 0 || *top_a == 0) ? RONK_ERR_INVALID : 0;
+      out[0] = l ? ops.pow(l, ops.order() - 2) : 0;
+    } else {
+      out[i] = 0;
+    }
+  }
 }
 // quot[i] = (i >= t && i < L) ? qrev[L - 1 - i] : 0   for i < d     (reverse back, clear below t)
 __global__ void __launch_bounds__(256) dv_quot_kernel(const u64* __restrict__ qrev, size_t L, size_t t, u64* __restrict__ quot, size_t d) {
@@ -502,15 +527,38 @@ __global__ void __launch_bounds__(256) dv_quot_kernel(const u64* __restrict__ qr
     quot[i] = (i >= t && i < L) ? qrev[L - 1 - i] : 0;
 }
 // rem[i] = a[i] - prod[i] (prod has plen entries)
-__global__ void __launch_bounds__(256) dv_rem_kernel(const u64* __restrict__ a, const u64* __restrict__ prod, size_t plen, u64* __restrict__ rem, size_t d) {
+template <class Ops>
+__global__ void __launch_bounds__(256) dv_rem_kernel(Ops ops, const u64* __restrict__ a, const u64* __restrict__ prod, size_t plen, u64* __restrict__ rem, size_t d) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < d; i += (size_t)gridDim.x * blockDim.x)
-    rem[i] = i < plen ? gl64::sub(a[i], prod[i]) : a[i];
+    rem[i] = i < plen ? ops.sub(a[i], prod[i]) : a[i];
+}
+
+// Which fields the O(n log n) form serves, and with which root: the products inside it run on the NTT path (ronk_poly_mul_dev),
+// whose result does not depend on WHICH primitive root the transform uses -- so for a prime other than Goldilocks any quadratic
+// non-residue z serves (omega_{2^k} = z^((p-1)/2^k) has order exactly 2^k), found here like FieldExt::sqrt finds one
+// (prime/mod.rs:197-201), and the caller needs no generator.  The prime must have the 2-adicity of the largest product
+// (2 * 2^ceil(log2 d) points).  Round 5 knew only Goldilocks here: every other field took the one-workgroup long division,
+// minutes at 2^22 by 2^21.
+static bool newton_field(const FieldCtx& f, size_t d, u64* g) {
+  if (d > ((size_t)1 << 27)) return false;
+  if (f.kind == F_GL) { *g = RONK_GOLDILOCKS_G; return true; }
+  if (f.kind != F_MONT || ronk_check_prime(f.p) != RONK_OK) return false;
+  int need = 1; while (((size_t)1 << need) < d) need++;
+  need += 1;
+  if (need > 30 || (f.p - 1) % ((u64)1 << need) != 0) return false;
+  u64 z = 2 % f.p;
+  for (int tries = 0; tries < 1000 && h_powmod(z, (f.p - 1) / 2, f.p) == 1; tries++) z = (z + 1) % f.p;
+  if (h_powmod(z, (f.p - 1) / 2, f.p) != f.p - 1) return false;
+  *g = z;
+  return true;
 }
 
 // a: d coefficients with degree n (a[n] != 0), b: degree m (b[m] != 0), n >= m.  d_quot / d_rem: d coefficients each.
-static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b, size_t d2, size_t m, u64 lead_inv, u64* d_quot,
-                             u64* d_rem, hipStream_t s) {
-  const u64 P = RONK_GOLDILOCKS_P, G = RONK_GOLDILOCKS_G;
+// full_status: the device word that receives RONK_ERR_INVALID when a[n] or b[m] turns out to be ZERO (nullptr: the caller has
+// looked at the operands itself)
+static int newton_divrem_dev(const FieldCtx& fld, u64 G, const u64* d_a, size_t d, size_t n, const u64* d_b, size_t d2, size_t m,
+                             int* full_status, u64* d_quot, u64* d_rem, hipStream_t s) {
+  const u64 P = fld.p;
   const size_t L = n - m + 1;                       // coefficients of the true quotient
   size_t Lp = 1; while (Lp < L) Lp <<= 1;           // Newton runs to a power-of-two precision
   // temporaries from the event-guarded workspace pool (one lease, carved up): nothing is allocated, freed or waited for
@@ -528,11 +576,12 @@ static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b,
   const size_t flen = (m + 1 < Lp) ? m + 1 : Lp;
   hipLaunchKernelGGL(dv_reverse_kernel, dim3(grid_for(flen)), dim3(256), 0, s, d_b, m, f.u(), flen);
   // g = 1 / f[0] = 1 / lead(b)   (precision 1)
-  hipLaunchKernelGGL(dv_fill_kernel, dim3(grid_for(2 * Lp)), dim3(256), 0, s, g.u(), 2 * Lp, lead_inv);
+  FIELD_DISPATCH(fld, { hipLaunchKernelGGL((dv_fill_inv_kernel<decltype(ops)>), dim3(grid_for(2 * Lp)), dim3(256), 0, s, ops, g.u(), 2 * Lp,
+                                          d_b + m, d_a + n, full_status); });
   for (size_t k = 1; k < Lp; k <<= 1) {
     // e = f[0:2k] * g[0:k]: coefficients [k, 2k) are the error term (the low k are [1, 0, ..])
     RCHK(ronk_poly_mul_dev(P, G, f.u(), 2 * k, g.u(), k, e.u(), s));
-    hipLaunchKernelGGL(dv_neg_kernel, dim3(grid_for(k)), dim3(256), 0, s, e.u() + k, h.u(), k);
+    FIELD_DISPATCH(fld, { hipLaunchKernelGGL((dv_neg_kernel<decltype(ops)>), dim3(grid_for(k)), dim3(256), 0, s, ops, e.u() + k, h.u(), k); });
     // g[k:2k] = (g[0:k] * h)[0:k]
     RCHK(ronk_poly_mul_dev(P, G, g.u(), k, h.u(), k, t1.u(), s));
     HIPCHK(hipMemcpyAsync(g.u() + k, t1.p, k * 8, hipMemcpyDeviceToDevice, s));
@@ -545,7 +594,7 @@ static int newton_divrem_dev(const u64* d_a, size_t d, size_t n, const u64* d_b,
   hipLaunchKernelGGL(dv_quot_kernel, dim3(grid_for(d)), dim3(256), 0, s, qr.u(), L, t, d_quot, d);
   // rem = a - quot[0:L] * b[0:m+1]
   RCHK(ronk_poly_mul_dev(P, G, d_quot, L, d_b, m + 1, prod.u(), s));
-  hipLaunchKernelGGL(dv_rem_kernel, dim3(grid_for(d)), dim3(256), 0, s, d_a, prod.u(), L + m, d_rem, d);
+  FIELD_DISPATCH(fld, { hipLaunchKernelGGL((dv_rem_kernel<decltype(ops)>), dim3(grid_for(d)), dim3(256), 0, s, ops, d_a, prod.u(), L + m, d_rem, d); });
   HIPCHK(hipGetLastError());
   return RONK_OK;                                   // the lease's destructor leaves an event behind the last kernel
 }
@@ -580,9 +629,15 @@ extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, c
   FieldCtx f;
   RCHK(make_field(p, &f));
   hipStream_t s = (hipStream_t)stream;
-  if (f.kind == F_GL && d >= d2 && d2 >= 64 && d - d2 + 1 >= 2048 && d <= ((size_t)1 << 27)) {
+  u64 gz = 0;
+  if (d >= d2 && d2 >= 64 && d - d2 + 1 >= 2048 && newton_field(f, d, &gz)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    // A capturing stream cannot be synchronised for the degree probe.  Where the one-workgroup long division is still a
+    // matter of milliseconds it is captured instead; beyond that (d2 * (d - d2 + 1) field operations on ONE workgroup: seconds to
+    // minutes) the call is refused rather than silently captured as a kernel nobody can afford -- ronk_poly_divrem_full_dev is
+    // the capturable O(n log n) form.
+    if (cap != hipStreamCaptureStatusNone && (double)d2 * (double)(d - d2 + 1) > 1.0e9) return RONK_ERR_UNSUPPORTED;
     if (cap == hipStreamCaptureStatusNone) {
       unsigned long long probe[3] = {0, 0, 0};
       {
@@ -600,9 +655,8 @@ extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, c
       // the same window as the host-pointer form: a full-length divisor (a ragged one is the reference's panic, reported by
       // the long-division kernel), a quotient long enough for the O(n log n) form to win
       if (n > 0 && m == d2 && n >= m && (n - m + 1) >= 2048 && m >= 64) {
-        const u64 lead_inv = h_powmod((u64)probe[2] % p, p - 2, p);   // rhs.leading_coefficient().inverse().unwrap(), mod.rs:181,196
         HIPCHK(hipMemsetAsync(d_status, 0, 4, s));
-        return newton_divrem_dev(d_a, d, n - 1, d_b, d2, m - 1, lead_inv, d_quot, d_rem, s);
+        return newton_divrem_dev(f, gz, d_a, d, n - 1, d_b, d2, m - 1, nullptr, d_quot, d_rem, s);
       }
     }
   }
@@ -611,6 +665,23 @@ extern "C" int ronk_poly_divrem_dev(uint64_t p, const uint64_t* d_a, size_t d, c
                                         d_quot, d_status); });   // (copies the dividend and clears the status itself)
   HIPCHK(hipGetLastError());
   return RONK_OK;
+}
+
+// quotient_and_remainder for FULL-LENGTH operands (a[d - 1] != 0, b[d2 - 1] != 0 -- the common case: the caller knows its degrees),
+// d >= d2: the O(n log n) form with NOTHING read back -- the leading coefficient is inverted on the device, the promise is
+// checked there (*d_status = RONK_ERR_INVALID when a top coefficient is ZERO; the outputs are then meaningless) -- so the call
+// is asynchronous on `stream` and can be captured in a hipGraph whatever the sizes.  Fields: Goldilocks, and every odd prime
+// whose p - 1 has the 2-adicity of the product sizes (2^(ceil(log2 d) + 1) | p - 1); otherwise RONK_ERR_UNSUPPORTED (use
+// ronk_poly_divrem_dev).  For full-length operands the reference's loop is plain Euclidean division (mod.rs:170-225).
+extern "C" int ronk_poly_divrem_full_dev(uint64_t p, const uint64_t* d_a, size_t d, const uint64_t* d_b, size_t d2,
+                                         uint64_t* d_quot, uint64_t* d_rem, int* d_status, void* stream) {
+  if (!d_a || !d_b || !d_quot || !d_rem || !d_status || d == 0 || d2 == 0 || d < d2) return RONK_ERR_INVALID;
+  RCHK(need_device());
+  FieldCtx f;
+  RCHK(make_field(p, &f));
+  u64 gz = 0;
+  if (!newton_field(f, d, &gz)) return RONK_ERR_UNSUPPORTED;
+  return newton_divrem_dev(f, gz, d_a, d, d - 1, d_b, d2, d2 - 1, d_status, d_quot, d_rem, (hipStream_t)stream);
 }
 
 extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b, size_t d2, uint64_t* quot,
@@ -633,18 +704,18 @@ extern "C" int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const u
   // general divisor over Goldilocks, large enough for the O(n log n) form to win: Newton inversion on the NTT path.
   // Zero operands, short dividends and the reference's panics keep going through the long-division kernel below,
   // which follows the reference loop statement by statement.
-  if (f.kind == F_GL && d >= d2) {
+  u64 gz = 0;
+  if (d >= d2 && d2 >= 64 && d - d2 + 1 >= 2048 && newton_field(f, d, &gz)) {
     size_t n = d, m = d2;
     while (n > 0 && a[n - 1] % p == 0) n--;        // n = degree + 1 of the dividend (0: zero polynomial)
     while (m > 0 && b[m - 1] % p == 0) m--;
-    if (n > 0 && m == d2 && n >= m && (n - m + 1) >= 2048 && m >= 64 && d <= ((size_t)1 << 27)) {
+    if (n > 0 && m == d2 && n >= m && (n - m + 1) >= 2048 && m >= 64) {
       const size_t dn = n - 1, dm = m - 1;
       DevBuf da, db2, dq2, dr2;
       RCHK(da.alloc(d * 8)); RCHK(db2.alloc(d2 * 8)); RCHK(dq2.alloc(d * 8)); RCHK(dr2.alloc(d * 8));
       HIPCHK(hipMemcpy(da.p, a, d * 8, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(db2.p, b, d2 * 8, hipMemcpyHostToDevice));
-      const u64 lead_inv = h_powmod(b[dm] % p, p - 2, p);   // rhs.leading_coefficient().inverse().unwrap(), mod.rs:181,196
-      RCHK(newton_divrem_dev(da.u(), d, dn, db2.u(), d2, dm, lead_inv, dq2.u(), dr2.u(), 0));
+      RCHK(newton_divrem_dev(f, gz, da.u(), d, dn, db2.u(), d2, dm, nullptr, dq2.u(), dr2.u(), 0));
       HIPCHK(hipMemcpy(quot, dq2.p, d * 8, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(rem, dr2.p, d * 8, hipMemcpyDeviceToHost));
       return RONK_OK;

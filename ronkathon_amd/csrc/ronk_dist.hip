@@ -6,7 +6,29 @@
 //                      mesh of hipMemcpyPeerAsync copies over xGMI -- or as RCCL send/recv groups (librccl dlopen()ed) --
 //                      in column chunks so that chunk j is on the links while chunk j+1 is still being computed
 //                      (SURVEY.md 8e "overlap")
+#include <chrono>
+
 #include "runtime.h"
+
+// The field of a four-step plan: Goldilocks with the reference-convention generator 7 (the shift-twiddle kernels), or any odd
+// prime p < 2^64 with n | p - 1 whose g is a quadratic non-residue -- omega_n = g^((p-1)/n) then has order exactly n and the
+// phases run the same tile bodies over Montgomery arithmetic (field_policy.h MontField; plan.h HostField::montgomery), as
+// ronk_plan_create does for one GPU.  The reference's transform is generic over the modulus (src/algebra/field/prime/mod.rs:
+// 39-52, src/polynomial/mod.rs:273-323).  No radix-2 fallback here: a g that generates no full 2-power subgroup is
+// RONK_ERR_UNSUPPORTED.
+static int dist_field(u64 p, u64 g, uint32_t log2n, HostField* hf) {
+  if (p == RONK_GOLDILOCKS_P && g % p == RONK_GOLDILOCKS_G) {
+    if (log2n > 32) return RONK_ERR_NO_ROOT;   // 2-adicity of p - 1 is 32
+    *hf = HostField::goldilocks();
+    return RONK_OK;
+  }
+  if (p < 3) return RONK_ERR_INVALID;
+  RCHK(ronk_check_prime(p));
+  if (log2n > 63 || (p - 1) % ((u64)1 << log2n) != 0) return RONK_ERR_NO_ROOT;   // field/mod.rs:72
+  if (h_powmod(g % p, (p - 1) / 2, p) != p - 1) return RONK_ERR_UNSUPPORTED;
+  *hf = HostField::montgomery(p, g);
+  return RONK_OK;
+}
 
 // ------------------------------------------------------------------------------ multi-GPU four-step
 struct ronk_dist_plan {
@@ -23,16 +45,21 @@ extern "C" int ronk_dist_plan_destroy(ronk_dist_plan* pl) {
   delete pl;
   return RONK_OK;
 }
-extern "C" int ronk_dist_plan_create_chunked(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world,
-                                             int device, int chunks);
+extern "C" int ronk_dist_plan_create_p(ronk_dist_plan** out, uint64_t p, uint64_t g, uint32_t log2n, int inverse, int rank,
+                                       int world, int device, int chunks);
 extern "C" int ronk_dist_plan_create(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world, int device) {
-  return ronk_dist_plan_create_chunked(out, log2n, inverse, rank, world, device, 1);
+  return ronk_dist_plan_create_p(out, RONK_GOLDILOCKS_P, RONK_GOLDILOCKS_G, log2n, inverse, rank, world, device, 1);
 }
 extern "C" int ronk_dist_plan_create_chunked(ronk_dist_plan** out, uint32_t log2n, int inverse, int rank, int world,
                                              int device, int chunks) {
+  return ronk_dist_plan_create_p(out, RONK_GOLDILOCKS_P, RONK_GOLDILOCKS_G, log2n, inverse, rank, world, device, chunks);
+}
+extern "C" int ronk_dist_plan_create_p(ronk_dist_plan** out, uint64_t p, uint64_t g, uint32_t log2n, int inverse, int rank,
+                                       int world, int device, int chunks) {
   if (!out || world < 1 || rank < 0 || rank >= world) return RONK_ERR_INVALID;
   *out = nullptr;
-  if (log2n > 32) return RONK_ERR_NO_ROOT;  // 2-adicity of p - 1 is 32
+  HostField hf;
+  RCHK(dist_field(p, g, log2n, &hf));
   DistShape sh;
   if (!dist_shape((int)log2n, world, &sh)) return RONK_ERR_UNSUPPORTED;
   if (!dist_chunks_ok(sh, chunks)) return RONK_ERR_UNSUPPORTED;
@@ -41,8 +68,8 @@ extern "C" int ronk_dist_plan_create_chunked(ronk_dist_plan** out, uint32_t log2
   else HIPCHK(hipGetDevice(&device));
   ronk_dist_plan* pl = new ronk_dist_plan();
   pl->sh = sh; pl->device = device; pl->chunks = chunks;
-  int rc = pl->p1.compile(build_dist_phase1((int)log2n, inverse != 0, rank, world, 4, 0, 0, chunks));
-  if (!rc) rc = pl->p2.compile(build_dist_phase2((int)log2n, inverse != 0, rank, world, 4, 0, chunks));
+  int rc = pl->p1.compile(build_dist_phase1((int)log2n, inverse != 0, rank, world, 4, 0, 0, chunks, hf));
+  if (!rc) rc = pl->p2.compile(build_dist_phase2((int)log2n, inverse != 0, rank, world, 4, 0, chunks, hf));
   if (!rc) {
     hipError_t e = hipMalloc((void**)&pl->d_tmp, (sh.n / sh.W) * 8);
     if (e == hipSuccess) e = hipStreamSynchronize(0);   // table uploads (null-stream copies) before any non-blocking stream uses them
@@ -196,12 +223,19 @@ extern "C" int ronk_sharded_plan_create(ronk_sharded_plan** out, uint32_t log2n,
   return ronk_sharded_plan_create_ex(out, log2n, inverse, devices, ndev, chunks, RONK_EXCHANGE_MESH);
 }
 
+extern "C" int ronk_sharded_plan_create_p(ronk_sharded_plan** out, uint64_t p, uint64_t g, uint32_t log2n, int inverse,
+                                          const int* devices, int ndev, int chunks, int exchange);
 extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log2n, int inverse, const int* devices, int ndev,
                                            int chunks, int exchange) {
+  return ronk_sharded_plan_create_p(out, RONK_GOLDILOCKS_P, RONK_GOLDILOCKS_G, log2n, inverse, devices, ndev, chunks, exchange);
+}
+extern "C" int ronk_sharded_plan_create_p(ronk_sharded_plan** out, uint64_t p, uint64_t g, uint32_t log2n, int inverse,
+                                          const int* devices, int ndev, int chunks, int exchange) {
   if (!out || !devices || ndev < 1) return RONK_ERR_INVALID;
   if (exchange != RONK_EXCHANGE_MESH && exchange != RONK_EXCHANGE_RCCL) return RONK_ERR_INVALID;
   *out = nullptr;
-  if (log2n > 32) return RONK_ERR_NO_ROOT;  // 2-adicity of p - 1 is 32
+  HostField hf;
+  RCHK(dist_field(p, g, log2n, &hf));
   DistShape sh;
   if (!dist_shape((int)log2n, ndev, &sh)) return RONK_ERR_UNSUPPORTED;
   RCHK(need_device());
@@ -255,8 +289,8 @@ extern "C" int ronk_sharded_plan_create_ex(ronk_sharded_plan** out, uint32_t log
       (void)hipGetLastError();
       how = pe == hipSuccess ? RONK_PEER_DIRECT : RONK_PEER_STAGED;
     }
-    if (!rc) rc = k.p1.compile(build_dist_phase1((int)log2n, inverse != 0, g, ndev, 4, 0, 0, chunks));
-    if (!rc) rc = k.p2.compile(build_dist_phase2((int)log2n, inverse != 0, g, ndev, 4, 0, chunks));
+    if (!rc) rc = k.p1.compile(build_dist_phase1((int)log2n, inverse != 0, g, ndev, 4, 0, 0, chunks, hf));
+    if (!rc) rc = k.p2.compile(build_dist_phase2((int)log2n, inverse != 0, g, ndev, 4, 0, chunks, hf));
     if (!rc && (k.p1.pd.passes.empty() || k.p2.pd.passes.empty())) rc = RONK_ERR_UNSUPPORTED;
     hipError_t e = hipSuccess;
     if (!rc) e = hipStreamSynchronize(0);   // the table uploads (null-stream copies) before the plan's non-blocking streams use them
@@ -391,6 +425,91 @@ static int sharded_enqueue(ronk_sharded_plan* pl, const uint64_t* const* d_in, u
     k.used = true;
   }
   return RONK_OK;
+}
+
+// Diagnostics for the first runs on a real node (bench.py --workload sharded): ONE transform in three SERIALISED stages -- every
+// rank's phase 1 (all chunks), the whole exchange, every rank's phase 2 -- with all devices drained between the stages, wall
+// time per stage in ms[0..2].  The product path (sharded_enqueue) overlaps the stages chunk by chunk; this one exists so that a
+// slow result can be attributed: stage times, and with them the achieved rate per directed link
+// (n * 8 / W^2 bytes per ordered rank pair / ms[1]).  Same results in d_out as ronk_ntt_sharded_dev.
+static int sharded_drain(ronk_sharded_plan* pl) {
+  for (auto& k : pl->r) {
+    RCHK(on_device(k.device));
+    for (size_t h = 0; h < k.copy.size(); h++) if (k.owns[h]) HIPCHK(hipStreamSynchronize(k.copy[h]));
+    HIPCHK(hipStreamSynchronize(k.compute));
+  }
+  return RONK_OK;
+}
+static int sharded_timed(ronk_sharded_plan* pl, const uint64_t* const* d_in, uint64_t* const* d_out, float* ms) {
+  const DistShape& sh = pl->sh;
+  const int W = pl->ndev, chunks = pl->chunks;
+  const bool rccl = pl->exchange == RONK_EXCHANGE_RCCL;
+  const u64 Cwc = sh.Cw / (u64)chunks, blk = sh.Rw * Cwc;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  RCHK(sharded_drain(pl));
+  auto t0 = now();
+  for (int j = 0; j < chunks; j++)
+    for (int g = 0; g < W; g++) {
+      ShardRank& k = pl->r[g];
+      RCHK(on_device(k.device));
+      RCHK(k.p1.run(d_in[g] + (u64)j * Cwc, nullptr, k.send + (u64)j * sh.R * Cwc, k.tmp, k.compute, ~(u64)0, ~(u64)0, 0, (u64)j * Cwc));
+    }
+  RCHK(sharded_drain(pl));
+  ms[0] = since(t0);
+  t0 = now();
+  for (int j = 0; j < chunks; j++) {
+    if (rccl) {
+      RCCLCHK(g_rccl.GroupStart());
+      int r_ = 0;
+      for (int g = 0; g < W && !r_; g++) {
+        ShardRank& k = pl->r[g];
+        const u64* piece = k.send + (u64)j * sh.R * Cwc;
+        for (int h = 0; h < W && !r_; h++) {
+          r_ = g_rccl.Send(piece + (u64)h * blk, (size_t)blk, kNcclUint64, h, k.comm, k.copy[0]);
+          if (!r_) r_ = g_rccl.Recv(k.recv + ((u64)h * chunks + j) * blk, (size_t)blk, kNcclUint64, h, k.comm, k.copy[0]);
+        }
+      }
+      const int r2 = g_rccl.GroupEnd();
+      if (r_) return rccl_fail(r_, "ncclSend / ncclRecv");
+      if (r2) return rccl_fail(r2, "ncclGroupEnd");
+      continue;
+    }
+    for (int g = 0; g < W; g++) {
+      ShardRank& k = pl->r[g];
+      RCHK(on_device(k.device));
+      const u64* piece = k.send + (u64)j * sh.R * Cwc;
+      for (int hh = 0; hh < W; hh++) {
+        const int h = (g + hh) % W;
+        u64* dst = pl->r[h].recv + ((u64)g * chunks + j) * blk;
+        const u64* src = piece + (u64)h * blk;
+        if (pl->peer[(size_t)g * W + h] == RONK_PEER_SAME_DEVICE) HIPCHK(hipMemcpyAsync(dst, src, blk * 8, hipMemcpyDeviceToDevice, k.copy[h]));
+        else HIPCHK(hipMemcpyPeerAsync(dst, pl->r[h].device, src, k.device, blk * 8, k.copy[h]));
+      }
+    }
+  }
+  RCHK(sharded_drain(pl));
+  ms[1] = since(t0);
+  t0 = now();
+  for (int h = 0; h < W; h++) {
+    ShardRank& k = pl->r[h];
+    RCHK(on_device(k.device));
+    RCHK(k.p2.run(k.recv, nullptr, d_out[h], k.tmp, k.compute));
+  }
+  RCHK(sharded_drain(pl));
+  ms[2] = since(t0);
+  return RONK_OK;
+}
+extern "C" int ronk_sharded_time_stages(ronk_sharded_plan* pl, const uint64_t* const* d_in, uint64_t* const* d_out, float* ms) {
+  if (!pl || !d_in || !d_out || !ms) return RONK_ERR_INVALID;
+  for (int g = 0; g < pl->ndev; g++)
+    if (!d_in[g] || !d_out[g] || d_in[g] == d_out[g]) return RONK_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  int prev = 0;
+  HIPCHK(hipGetDevice(&prev));
+  int rc = sharded_timed(pl, d_in, d_out, ms);
+  (void)hipSetDevice(prev);
+  return rc;
 }
 
 extern "C" int ronk_ntt_sharded_dev(ronk_sharded_plan* pl, const uint64_t* const* d_in, uint64_t* const* d_out) {

@@ -219,6 +219,10 @@ int fr_div_linear_run(const uint64_t* d_coeffs, size_t n, const uint64_t* z, uin
   // (the previous call on this device may still be reading the tables: stream-ordered copy from a pageable buffer is
   //  synchronous with respect to the host, and kernels of earlier calls on OTHER streams are waited for)
   HIPCHK(hipStreamSynchronize(s));
+  // From the first enqueue on, EVERY exit path drains `s` before the per-device lock is dropped: the workspace (tables, chunk
+  // sums) and the stack buffer `tabs` the copy reads are shared / short-lived, so a failed launch in the middle must not let
+  // the next opener overwrite tables that queued work still reads.
+  struct DrainOnExit { hipStream_t st; ~DrainOnExit() { (void)hipStreamSynchronize(st); } } drain{s};
   HIPCHK(hipMemcpyAsync(w.tabs.p, tabs, sizeof tabs, hipMemcpyHostToDevice, s));
   const FrScanTab* dt = (const FrScanTab*)w.tabs.p;
   uint64_t* rem = d_rem ? d_rem : (uint64_t*)w.rem.p;
@@ -226,7 +230,7 @@ int fr_div_linear_run(const uint64_t* d_coeffs, size_t n, const uint64_t* z, uin
   hipLaunchKernelGGL(fr_carry_kernel, dim3(1), dim3(256), 0, s, (const uint64_t*)w.H.p, nchunks, dt + 1, (uint64_t*)w.G.p, rem);
   hipLaunchKernelGGL(fr_apply_kernel, dim3((u32)nchunks), dim3(256), 0, s, d_coeffs, n, dt, (const uint64_t*)w.G.p, d_quot);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));                          // the workspace is per device, the tables per call
+  HIPCHK(hipStreamSynchronize(s));                          // the workspace is per device, the tables per call (errors surface here)
   return RONK_OK;
 }
 }  // namespace

@@ -137,9 +137,17 @@ extern "C" int ronk_plan_create_opts(ronk_plan** out, uint64_t p, uint64_t g, ui
     // generic first pass, 110 with the (12, 2, 1) shape); batches of 2^23 keep three passes (measured in round 2).
     int three_from = (log2n == 23 && batch == 1) ? 24 : 23;
     if (const char* e = getenv("RONK_THREE_PASS_FROM")) { int v = atoi(e); if (v >= 13 && v <= 25) three_from = v; }
-    if (opts && opts->reserved[0] >= 13 && opts->reserved[0] <= 25) three_from = opts->reserved[0];   // (include/ronk_ntt.h)
-    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
-    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf));
+    if (opts && opts->three_pass_from_log2 >= 13 && opts->three_pass_from_log2 <= 25) three_from = opts->three_pass_from_log2;
+    // The full twiddle matrix of a 2^11-row x 4-column column pass, transposed (plan.h twf_transposed), where ntt_tile_wl.h's
+    // kernels run it.  EXPERIMENT, measured SLOWER over Goldilocks and kept off (round 6, same box, profiles/r06_wl_ab.txt: two
+    // lanes at 2^22 24.1 k -> 22.3 k NTT/s, 2^21 38.0 k -> 35.2 k; the Montgomery prime +1 %): whole 128-byte lines per load
+    // instruction lose against 32-byte pieces of lines that four neighbouring tiles pull through the same L2 at the same time.
+    // RONK_TWF_T = 0 (default) never, 1 the automatic two-lane plans, 2 every plan with such a pass.
+    static const int twf_t_mode = [] { const char* e = getenv("RONK_TWF_T"); return e ? atoi(e) : 0; }();
+    bool wl_half_ = false;
+    const bool twf_t = tile_wl_wanted(3, &wl_half_) && (twf_t_mode == 2 || (twf_t_mode == 1 && in_flight == 2 && tile_log2_columns < 0 && max_logc == 2));
+    rc = pl->fwd.compile(build_plan((int)log2n, batch, false, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf, twf_t));
+    if (!rc) rc = pl->inv.compile(build_plan((int)log2n, batch, true, max_logc, twf_max_log, three_from, auto_tiles, split_ka, hf, twf_t));
     for (auto& ps : pl->fwd.pd.passes)  // grid must fit the launch API
       if (!rc && (u64)ps.args.tiles * ps.args.nb1 * ps.args.nb2 > 0x7FFFFFFFull) rc = RONK_ERR_UNSUPPORTED;
     // the tables were uploaded by null-stream copies; the plan may be used from any (non-blocking) stream the moment this
@@ -586,6 +594,19 @@ static std::mutex g_cache_mu;
 static std::vector<CacheEntry*> g_cache;   // heap entries: addresses stay valid while the vector changes
 static uint64_t g_cache_clock = 0;
 
+// Cross-stream guard of a cache entry's scratch buffers: every use waits for the event the previous use left behind and leaves
+// its own.  A CAPTURING stream can neither wait for an event recorded outside its capture nor lend the entry an event recorded
+// inside it (it would never complete for anybody else): a captured call skips both -- the graph then owns the entry's
+// scratch whenever it is replayed, like a captured transform owns its plan (transform_dev), and replays must not overlap other
+// users of the same product / transform size (include/ronk_ntt.h).
+static bool entry_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cap != hipStreamCaptureStatusNone;
+}
+static hipError_t entry_wait(hipStream_t s, hipEvent_t ev) { return entry_capturing(s) ? hipSuccess : hipStreamWaitEvent(s, ev, 0); }
+static hipError_t entry_record(hipEvent_t ev, hipStream_t s) { return entry_capturing(s) ? hipSuccess : hipEventRecord(ev, s); }
+
 static void cache_entry_free(CacheEntry* e) {
   if (e->pl) ronk_plan_destroy(e->pl);
   if (e->fa) (void)hipFree(e->fa);
@@ -703,9 +724,9 @@ extern "C" int ronk_dft_dev(uint64_t p, uint64_t g, const uint64_t* d_in, uint64
     CacheEntry* e = nullptr;
     std::lock_guard<std::mutex> lk(g_cache_mu);
     RCHK(cache_get(p, g, (u32)ilog2(n), &e));
-    HIPCHK(hipStreamWaitEvent(s, e->done, 0));
+    HIPCHK(entry_wait(s, e->done));
     RCHK(transform_dev(e->pl, false, d_in, nullptr, d_out, s));
-    HIPCHK(hipEventRecord(e->done, s));
+    HIPCHK(entry_record(e->done, s));
     return RONK_OK;
   }
   if (d_in == d_out) return RONK_ERR_INVALID;
@@ -805,7 +826,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
         ronk_plan_opts o = RONK_PLAN_OPTS_DEFAULT;
         o.tile_log2_columns = 2;
         o.twiddle_matrix_log2_max = ftw;
-        if (k == 23 && fused23) o.reserved[0] = 24;
+        if (k == 23 && fused23) o.three_pass_from_log2 = 24;
         RCHK(ronk_plan_create_opts(&e->pl2, p, g, (u32)k, 2, pl->device, &o));
       } else {
         RCHK(ronk_plan_create(&e->pl2, p, g, (u32)k, 2, pl->device));
@@ -831,7 +852,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
         o.tile_log2_columns = 2;
         o.twiddle_matrix_log2_max = inv_twf != -2 ? inv_twf : 18;
         o.split_log2_rows = k / 2;          // 2^21: 2^10 x 2^11, 2^22: 2^11 x 2^11, 2^23: 2^11 x 2^12
-        if (k == 23) o.reserved[0] = 24;    // two passes
+        if (k == 23) o.three_pass_from_log2 = 24;    // two passes
         RCHK(ronk_plan_create_opts(&e->plf, p, g, (u32)k, 1, pl->device, &o));
       }
       const CompiledPlan& F = e->pl2->fwd;
@@ -848,7 +869,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
         const bool mont = pl->mont_tiled;
         if (mul_mid_matches(fa, ia, fp.logr, (int)fa.logc, kindi) &&
             (mont ? mul_mid_available_mont(fp.logr, (int)fa.logc, kindi) : mul_mid_available(fp.logr, (int)fa.logc, kindi))) {
-          HIPCHK(hipStreamWaitEvent(s, e->done, 0));
+          HIPCHK(entry_wait(s, e->done));
           RCHK(F.launch(0, d_a, nullptr, nullptr, e->pl2->d_tmp, s, (u64)d, ~(u64)0, stride, 0, 0, 0, (u64)d2));
           bool found = false;
           hipError_t he = mont ? launch_mul_mid_mont(fp.logr, kindi, fa, ia, fa.tiles, fp.block, fp.lds_bytes, s, &found)
@@ -856,7 +877,7 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
           if (he != hipSuccess) return hip_fail(he, "launch_mul_mid");
           if (found) {
             RCHK(I.launch(1, nullptr, nullptr, d_out, e->plf->d_tmp, s, ~(u64)0, (u64)m));
-            HIPCHK(hipEventRecord(e->done, s));
+            HIPCHK(entry_record(e->done, s));
             return RONK_OK;
           }
           // (not reached: mul_mid_available said yes)
@@ -865,22 +886,22 @@ static int conv_dev(u64 p, u64 g, int k, const u64* d_a, size_t d, const u64* d_
     }
     ronk_plan* const plinv = e->pli ? e->pli : pl;
     if (!e->fab) HIPCHK(hipMalloc((void**)&e->fab, 2 * N * 8));
-    HIPCHK(hipStreamWaitEvent(s, e->done, 0));
+    HIPCHK(entry_wait(s, e->done));
     RCHK(transform_dev(e->pl2, false, d_a, nullptr, e->fab, s, (u64)d, ~(u64)0, stride, (u64)d2));
     RCHK(transform_dev(plinv, true, e->fab, e->fab + N, d_out, s, ~(u64)0, (u64)m));
-    HIPCHK(hipEventRecord(e->done, s));
+    HIPCHK(entry_record(e->done, s));
     return RONK_OK;
   }
   if (!e->fa) HIPCHK(hipMalloc((void**)&e->fa, N * 8));
   if (!e->fb) HIPCHK(hipMalloc((void**)&e->fb, N * 8));
-  HIPCHK(hipStreamWaitEvent(s, e->done, 0));                                // previous use of this entry's scratch
+  HIPCHK(entry_wait(s, e->done));                                // previous use of this entry's scratch
   // From<[F;N]> zero padding (mod.rs:503-515) is implicit: the forward transforms read the operands in place and
   // treat indices >= d (d2) as ZERO; the inverse loads NTT(a)*NTT(b) (pointwise product fused into the load) and
   // stores only the d + d2 - 1 product coefficients, straight into the caller's buffer.  No memset, no copy.
   RCHK(transform_dev(pl, false, d_a, nullptr, e->fa, s, (u64)d));
   RCHK(transform_dev(pl, false, d_b, nullptr, e->fb, s, (u64)d2));
   RCHK(transform_dev(pl, true, e->fa, e->fb, d_out, s, ~(u64)0, (u64)m));
-  HIPCHK(hipEventRecord(e->done, s));
+  HIPCHK(entry_record(e->done, s));
   return RONK_OK;
 }
 extern "C" int ronk_poly_mul(uint64_t p, uint64_t g, const uint64_t* a, size_t d, const uint64_t* b, size_t d2,

@@ -55,12 +55,11 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
         if (found) return e;
         continue;
       }
-      // 2^11-row x 4-column passes: wave-local exchange + half image (ntt_tile_wl.h).  RONK_WL = 0 off, 1 both passes, 2 column
-      // pass only, 3 row pass only; RONK_WL_WPE = 8 / 6 waves per SIMD the kernel is built for.
-      static const int wl_mode = [] { const char* e_ = getenv("RONK_WL"); return e_ ? atoi(e_) : 0; }();
-      static const int wl_wpe = [] { const char* e_ = getenv("RONK_WL_WPE"); return e_ ? atoi(e_) : 8; }();
-      if (wl_mode && kind < 4 && logr == 11 && a.logc == 2 && (wl_mode == 1 || (wl_mode == 2 && kind != 2) || (wl_mode == 3 && kind == 2))) {
-        hipError_t e = launch_tile_wl(logr, inverse, kind, wl_wpe, a, grid, s, &found);
+      // 2^11-row x 4-column passes (the two-lane plans of 2^21 .. 2^23): one wave-local and one cross-wave exchange, one barrier
+      // per pass (ntt_tile_wl.h).  Round 6, same box: two lanes at 2^22 22.4 k -> 23.6 k NTT/s, one stream 58.5 -> 55.5 us.
+      bool wl_half = false;
+      if (kind < 4 && logr == 11 && a.logc == 2 && tile_wl_wanted(kind, &wl_half)) {
+        hipError_t e = launch_tile_wl(logr, inverse, kind, wl_half, a, grid, s, &found);
         if (found) return e;
       }
       if (kind < 4 && use_half(a, logr, grid, block, kind)) {

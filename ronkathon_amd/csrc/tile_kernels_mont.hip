@@ -14,6 +14,7 @@
 #include "ntt_small.h"
 #include "tile_cfg_table.h"
 #include "tile_kernel_def.h"
+#include "tile_launch.h"
 
 namespace ronk {
 
@@ -63,6 +64,14 @@ hipError_t launch_tile_mont(int logr, bool inverse, const TileArgs& a, u32 grid,
     bool found = false;
     hipError_t e = launch_tile_mont_feat(logr, inverse, tile_features(a), a, grid, block, lds, s, &found);
     if (found) return e;
+  }
+  if (!no_cfg && tile_features(a) == 0 && logr == 11 && a.logc == 2) {   // ntt_tile_wl.h over the Montgomery field policy
+    for (int kind : {1, 2, 3}) {
+      bool half = false, found = false;
+      if (!tile_wl_wanted(kind, &half)) continue;
+      hipError_t e = launch_tile_wl(logr, inverse, kind, false, a, grid, s, &found);
+      if (found) return e;
+    }
   }
   if (!no_cfg && tile_features(a) == 0) {
 #define RONK_MONT_CASE(LR, LC, KD)                                                               \

@@ -1,7 +1,7 @@
 // tile_kernels_wl.hip -- gfx950 instantiations of ntt_tile_wl.h: the 2^11-row x 4-column column / row passes of the two-pass
-// plans with a wave-local exchange, half the LDS image and two workgroup barriers per pass (3-4 resident workgroups per CU).
-// Built for 8 waves per SIMD (<= 64 VGPRs, four workgroups per CU) and for 6 (<= 80 VGPRs, three per CU); the launcher
-// (tile_kernels.hip) picks by RONK_WL / RONK_WL_WPE.
+// plans with one wave-local and one cross-wave exchange per pass.  FULL image (8-byte cells, one barrier per pass, two
+// workgroups per CU): the product's kernels for these shapes, Goldilocks and Montgomery primes.  Half image (4-byte cells,
+// two 32-bit phases, built for 6 waves per SIMD): opt-in with RONK_WL_HALF=1, measured slower (ntt_tile_wl.h).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -11,8 +11,8 @@
 
 namespace ronk {
 
-#define RONK_WL_PROLOGUE                                                                       \
-  __shared__ __attribute__((aligned(16))) u32 l32[8 * WL_REGION];                              \
+#define RONK_WL_PROLOGUE(FULL)                                                                 \
+  __shared__ __attribute__((aligned(16))) u32 l32[8 * WL_REGION * ((FULL) ? 2 : 1)];           \
   const u32 nb = gridDim.x, b = blockIdx.x;                                                    \
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;                                \
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;               \
@@ -23,52 +23,49 @@ namespace ronk {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                     \
   };
 
-template <bool INV, int KIND, int WPE, int MF>
-__global__ void __launch_bounds__(WL_THREADS, WPE) ntt_tile_wl_col_kernel(const TileArgs a) {
-  RONK_WL_PROLOGUE
-  tile_body_wl_col<INV, KIND, MF>(a, l32, threadIdx.x, bid, bar, wsync);
+// WPE: waves per SIMD the kernel is built for (FULL: 4 = two workgroups per CU, up to 128 VGPRs; half image: 6)
+template <bool INV, int KIND, bool FULL, class FLD>
+__global__ void __launch_bounds__(WL_THREADS, FULL ? 4 : 6) ntt_tile_wl_col_kernel(const TileArgs a) {
+  RONK_WL_PROLOGUE(FULL)
+  tile_body_wl_col<INV, KIND, FULL, FLD>(a, l32, threadIdx.x, bid, bar, wsync);
   tile_prefetch_tail(a, bid);
 }
-template <bool INV, int WPE, int MF>
-__global__ void __launch_bounds__(WL_THREADS, WPE) ntt_tile_wl_row_kernel(const TileArgs a) {
-  RONK_WL_PROLOGUE
-  tile_body_wl_row<INV, MF>(a, l32, threadIdx.x, bid, bar, wsync);
+template <bool INV, bool FULL, class FLD>
+__global__ void __launch_bounds__(WL_THREADS, FULL ? 4 : 6) ntt_tile_wl_row_kernel(const TileArgs a) {
+  RONK_WL_PROLOGUE(FULL)
+  tile_body_wl_row<INV, FULL, FLD>(a, l32, threadIdx.x, bid, bar, wsync);
   tile_prefetch_tail(a, bid);
 }
 
-// experiments: RONK_WL_PAD = bytes of (unused) dynamic LDS per workgroup, to bound the workgroups per CU from above;
-// RONK_WL_MF_COL / RONK_WL_MF_ROW = memory-policy flags (ntt_tile_wl.h WL_NT_*; forward matrix column pass / forward row pass
-// of the 6-waves-per-SIMD build only)
+// experiments with the half image: RONK_WL_PAD = bytes of (unused) dynamic LDS per workgroup, to bound the workgroups per CU
 static u32 wl_pad() { static const u32 v = [] { const char* e = getenv("RONK_WL_PAD"); return e ? (u32)atoi(e) : 0u; }(); return v; }
-static int wl_mf(bool row) {
-  static const int c = [] { const char* e = getenv("RONK_WL_MF_COL"); return e ? atoi(e) : 0; }();
-  static const int r = [] { const char* e = getenv("RONK_WL_MF_ROW"); return e ? atoi(e) : 0; }();
-  return row ? r : c;
-}
 
-template <bool INV, int WPE>
+template <bool INV, bool FULL, class FLD>
 static hipError_t launch_wl(int kind, const TileArgs& a, u32 grid, hipStream_t s) {
-  const u32 pad = wl_pad();
-  if constexpr (!INV && WPE == 6) {
-    const int mf = wl_mf(kind == 2);
-#define RONK_WL_MF_COL_CASE(M) if (kind == 3 && mf == M) { hipLaunchKernelGGL((ntt_tile_wl_col_kernel<false, 3, 6, M>), dim3(grid), dim3(WL_THREADS), pad, s, a); return hipGetLastError(); }
-#define RONK_WL_MF_ROW_CASE(M) if (kind == 2 && mf == M) { hipLaunchKernelGGL((ntt_tile_wl_row_kernel<false, 6, M>), dim3(grid), dim3(WL_THREADS), pad, s, a); return hipGetLastError(); }
-    RONK_WL_MF_COL_CASE(1) RONK_WL_MF_COL_CASE(2) RONK_WL_MF_COL_CASE(3)
-    RONK_WL_MF_ROW_CASE(2) RONK_WL_MF_ROW_CASE(4) RONK_WL_MF_ROW_CASE(6)
-  }
+  const u32 pad = FULL ? 0u : wl_pad();
   switch (kind) {
-    case 1: hipLaunchKernelGGL((ntt_tile_wl_col_kernel<INV, 1, WPE, 0>), dim3(grid), dim3(WL_THREADS), pad, s, a); break;
-    case 3: hipLaunchKernelGGL((ntt_tile_wl_col_kernel<INV, 3, WPE, 0>), dim3(grid), dim3(WL_THREADS), pad, s, a); break;
-    default: hipLaunchKernelGGL((ntt_tile_wl_row_kernel<INV, WPE, 0>), dim3(grid), dim3(WL_THREADS), pad, s, a); break;
+    case 1: hipLaunchKernelGGL((ntt_tile_wl_col_kernel<INV, 1, FULL, FLD>), dim3(grid), dim3(WL_THREADS), pad, s, a); break;
+    case 3: hipLaunchKernelGGL((ntt_tile_wl_col_kernel<INV, 3, FULL, FLD>), dim3(grid), dim3(WL_THREADS), pad, s, a); break;
+    default: hipLaunchKernelGGL((ntt_tile_wl_row_kernel<INV, FULL, FLD>), dim3(grid), dim3(WL_THREADS), pad, s, a); break;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_tile_wl(int logr, bool inverse, int kind, int wpe, const TileArgs& a, u32 grid, hipStream_t s, bool* found) {
+hipError_t launch_tile_wl(int logr, bool inverse, int kind, bool half, const TileArgs& a, u32 grid, hipStream_t s, bool* found) {
   *found = tile_wl_matches(a, logr, kind);
   if (!*found) return hipSuccess;
-  if (wpe >= 8) return inverse ? launch_wl<true, 8>(kind, a, grid, s) : launch_wl<false, 8>(kind, a, grid, s);
-  return inverse ? launch_wl<true, 6>(kind, a, grid, s) : launch_wl<false, 6>(kind, a, grid, s);
+  if (a.fc.p) return inverse ? launch_wl<true, true, MontField>(kind, a, grid, s) : launch_wl<false, true, MontField>(kind, a, grid, s);
+  if (half) return inverse ? launch_wl<true, false, GlField>(kind, a, grid, s) : launch_wl<false, false, GlField>(kind, a, grid, s);
+  return inverse ? launch_wl<true, true, GlField>(kind, a, grid, s) : launch_wl<false, true, GlField>(kind, a, grid, s);
+}
+
+// RONK_WL: 0 = the ntt_tile.h kernels for these shapes (A/B), 1 (default) = both passes, 2 = column pass only, 3 = row pass only;
+// RONK_WL_HALF=1: the half-image form (Goldilocks)
+bool tile_wl_wanted(int kind, bool* half) {
+  static const int mode = [] { const char* e = getenv("RONK_WL"); return e ? atoi(e) : 1; }();
+  static const bool h = [] { const char* e = getenv("RONK_WL_HALF"); return e && atoi(e) != 0; }();
+  *half = h;
+  return mode == 1 || (mode == 2 && kind != 2) || (mode == 3 && kind == 2);
 }
 
 }  // namespace ronk

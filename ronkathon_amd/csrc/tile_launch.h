@@ -7,9 +7,10 @@
 namespace ronk {
 hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
                        hipStream_t stream);
-// ntt_tile_wl.h (tile_kernels_wl.hip): 2^11-row x 4-column passes with a wave-local exchange and half the LDS image; wpe = waves
-// per SIMD the kernel is built for (8 or 6); *found = the pass has that shape
-hipError_t launch_tile_wl(int logr, bool inverse, int kind, int wpe, const TileArgs& a, u32 grid, hipStream_t stream, bool* found);
+// ntt_tile_wl.h (tile_kernels_wl.hip): 2^11-row x 4-column passes with one wave-local and one cross-wave exchange (one barrier per
+// pass); Goldilocks and Montgomery primes (a.fc).  half = the half-image form (experiments).  *found = the pass has that shape.
+hipError_t launch_tile_wl(int logr, bool inverse, int kind, bool half, const TileArgs& a, u32 grid, hipStream_t stream, bool* found);
+bool tile_wl_wanted(int kind, bool* half);   // RONK_WL / RONK_WL_HALF
 // the latency form of a pass (ntt_small.h: 4 coefficients per work-item), 2^4 .. 2^10 rows
 hipError_t launch_small(int logr, bool inverse, const TileArgs& a, u32 grid, u32 block, size_t lds_bytes,
                         hipStream_t stream);

@@ -50,10 +50,14 @@ def place_output(out_global, local_out, rank, world):
 class HipEngine:
     """the product local engine: ronk_dist_plan over the C ABI (HIP kernels); torch tensors only carry memory"""
 
-    def __init__(self, log2n, inverse, rank, world, device=-1, chunks=1):
+    def __init__(self, log2n, inverse, rank, world, device=-1, chunks=1, p=None, g=None):
+        """p, g: any odd prime with 2^log2n | p - 1 and a primitive element of it (ronk_dist_plan_create_p); default Goldilocks"""
         self.h = None
         h = C.c_void_p()
-        L.check(L.lib.ronk_dist_plan_create_chunked(C.byref(h), log2n, int(inverse), rank, world, device, chunks))
+        if p is None:
+            L.check(L.lib.ronk_dist_plan_create_chunked(C.byref(h), log2n, int(inverse), rank, world, device, chunks))
+        else:
+            L.check(L.lib.ronk_dist_plan_create_p(C.byref(h), int(p), int(g), log2n, int(inverse), rank, world, device, chunks))
         self.h = h
 
     def phase1(self, d_in, d_send, stream=0):
@@ -249,10 +253,51 @@ def bench_fourstep(log2n, steps, warmup, chunks=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n = 1 << log2n
+    # Where one transform's time goes when nothing overlaps: phase 1 (all chunks), ONE whole all-to-all, phase 2 -- each between
+    # device synchronisations and rank barriers, maximum over the ranks, best of three.  With it: the achieved rate per directed
+    # link of the exchange (n * 8 / W^2 bytes per ordered rank pair) -- what tells a peer-to-peer xGMI exchange from one that is
+    # staged through host memory without a second run.
+    def _max_over_ranks(v):
+        if world > 1:
+            t_ = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        return v
+
+    def _stage(fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_ = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return _max_over_ranks((time.perf_counter() - t_) * 1e3)
+
+    def _exchange_only():
+        if world == 1:
+            return
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(recv, send)
+        else:
+            h_ = send.cpu(); r_ = torch.empty_like(h_)
+            dist.all_to_all_single(r_, h_)
+            recv.copy_(r_)
+
+    runs = []
+    for _ in range(3):
+        p1 = _stage(lambda: fs.engine.phase1(fs._ptr(loc), fs._ptr(send), 0))
+        ex = _stage(_exchange_only)
+        p2 = _stage(lambda: fs.engine.phase2(fs._ptr(recv if world > 1 else send), fs._ptr(out), 0))
+        runs.append((p1, ex, p2))
+    p1, ex, p2 = min(runs, key=sum)
+    per_link = n * 8 / float(world * world)
+    stages = {"phase1_ms": p1, "exchange_ms": ex, "phase2_ms": p2, "bytes_per_directed_link": per_link,
+              "GBs_per_directed_link": (per_link / (ex * 1e-3) / 1e9) if (world > 1 and ex > 0) else None,
+              "overlap_gain_ms": p1 + ex + p2 - dt / steps * 1e3}
     return {"metric": "sharded four-step forward NTTs/s, degree 2^%d" % log2n, "value": steps / dt, "unit": "NTT/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "four-step NTT n = 2^%d sharded over %d GPUs, RCCL all-to-all transpose in %d column chunk(s)"
-                                   % (log2n, world, fs.chunks), "chunks": fs.chunks},
+                                   % (log2n, world, fs.chunks), "chunks": fs.chunks, "stages_serialised": stages},
             "roofline": {"bound": "hbm", "achieved": 16.0 * n / world / (dt / steps) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": 16.0 * n / world / (dt / steps) / 1e9 / 8000.0, "traffic": None}}

@@ -406,6 +406,12 @@ class ShardedPlan {
       : n_((size_t)1 << log2n) {
     check(ronk_sharded_plan_create_ex(&h_, log2n, inverse ? 1 : 0, devices.data(), (int)devices.size(), chunks, exchange));
   }
+  // the same over any odd prime p with 2^log2n | p - 1 and primitive element g (ronk_sharded_plan_create_p)
+  ShardedPlan(uint64_t p, uint64_t g, uint32_t log2n, const std::vector<int>& devices, bool inverse = false, int chunks = 0,
+              int exchange = RONK_EXCHANGE_MESH)
+      : n_((size_t)1 << log2n) {
+    check(ronk_sharded_plan_create_p(&h_, p, g, log2n, inverse ? 1 : 0, devices.data(), (int)devices.size(), chunks, exchange));
+  }
   ShardedPlan(const ShardedPlan&) = delete;
   ShardedPlan& operator=(const ShardedPlan&) = delete;
   ~ShardedPlan() { if (h_) ronk_sharded_plan_destroy(h_); }

@@ -291,6 +291,24 @@ impl DevicePoly {
     (quot, rem)
   }
 
+  /// `div_rem` for operands the caller KNOWS to be full-length (`self[len - 1] != 0`, `rhs[len - 1] != 0`, `self.len >= rhs.len`):
+  /// `ronk_poly_divrem_full_dev` -- the O(n log n) form with nothing read back before the work is queued (one synchronisation at
+  /// the end, for the status word).  Panics with "invalid argument" when the promise does not hold.
+  pub fn div_rem_full(&self, rhs: &DevicePoly) -> (DevicePoly, DevicePoly) {
+    self.same_device(rhs);
+    let _g = OnDevice::new(self.device);
+    let (quot, rem) = (DevicePoly::alloc_on(self.device, self.len), DevicePoly::alloc_on(self.device, self.len));
+    let mut status = 0 as c_int;
+    let d_status = DevicePoly::alloc_on(self.device, 1);
+    check(unsafe {
+      ffi::ronk_poly_divrem_full_dev(P, self.ptr, self.len, rhs.ptr, rhs.len, quot.ptr, rem.ptr, d_status.ptr as *mut c_int, ptr::null_mut())
+    });
+    check(unsafe { ffi::ronk_dev_sync() });
+    check(unsafe { ffi::ronk_memcpy_d2h(&mut status as *mut c_int as *mut c_void, d_status.ptr as *const c_void, 4) });
+    check(status);
+    (quot, rem)
+  }
+
   /// element-wise `impl Add` / `impl Sub` of two equally long polynomials (arithmetic.rs:16-68), `impl Mul` of two
   /// Lagrange-basis polynomials on the same nodes
   pub fn add(&self, rhs: &DevicePoly) -> DevicePoly { self.zip(rhs, ffi::ronk_vec_add_dev) }
@@ -421,6 +439,18 @@ impl ShardedPlan {
     let ex = match exchange { Exchange::Mesh => ffi::EXCHANGE_MESH, Exchange::Rccl => ffi::EXCHANGE_RCCL };
     check(unsafe {
       ffi::ronk_sharded_plan_create_ex(&mut raw, log2n, inverse as c_int, devices.as_ptr(), devices.len() as c_int, chunks, ex)
+    });
+    Self { raw, n: 1usize << log2n, ndev: devices.len(), devices: devices.to_vec() }
+  }
+
+  /// `ronk_sharded_plan_create_p`: the same transform over any odd 64-bit prime `p` with 2^log2n | p - 1 and primitive element
+  /// `g` -- what `Prime64<P, G>` hands over (`ShardedPlan::for_prime(P, G, ..)`); the phases run the tile kernels over Montgomery
+  /// arithmetic.  The reference's field is generic over its modulus (src/algebra/field/prime/mod.rs:39-52).
+  pub fn for_prime(p: u64, g: u64, log2n: u32, inverse: bool, devices: &[i32], chunks: i32, exchange: Exchange) -> Self {
+    let mut raw: *mut RonkShardedPlan = ptr::null_mut();
+    let ex = match exchange { Exchange::Mesh => ffi::EXCHANGE_MESH, Exchange::Rccl => ffi::EXCHANGE_RCCL };
+    check(unsafe {
+      ffi::ronk_sharded_plan_create_p(&mut raw, p, g, log2n, inverse as c_int, devices.as_ptr(), devices.len() as c_int, chunks, ex)
     });
     Self { raw, n: 1usize << log2n, ndev: devices.len(), devices: devices.to_vec() }
   }

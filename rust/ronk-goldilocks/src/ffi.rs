@@ -38,11 +38,13 @@ pub struct RonkPlanOpts {
   pub in_flight:               c_int,
   /// two-pass plans: log2 of the first pass's rows, 0 = the planner's (balanced) choice
   pub split_log2_rows:         c_int,
-  pub reserved:                [c_int; 4],
+  /// 0 = the planner's choice; 13 .. 25: the smallest log2n that is split in three passes
+  pub three_pass_from_log2:    c_int,
+  pub reserved:                [c_int; 3],
 }
 impl Default for RonkPlanOpts {
   fn default() -> Self {
-    Self { tile_log2_columns: -1, twiddle_matrix_log2_max: -1, in_flight: -1, split_log2_rows: 0, reserved: [0; 4] }
+    Self { tile_log2_columns: -1, twiddle_matrix_log2_max: -1, in_flight: -1, split_log2_rows: 0, three_pass_from_log2: 0, reserved: [0; 3] }
   }
 }
 
@@ -137,6 +139,12 @@ extern "C" {
     p: u64, d_a: *const u64, d: usize, d_b: *const u64, d2: usize, d_quot: *mut u64, d_rem: *mut u64,
     d_status: *mut c_int, stream: *mut c_void,
   ) -> c_int;
+  /// the same for FULL-LENGTH operands (top coefficients non-zero, d >= d2): nothing is read back, so the call is asynchronous
+  /// and capturable at any size; `*d_status = RONK_ERR_INVALID` when a top coefficient turns out to be ZERO
+  pub fn ronk_poly_divrem_full_dev(
+    p: u64, d_a: *const u64, d: usize, d_b: *const u64, d2: usize, d_quot: *mut u64, d_rem: *mut u64,
+    d_status: *mut c_int, stream: *mut c_void,
+  ) -> c_int;
   /// batched `Message::encode::<N>` (codes/reed_solomon.rs:42-52): `plan.batch` messages of k coefficients -> batch x N y-coordinates
   pub fn ronk_rs_encode_batch_dev(plan: *mut RonkPlan, d_msgs: *const u64, k: usize, d_ys: *mut u64, stream: *mut c_void) -> c_int;
   /// low-degree extension of a batch: values on {omega_K^i} -> values on coset_shift * {omega_N^i} (ifft, then encode::<N>)
@@ -171,6 +179,12 @@ extern "C" {
   pub fn ronk_sharded_plan_create_ex(
     out: *mut *mut RonkShardedPlan, log2n: u32, inverse: c_int, devices: *const c_int, ndev: c_int, chunks: c_int,
     exchange: c_int,
+  ) -> c_int;
+  /// the same over any odd 64-bit prime `p` with 2^log2n | p - 1 and primitive element `g` (the phases run the tile kernels over
+  /// Montgomery arithmetic); `Prime64<P, G>`'s sharded transform
+  pub fn ronk_sharded_plan_create_p(
+    out: *mut *mut RonkShardedPlan, p: u64, g: u64, log2n: u32, inverse: c_int, devices: *const c_int, ndev: c_int,
+    chunks: c_int, exchange: c_int,
   ) -> c_int;
   pub fn ronk_sharded_plan_exchange(plan: *const RonkShardedPlan) -> c_int;
   pub fn ronk_sharded_plan_peer_access(plan: *const RonkShardedPlan, matrix: *mut c_int, capacity: c_int) -> c_int;

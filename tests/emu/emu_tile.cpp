@@ -54,6 +54,28 @@ template <bool INV, class FLD>
 static bool dispatch_cfg(int logr, u32 tid) {
   const TileArgs& a = *g_fa.a;
   static const bool half = getenv("RONK_HALF_LDS") && atoi(getenv("RONK_HALF_LDS")) == 1;   // TileCfg::HALF instantiations
+  // the wave-local bodies of the 2^11-row x 4-column passes (ntt_tile_wl.h), selected like the library does: RONK_WL = 0 off, 1
+  // (default) both passes, 2 column pass only, 3 row pass only; RONK_WL_HALF=1 the half-image form (Goldilocks)
+  {
+    static const int wl = getenv("RONK_WL") ? atoi(getenv("RONK_WL")) : 1;
+    static const bool wl_half = getenv("RONK_WL_HALF") && atoi(getenv("RONK_WL_HALF")) != 0;
+    if (wl && logr == WL_LOGR && (int)a.logc == WL_LOGC) {
+      for (int kind : {1, 2, 3}) {
+        if (!tile_wl_matches(a, logr, kind)) continue;
+        if (kind == 2 ? wl == 2 : wl == 3) continue;
+        u32* l32 = reinterpret_cast<u32*>(g_fa.lds);
+        if (wl_half && !FLD::MONT) {
+          if (kind == 1) tile_body_wl_col<INV, 1, false, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+          else if (kind == 3) tile_body_wl_col<INV, 3, false, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+          else tile_body_wl_row<INV, false, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+        } else if (kind == 1) tile_body_wl_col<INV, 1, true, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+        else if (kind == 3) tile_body_wl_col<INV, 3, true, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+        else tile_body_wl_row<INV, true, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+        g_cfg_used = 30 + kind;
+        return true;
+      }
+    }
+  }
   if constexpr (FLD::MONT) {   // the shapes the library instantiates for Montgomery primes (tile_kernels_mont.hip): the plain table
     if (const int feat = tile_features(a)) {   // ... and the feature shapes in the direction they occur in (tile_kernels_mont_feat.hip)
 #define EMU_MONT_FEAT_CASE(LR, LC, KD, FT)                                                       \
@@ -76,21 +98,6 @@ static bool dispatch_cfg(int logr, u32 tid) {
 #undef EMU_MONT_CASE
     return false;
   } else {
-  // the wave-local / half-image bodies of the 2^11-row x 4-column passes (ntt_tile_wl.h; RONK_WL as in the library: 1 both
-  // passes, 2 column pass only, 3 row pass only)
-  static const int wl = getenv("RONK_WL") ? atoi(getenv("RONK_WL")) : 0;
-  if (wl && logr == WL_LOGR && (int)a.logc == WL_LOGC) {
-    for (int kind : {1, 2, 3}) {
-      if (!tile_wl_matches(a, logr, kind)) continue;
-      if (kind == 2 ? wl == 2 : wl == 3) continue;
-      u32* l32 = reinterpret_cast<u32*>(g_fa.lds);
-      if (kind == 1) tile_body_wl_col<INV, 1>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-      else if (kind == 3) tile_body_wl_col<INV, 3>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-      else tile_body_wl_row<INV>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-      g_cfg_used = 30 + kind;
-      return true;
-    }
-  }
   if (half) {
 #define EMU_HALF_CASE(LR, LC, KD)                                                                \
   if (logr == LR && (int)a.logc == LC && tile_cfg_matches(a, LR, LC, KD)) {                      \
@@ -405,7 +412,8 @@ int main(int argc, char** argv) {
   bool auto_tiles = argc > 9 && atoi(argv[9]) != 0;   // the planner's own per-pass tile rules (ronk_plan_create's default)
   u64 in_valid1 = argc > 10 ? strtoull(argv[10], 0, 10) : 0;   // TileArgs::in_valid1: the limit of batch entries >= 1 (paired multiply operands)
   const bool with_in2 = argc > 11 && atoi(argv[11]) != 0;      // TileArgs::in2: a second operand multiplied in on load (fused pointwise product)
-  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles, 0, g_hf);
+  const bool twf_t = getenv("RONK_TWF_T") && atoi(getenv("RONK_TWF_T")) != 0;   // the full twiddle matrix transposed (plan.h)
+  PlanDesc pd = build_plan(log2n, batch, inv, max_logc, twf, three_from, auto_tiles, 0, g_hf, twf_t);
 
   std::vector<u64> in(n * batch), out(n * batch, 0xDEADBEEFull), tmp(n * batch, 0xDEADBEEFull), ref(n * batch);
   u64 s = 0x5EED0000ull + log2n;

@@ -135,7 +135,7 @@ def test_argument_errors_of_the_round_3_entry_points_need_no_device():
     assert L.lib.ronk_sharded_plan_exchange(None) == L.ERR_INVALID
     assert L.ERR_RCCL == -12 and L.lib.ronk_strerror(L.ERR_RCCL) == b"RCCL error"
     opts = L.PlanOpts()
-    assert (opts.tile_log2_columns, opts.twiddle_matrix_log2_max, opts.in_flight, opts.split_log2_rows, list(opts.reserved)) == (-1, -1, -1, 0, [0] * 4)
+    assert (opts.tile_log2_columns, opts.twiddle_matrix_log2_max, opts.in_flight, opts.split_log2_rows, opts.three_pass_from_log2, list(opts.reserved)) == (-1, -1, -1, 0, 0, [0] * 3)
     assert C.sizeof(L.PlanOpts) == 32                                                                  # 8 ints, as in the header
 
 

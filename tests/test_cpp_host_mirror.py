@@ -123,10 +123,10 @@ def test_rust_ffi_replay_compiles_and_shim_sources_match_the_header():
     # ronk_plan_opts field for field
     m = re.search(r"typedef struct ronk_plan_opts \{(.*?)\} ronk_plan_opts;", hdr, re.S)
     c_fields = [re.sub(r"\s+", " ", f.strip()) for f in m.group(1).split(";") if f.strip()]
-    assert c_fields == ["int tile_log2_columns", "int twiddle_matrix_log2_max", "int in_flight", "int split_log2_rows", "int reserved[4]"]
+    assert c_fields == ["int tile_log2_columns", "int twiddle_matrix_log2_max", "int in_flight", "int split_log2_rows", "int three_pass_from_log2", "int reserved[3]"]
     r_fields = re.search(r"pub struct RonkPlanOpts \{(.*?)\}", ffi, re.S).group(1)
     assert re.findall(r"pub (\w+):\s*([^,]+),", r_fields) == [("tile_log2_columns", "c_int"), ("twiddle_matrix_log2_max", "c_int"),
-                                                              ("in_flight", "c_int"), ("split_log2_rows", "c_int"), ("reserved", "[c_int; 4]")]
+                                                              ("in_flight", "c_int"), ("split_log2_rows", "c_int"), ("three_pass_from_log2", "c_int"), ("reserved", "[c_int; 3]")]
     # visibility desk-check: every method the shim's sources call on the reference's Polynomial is `pub` there
     # (src/polynomial/mod.rs:98 new, :113 degree, :133 evaluate, :240 dft, :273 fft, :358 Lagrange new, :382 evaluate,
     # :430 ifft); the private ones (:101 trim_zeros, :170 quotient_and_remainder, :295 fft_recursive, :456 ifft_recursive)

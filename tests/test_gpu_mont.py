@@ -126,6 +126,88 @@ def test_mont_three_pass_whole_vector(L, orc, p, g, k):
     plan.close()
 
 
+@pytest.mark.parametrize("k", [25, 26])
+def test_mont_three_pass_largest_sizes_whole_vector(L, orc, k):
+    """2^25 / 2^26 over the prime above 2^63 (three-pass plans on the Montgomery bodies): every output against the oracle,
+    forward; the inverse by round trip"""
+    p, g = PRIMES[0]
+    n = 1 << k
+    x = corners(splitmix_field(0x900 + k, n, p), p)
+    plan = L.Plan(p, g, k)
+    assert plan.path() == 2
+    y = plan.forward(x)
+    assert np.array_equal(y, orc.fft(p, g, x))
+    assert np.array_equal(plan.inverse(y), x)
+    plan.close()
+
+
+@pytest.mark.parametrize("p,g", PRIMES[:2] + [GL_OTHER])
+def test_mont_sharded_transform(L, orc, p, g):
+    """ronk_sharded_plan_create_p: the four-step transform inside the library over a generic prime (the phases on the Montgomery
+    tile bodies), 1 .. 8 logical ranks on the visible GPU(s), chunked and unchunked, forward and inverse, up to 2^24 -- whole
+    vectors against the oracle called with (p, g).  Reference: the transform is generic over the modulus
+    (src/algebra/field/prime/mod.rs:39-52, src/polynomial/mod.rs:273-323)."""
+    import ronkathon_amd as R
+    ndev = R.device_count()
+    cases = [(12, 1, 1, False), (16, 2, 0, False), (16, 4, 2, True), (18, 8, 1, False), (20, 8, 4, False), (20, 4, 0, True)]
+    if (p, g) == PRIMES[0]:
+        cases += [(22, 2, 0, True), (24, 8, 2, False)]
+    for log2n, W, chunks, inv in cases:
+        x = corners(splitmix_field(0xA00 + log2n + W, 1 << log2n, p), p)
+        ref = orc.ifft(p, g, x) if inv else orc.fft(p, g, x)
+        layouts = [[0] * W] + ([[r % ndev for r in range(W)]] if ndev >= 2 else [])
+        for devs in layouts:
+            sp = L.ShardedPlan(log2n, devs, inverse=inv, chunks=chunks, p=p, g=g)
+            assert np.array_equal(sp.transform(x), ref), (hex(p), log2n, W, chunks, inv, devs)
+            if log2n <= 20:
+                assert np.array_equal(sp.transform(x), ref)     # second call: buffer reuse behind the event guards
+            sp.close()
+    # what the reference reports by panicking, and what this path does not cover
+    with pytest.raises(L.RonkPanic) as e:
+        L.ShardedPlan(60, [0], p=p, g=g)                        # 2^60 does not divide p - 1
+    assert e.value.code == L.ERR_NO_ROOT
+    with pytest.raises(L.RonkPanic) as e:
+        L.ShardedPlan(16, [0, 0], p=p, g=(g * g) % p)           # a residue generates no full 2-power subgroup: no radix-2 fallback here
+    assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(L.RonkPanic) as e:
+        L.ShardedPlan(16, [0, 0], p=p - 2, g=3)                 # not a prime
+    assert e.value.code in (L.ERR_NOT_PRIME, L.ERR_NO_ROOT)
+
+
+def test_mont_dist_phases_one_process_per_rank_protocol(L, orc):
+    """ronk_dist_plan_create_p: the two local phases a rank runs around the caller's all-to-all (one process per GPU), here for
+    every rank of a world of 4 in one process with the exchange done by numpy -- generic prime, chunked send layout"""
+    import ctypes as C
+    from ronkathon_amd import dist as D
+    from test_gpu_parity import _DevArr
+    p, g = PRIMES[0]
+    for log2n, W, chunks in ((16, 4, 1), (20, 4, 2), (20, 2, 4)):
+        n = 1 << log2n
+        x = corners(splitmix_field(0xB00 + log2n + W, n, p), p)
+        Rr, Cc, Rw, Cw = D.shape(log2n, W)
+        Cwc = Cw // chunks
+        send = []
+        for r in range(W):
+            eng = D.HipEngine(log2n, False, r, W, chunks=chunks, p=p, g=g)
+            din, dsend = _DevArr(D.scatter_input(x, r, W)), _DevArr(n=n // W)
+            eng.phase1(din.ptr, dsend.ptr)
+            send.append(dsend.get())
+            eng.close()
+        out = np.empty(n, dtype=np.uint64)
+        for h in range(W):
+            recv = np.empty(n // W, dtype=np.uint64)
+            blk = Rw * Cwc
+            for r in range(W):
+                for j in range(chunks):
+                    recv[(r * chunks + j) * blk:(r * chunks + j + 1) * blk] = send[r][j * Rr * Cwc + h * blk: j * Rr * Cwc + (h + 1) * blk]
+            eng = D.HipEngine(log2n, False, h, W, chunks=chunks, p=p, g=g)
+            drecv, dout = _DevArr(recv), _DevArr(n=n // W)
+            eng.phase2(drecv.ptr, dout.ptr)
+            D.place_output(out, dout.get(), h, W)
+            eng.close()
+        assert np.array_equal(out, orc.fft(p, g, x)), (log2n, W, chunks)
+
+
 @pytest.mark.parametrize("p,g", PRIMES + [GL_OTHER])
 def test_mont_poly_mul_ntt_path(L, orc, p, g):
     """Polynomial Mul (src/polynomial/arithmetic.rs:97-119) through the Montgomery NTT path: schoolbook oracle at small sizes,
@@ -222,3 +304,114 @@ def test_mont_rs_encode_batch_and_lde(L, orc, p, g):
         pad = np.zeros(1 << kn, dtype=np.uint64); pad[:1 << kk] = orc.vec_mul(p, coeffs[b << kk:(b + 1) << kk], pw)
         assert np.array_equal(got[b << kn:(b + 1) << kn], orc.fft(p, g, pad)), b
     pk.close(); pn.close()
+
+
+def test_newton_division_over_generic_primes(L, orc):
+    """quotient_and_remainder (reference src/polynomial/mod.rs:170-225) in O(n log n) for EVERY prime with enough 2-adicity, not
+    only Goldilocks (round 6): ronk_poly_divrem and ronk_poly_divrem_dev take the Newton form on the NTT path over Montgomery
+    arithmetic; the oracle is the statement-by-statement long division called with p.  Whole quotients and remainders; 2^20 by
+    2^19 for the prime above 2^63 (the one-workgroup long division needs minutes there) via the identity a = q b + r."""
+    import torch
+
+    def divrem(p, a, b):
+        a, b = L.arr(a), L.arr(b)
+        q, r = np.empty_like(a), np.empty_like(a)
+        L.check(L.lib.ronk_poly_divrem(p, L.ptr(a), a.size, L.ptr(b), b.size, L.ptr(q), L.ptr(r)))
+        return q, r
+
+    def z(v, k):
+        return np.concatenate([v, np.zeros(k, dtype=np.uint64)])
+
+    for p, g in PRIMES[:2] + [(GP, 7)]:
+        cases = [(splitmix_field(1, 40000, p), splitmix_field(2, 9000, p)),
+                 (z(splitmix_field(5, 20000, p), 1234), splitmix_field(6, 700, p)),      # dividend with leading zeros
+                 (splitmix_field(3, 30000, p), z(splitmix_field(4, 3000, p), 500)),      # ragged divisor: the reference's early stop / panic
+                 (splitmix_field(9, 8192, p), splitmix_field(10, 4096, p))]
+        for a, b in cases:
+            try:
+                oq, o_r = orc.poly_divrem(p, a, b)
+            except orc.OraclePanic as e:
+                with pytest.raises(L.RonkPanic) as e2:
+                    divrem(p, a, b)
+                assert e2.value.code == e.code
+                continue
+            q, r = divrem(p, a, b)
+            assert np.array_equal(q, oq) and np.array_equal(r, o_r), (hex(p), a.size, b.size)
+        # device-resident forms: the probing one and the fully asynchronous one for full-length operands
+        a, b = cases[0]
+        oq, o_r = orc.poly_divrem(p, a, b)
+        da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        for fn in (L.lib.ronk_poly_divrem_dev, L.lib.ronk_poly_divrem_full_dev):
+            dq = torch.full((a.size,), -1, dtype=torch.int64, device="cuda"); dr = torch.full((a.size,), -1, dtype=torch.int64, device="cuda")
+            status = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            L.check(fn(p, da.data_ptr(), a.size, db.data_ptr(), b.size, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            assert np.array_equal(dq.cpu().numpy().view(np.uint64), oq) and np.array_equal(dr.cpu().numpy().view(np.uint64), o_r), hex(p)
+        # the promise of the full-length form is checked on the device
+        a0 = a.copy(); a0[-1] = 0
+        da0 = torch.from_numpy(a0.view(np.int64)).cuda()
+        L.check(L.lib.ronk_poly_divrem_full_dev(p, da0.data_ptr(), a.size, db.data_ptr(), b.size, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert int(status.item()) == L.ERR_INVALID
+    p, g = PRIMES[0]
+    a, b = splitmix_field(21, 1 << 20, p), splitmix_field(22, 1 << 19, p)
+    q, r = divrem(p, a, b)
+    assert not r[b.size - 1:].any()
+    for pt in (5, 0xABCDEF0123456789 % p):
+        lhs = orc.poly_eval(p, a, pt)
+        rhs = orc.add(p, orc.mul(p, orc.poly_eval(p, q, pt), orc.poly_eval(p, b, pt)), orc.poly_eval(p, r, pt))
+        assert lhs == rhs
+    assert int(q[a.size - b.size]) == orc.div(p, int(a[-1]), int(b[-1])) and not q[a.size - b.size + 1:].any()
+    # a prime without the 2-adicity (F_101: 4 | p - 1 only) keeps the long division -- same window, same results
+    a, b = splitmix_field(31, 3000, 101), splitmix_field(32, 100, 101)
+    a[-1] = 1; b[-1] = 1
+    q, r = divrem(101, a, b)
+    oq, o_r = orc.poly_divrem(101, a, b)
+    assert np.array_equal(q, oq) and np.array_equal(r, o_r)
+
+
+def test_full_length_division_is_capturable(L, orc):
+    """ronk_poly_divrem_full_dev inside a hipGraph: nothing is read back, so a size the long division could never serve (2^17 by
+    2^16) is captured and replayed; values against the oracle on a smaller pair, identity a = q b + r on the large one"""
+    import torch
+    for p in (GP, PRIMES[0][0]):
+        d, d2 = 6000, 1500
+        a, b = splitmix_field(41, d, p), splitmix_field(42, d2, p)
+        da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        dq = torch.zeros(d, dtype=torch.int64, device="cuda"); dr = torch.zeros(d, dtype=torch.int64, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        s = torch.cuda.Stream()
+        # warm the workspace pool and the plan cache outside the capture
+        L.check(L.lib.ronk_poly_divrem_full_dev(p, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), s.cuda_stream))
+        s.synchronize()
+        oq, o_r = orc.poly_divrem(p, a, b)
+        assert int(status.item()) == 0 and np.array_equal(dq.cpu().numpy().view(np.uint64), oq) and np.array_equal(dr.cpu().numpy().view(np.uint64), o_r)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            st = torch.cuda.current_stream().cuda_stream
+            L.check(L.lib.ronk_poly_divrem_full_dev(p, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), st))
+        for rep in range(2):
+            a = splitmix_field(43 + rep, d, p)
+            da.copy_(torch.from_numpy(a.view(np.int64)))
+            oq, o_r = orc.poly_divrem(p, a, b)
+            dq.fill_(-1); dr.fill_(-1); status.fill_(9)
+            gr.replay()
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            assert np.array_equal(dq.cpu().numpy().view(np.uint64), oq) and np.array_equal(dr.cpu().numpy().view(np.uint64), o_r), (hex(p), rep)
+        del gr
+    # the probing form refuses a capture it could only serve with minutes of long division
+    d, d2 = 1 << 17, 1 << 16
+    a, b = splitmix_field(51, d), splitmix_field(52, d2)
+    da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    dq = torch.zeros(d, dtype=torch.int64, device="cuda"); dr = torch.zeros(d, dtype=torch.int64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s):
+        st = torch.cuda.current_stream().cuda_stream
+        rc = L.lib.ronk_poly_divrem_dev(GP, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), status.data_ptr(), st)
+    assert rc == L.ERR_UNSUPPORTED
+    del gr

@@ -257,9 +257,10 @@ def strip_tests(t):
 
 
 def vendor_field(t):
-    t = t.replace("use ronkathon::algebra::{\n  field::{Field, FiniteField},\n  Finite,\n};",
-                  "use crate::algebra::{\n  field::{Field, FiniteField},\n  Finite,\n};")
+    t = t.replace("use ronkathon::algebra::{\n  field::{Field, FieldExt, FiniteField},\n  Finite,\n};",
+                  "use crate::algebra::{\n  field::{Field, FieldExt, FiniteField},\n  Finite,\n};")
     t = replace_once(t, "use crate::ffi::P;\n", "pub mod ffi;\npub mod gpu;\n\nuse self::ffi::P;\n", "field.rs ffi import")
+    t = t.replace("crate::ffi::", "self::ffi::")   # the array forms of FieldExt (euler_criterion_many / sqrt_many)
     assert "ronkathon::" not in strip_tests(t)
     return strip_tests(t)
 
