@@ -67,7 +67,8 @@ KERNEL_SOURCES = ("ronkathon_amd/csrc/ntt_tile.h", "ronkathon_amd/csrc/gl64.h", 
                   "ronkathon_amd/csrc/tile_kernel_def.h", "ronkathon_amd/csrc/tile_cfg_table.h",
                   "ronkathon_amd/csrc/tile_kernels_half.hip", "ronkathon_amd/csrc/tile_kernels_feat.hip",
                   "ronkathon_amd/csrc/field_policy.h", "ronkathon_amd/csrc/mont64.h", "ronkathon_amd/csrc/tile_kernels_mont.hip",
-                  "ronkathon_amd/csrc/tile_kernels_mont_feat.hip")
+                  "ronkathon_amd/csrc/tile_kernels_mont_feat.hip", "ronkathon_amd/csrc/ntt_tile_wl.h",
+                  "ronkathon_amd/csrc/tile_kernels_wl.hip")
 VALU_PEAK_LANE_OPS = 52.5e12   # full-rate 32-bit VALU lane-instructions/s measured on MI355X (profiles/r01_instr_rate_gfx950.txt)
 
 
@@ -903,8 +904,11 @@ def main():
                 "rotate": R_cold,
                 "traffic": traffic,
                 "traffic_note": traffic_note,
-                "kernel": wl_kernel or "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n,
-                                                                                         plan.num_passes()),
+                "kernel": wl_kernel or (
+                    "ntt_tile_wl_col_kernel + ntt_tile_wl_row_kernel (2^11-row x 4-column passes, csrc/ntt_tile_wl.h), 2 launches per NTT"
+                    if (wl == "ntt22" and log2n == 22 and mode in ("many", "streams") and os.environ.get("RONK_WL", "1") != "0"
+                        and (mode == "many" or args.tile_logc == 2))
+                    else "ntt_tile_kernel<%d> x %d launches per NTT" % ((log2n + 1) // 2 if log2n > 12 else log2n, plan.num_passes())),
                 "algorithmic_bytes_per_step": alg_bytes_step, "device_us_per_step": step_s * 1e6,
                 "device_us_per_step_min": min(dev_ms_samples) * 1e3 / args.steps,
                 "note": "achieved / frac: the regime of `value` (%s) on the clock of ms_per_step (wall, median region); frac_device / "

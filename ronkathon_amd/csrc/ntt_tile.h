@@ -80,12 +80,6 @@ struct TileArgs {
   u32 stage_io;
   // the prime of a Montgomery pass (field_policy.h; p == 0: Goldilocks, nothing of it is read)
   FieldConst fc;
-  // Software prefetch of the NEXT input array (ronk_ntt_forward_many_dev: the caller handed over K arrays, so the library
-  // knows what a lane reads next): workgroup b touches one word in every 128-byte line of bytes [b * pf_wg_bytes,
-  // (b + 1) * pf_wg_bytes) of `pf` after its last store (tile_kernel_def.h tile_prefetch_tail), so that the HBM-cold input of
-  // the transform after this one is on its way into the Infinity Cache while this one computes.  nullptr = none.
-  const u64* pf = nullptr;
-  u32 pf_wg_bytes = 0;
 };
 
 // ---- compile-time helpers -------------------------------------------------------------

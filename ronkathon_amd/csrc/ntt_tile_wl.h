@@ -129,6 +129,16 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
   //   low words   the same
   //   high words  parked in the cells just read: region k2 >> 1, block l, slot 2w + (k2 & 1)   | barrier |  read from the own
   //               region, slot 2 j3 + g  (the writer of a cell is the one lane that read it: no barrier in between)
+  // (the matrix entries of the first two output chunks are requested BEFORE the barrier -- the kernels' barrier waits for LDS
+  // only, tile_kernels_wl.hip -- so that their trip to memory passes under the barrier wait and the exchange's LDS reads)
+  constexpr int SH = 3;   // NARROW byte offsets (KIND != 0)
+  const u32 kbase = l + 32 * w;
+  const u32 tf_lane = KIND == 3 ? (cx.col * a_in.tf_sc) << SH : 0, tf_sk = KIND == 3 ? a_in.tf_sk << SH : 0;
+  u64 wq[2][4];
+  auto fetch = [&](int q, u64* wv) {   // chunk q = (g, h): registers g*8 + 4h .. + 3
+#pragma unroll
+    for (int i = 0; i < 4; i++) wv[i] = ld_g<true>(a.tw_full, tf_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * tf_sk);
+  };
   {
     Dif<16, INV, true, FLD>::run(x, f);
     tb[0] = 0; tb[1] = w << 7;
@@ -141,6 +151,9 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
       if (k2) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k2]));
       if constexpr (FULL) img.put(own + k2 * 4, x[i]); else img.put_lo(own + k2 * 4, x[i]);
     }
+#ifndef RONK_WL_NO_PREFETCH   // (A/B builds: tools/build_variant.sh nopf -DRONK_WL_NO_PREFETCH)
+    if constexpr (KIND == 3 && FULL) { fetch(0, wq[0]); fetch(1, wq[1]); }
+#endif
     barrier();
     const u32 gat = l * WL_BLOCK + (2 * w) * 4 + c;
     if constexpr (FULL) {
@@ -169,24 +182,18 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
   }
   // ---- round 3 (over j3): wavefront p = w owns k2 in {2p, 2p+1}, lane k1 = l; register g*8 + j3.  Natural output row of
   // register (g, i): k = l + 16 (2 w + g) + 256 brev3(i): the 16 lanes of a column hold 16 consecutive rows.
-  constexpr int SH = 3;   // NARROW byte offsets (KIND != 0)
-  const u32 kbase = l + 32 * w;
   const u32 out_sk = cx.out_sk, out_lane = cx.out_lane;
   u64* __restrict__ const outp = cx.out;
   if constexpr (KIND == 3) {
-    // (the strides of the launch, not those tile_ctx folds in: the matrix may be transposed -- [col][k], plan.h twf_transposed --
-    // and then the 16 lanes of a column read 128 consecutive bytes)
-    const u32 tf_lane = (cx.col * a_in.tf_sc) << SH, tf_sk = a_in.tf_sk << SH;
-    // The matrix entries travel in chunks of four, two chunks in flight: chunk q + 2 is fetched before the stores of chunk q are
-    // issued (one in-order vmcnt for loads and stores: a load behind a store waits for the store's whole trip).
-    // chunk q = (g, h): registers g*8 + 4h .. + 3
-    u64 wq[2][4];
-    auto fetch = [&](int q, u64* wv) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) wv[i] = ld_g<true>(a.tw_full, tf_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * tf_sk);
-    };
-    fetch(0, wq[0]);
-    fetch(1, wq[1]);
+    // (tf_lane / tf_sk above are the strides of the LAUNCH, not those tile_ctx folds in: the matrix may be transposed -- [col][k],
+    // plan.h twf_transposed.)  The matrix entries travel in chunks of four, two chunks in flight: chunk q + 2 is fetched before
+    // the stores of chunk q are issued (one in-order vmcnt for loads and stores: a load behind a store waits for the store's
+    // whole trip).
+#ifndef RONK_WL_NO_PREFETCH
+    if constexpr (!FULL) { fetch(0, wq[0]); fetch(1, wq[1]); }
+#else
+    fetch(0, wq[0]); fetch(1, wq[1]);
+#endif
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       u64* xq = x + 4 * q;

@@ -325,15 +325,12 @@ static int many_dev(ronk_plan* pl, bool inverse, const uint64_t* const* d_in, ui
   HIPCHK(hipEventRecord(pl->ev_fork, s));
   HIPCHK(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
   int rc = RONK_OK;
-  // RONK_PF: software prefetch of the array a lane transforms next (TileArgs::pf): 0 = off, 1 = from the first pass, 2 = from
-  // the last pass of the transform before it on the same lane; RONK_PF_DIST = how many arrays ahead (2 = the lane's next one)
-  static const int pf_mode = [] { const char* e = getenv("RONK_PF"); return e ? atoi(e) : 0; }();
-  static const size_t pf_dist = [] { const char* e = getenv("RONK_PF_DIST"); int v = e ? atoi(e) : 2; return (size_t)(v < 1 ? 1 : v); }();
+  // (Round 6 measured a software prefetch of the array a lane transforms next -- one 4-byte load per 128-byte line as the last
+  //  instructions of a pass -- and removed it: 7 % slower, the same bytes moved earlier cost more than the warm input saves;
+  //  profiles/r06_occupancy_ab.txt.)
   for (size_t i = 0; i < count && !rc; i++) {
     const bool lane1 = (i & 1) != 0;
-    const u64* pf = (pf_mode && i + pf_dist < count) ? d_in[i + pf_dist] : nullptr;
-    rc = cp->run(d_in[i], nullptr, d_out[i], lane1 ? pl->d_tmp2 : pl->d_tmp, lane1 ? pl->side : s, ~(u64)0, ~(u64)0, 0, 0, ~(u64)0, pf,
-                 pf_mode == 2 ? -1 : 0);
+    rc = cp->run(d_in[i], nullptr, d_out[i], lane1 ? pl->d_tmp2 : pl->d_tmp, lane1 ? pl->side : s);
   }
   hipError_t e = hipEventRecord(pl->ev_join, pl->side);
   if (e == hipSuccess) e = hipStreamWaitEvent(s, pl->ev_join, 0);

@@ -143,10 +143,9 @@ struct CompiledPlan {
     if (ps.twf_id >= 0) a.tw_full = d_twf[ps.twf_id];
     return a;
   }
-  // pf: the input array the caller's lane transforms next (TileArgs::pf; many_dev), attached to ONE pass of this transform
   int launch(size_t idx, const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
              u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u32 sb0 = 0, u32 sbn = 0,
-             u64 in_valid1 = ~(u64)0, const u64* pf = nullptr) const {
+             u64 in_valid1 = ~(u64)0) const {
     const PassDesc& ps = pd.passes[idx];
     TileArgs a = ps.args;
     const u64* bufs_in[3] = {in, out, tmp};
@@ -175,10 +174,6 @@ struct CompiledPlan {
       // a slice that starts past polynomial 0 sees its first polynomial as b1 = 0: its padding limit is the one of b1 >= 1
       if (sb0 >= 1 && ps.in_buf == BUF_IN && in_valid1 != ~(u64)0) a.in_valid = in_valid1;
     }
-    if (pf && grid) {   // every workgroup one slice; a slice that one sweep of the workgroup's lanes cannot cover is not prefetched
-      const u64 bytes = ((u64)pd.batch << pd.log2n) * 8, per = bytes / grid;
-      if (per * grid == bytes && per % 128 == 0 && per <= (u64)ps.block * 128) { a.pf = pf; a.pf_wg_bytes = (u32)per; }
-    }
     hipError_t e = ps.small ? launch_small(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s)
                             : launch_tile(ps.logr, pd.inverse, a, grid, ps.block, ps.lds_bytes, s);
     if (e != hipSuccess) return hip_fail(e, "launch_tile");
@@ -188,10 +183,8 @@ struct CompiledPlan {
   // scratch a slice writes in one pass is read back by the next pass while it is still in the 256 MB Infinity Cache,
   // instead of streaming the whole batch (512 MiB for 1024 x 2^16) through HBM between the passes.
   // RONK_SUB_BATCH_MIB: slice size in MiB of coefficients (0 = off).
-  // pf_next / pf_pass: prefetch `pf_next` from pass pf_pass (0-based; -1 = the last pass)
   int run(const u64* in, const u64* in2, u64* out, u64* tmp, hipStream_t s, u64 in_valid = ~(u64)0,
-          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u64 in_valid1 = ~(u64)0,
-          const u64* pf_next = nullptr, int pf_pass = 0) const {
+          u64 out_valid = ~(u64)0, u64 in_poly_stride = 0, u64 x0_add = 0, u64 in_valid1 = ~(u64)0) const {
     static const long slice_mib = [] { const char* e = getenv("RONK_SUB_BATCH_MIB"); return e ? atol(e) : 0L; }();
     const u64 n = (u64)1 << pd.log2n;
     if (slice_mib > 0 && pd.passes.size() >= 2 && pd.batch > 1) {
@@ -208,9 +201,8 @@ struct CompiledPlan {
         return RONK_OK;
       }
     }
-    const size_t pfi = pf_pass < 0 ? pd.passes.size() - 1 : (size_t)pf_pass;
     for (size_t i = 0; i < pd.passes.size(); i++)
-      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, 0, 0, in_valid1, i == pfi ? pf_next : nullptr));
+      RCHK(launch(i, in, in2, out, tmp, s, in_valid, out_valid, in_poly_stride, x0_add, 0, 0, in_valid1));
     return RONK_OK;
   }
   // every pass of the plan for polynomials [sb0, sb0 + sbn) of the batch only (multi-pass plans whose batch axis is b1)

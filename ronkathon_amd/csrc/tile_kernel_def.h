@@ -8,20 +8,6 @@
 
 namespace ronk {
 
-// TileArgs::pf: one 4-byte non-temporal load per 128-byte line of this workgroup's slice of the next input array, issued as the
-// LAST instructions of the kernel: nothing waits for them (the wavefront ends with the loads in flight, like it does with its
-// stores), no live register can be clobbered by the returning data, and no earlier vmcnt wait includes them.
-__device__ __forceinline__ void tile_prefetch_tail(const TileArgs& a, u32 bid) {
-  if (!a.pf) return;
-  const u32 off = threadIdx.x * 128u;
-  if (off < a.pf_wg_bytes) {
-    const char* q = reinterpret_cast<const char*>(a.pf) + (size_t)bid * a.pf_wg_bytes + off;
-    u32 sink;
-    asm volatile("" ::: "memory");
-    asm volatile("global_load_dword %0, %1, off nt" : "=v"(sink) : "v"(q) : "memory");
-  }
-}
-
 // Workgroup = 2^LOGR * C / 16 work-items (<= 1024), dynamic LDS = (2^LOGR + 2^LOGR/16) * C * 8 bytes (<= 136 KiB of the
 // CU's 160 KiB).
 template <int LOGR, bool INV, int LOGC, int KIND, bool HALF, int FEAT = 0, class FLD = GlField>
@@ -33,7 +19,6 @@ __device__ __forceinline__ void tile_kernel_main(const TileArgs& a, u64* lds) {
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   tile_body<LOGR, INV, 0, TileCfg<LOGC, KIND, !HALF && !FEAT && !FLD::MONT && cfg_ldstw(LOGR, LOGC, KIND), HALF, FEAT>, FLD>(a, lds, threadIdx.x, bid, [] { __syncthreads(); });
-  tile_prefetch_tail(a, bid);
 }
 
 // the shapes with features (tile_cfg_table.h RONK_CFG_TABLE_FEAT; tile_kernels_feat.hip)

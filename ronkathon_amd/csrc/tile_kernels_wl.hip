@@ -11,12 +11,19 @@
 
 namespace ronk {
 
+#ifdef RONK_WL_NO_PREFETCH
+#define RONK_WL_BARRIER __syncthreads()
+#else
+#define RONK_WL_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 #define RONK_WL_PROLOGUE(FULL)                                                                 \
   __shared__ __attribute__((aligned(16))) u32 l32[8 * WL_REGION * ((FULL) ? 2 : 1)];           \
   const u32 nb = gridDim.x, b = blockIdx.x;                                                    \
   const u32 q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;                                \
   const u32 bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;               \
-  auto bar = [] { __syncthreads(); };                                                          \
+  /* the exchanges need the workgroup's LDS traffic ordered, nothing else: __syncthreads() would also drain the global loads   \
+     in flight (the matrix entries requested ahead of the barrier, ntt_tile_wl.h) */                                            \
+  auto bar = [] { RONK_WL_BARRIER; };                                                          \
   auto wsync = [] {                                                                            \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                     \
     __builtin_amdgcn_wave_barrier();                                                           \
@@ -28,13 +35,11 @@ template <bool INV, int KIND, bool FULL, class FLD>
 __global__ void __launch_bounds__(WL_THREADS, FULL ? 4 : 6) ntt_tile_wl_col_kernel(const TileArgs a) {
   RONK_WL_PROLOGUE(FULL)
   tile_body_wl_col<INV, KIND, FULL, FLD>(a, l32, threadIdx.x, bid, bar, wsync);
-  tile_prefetch_tail(a, bid);
 }
 template <bool INV, bool FULL, class FLD>
 __global__ void __launch_bounds__(WL_THREADS, FULL ? 4 : 6) ntt_tile_wl_row_kernel(const TileArgs a) {
   RONK_WL_PROLOGUE(FULL)
   tile_body_wl_row<INV, FULL, FLD>(a, l32, threadIdx.x, bid, bar, wsync);
-  tile_prefetch_tail(a, bid);
 }
 
 // experiments with the half image: RONK_WL_PAD = bytes of (unused) dynamic LDS per workgroup, to bound the workgroups per CU

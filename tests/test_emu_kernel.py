@@ -16,7 +16,7 @@ def emu():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "emu", "emu_tile.cpp")]
     deps = srcs + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("ntt_tile.h", "ntt_small.h", "ntt_mul.h", "plan.h", "gl64.h", "tile_cfg_table.h",
-                                                                                  "field_policy.h", "mont64.h")]
+                                                                                  "field_policy.h", "mont64.h", "ntt_tile_wl.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
         subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
@@ -99,6 +99,28 @@ def test_tuned_tile_widths(emu, k, logc):
     run(emu, k, 1, (k + logc) & 1, logc, 0, 23)
 
 
+@pytest.mark.parametrize("env", [{}, {"RONK_WL_HALF": "1"}, {"RONK_WL": "0"}, {"RONK_WL": "2"}, {"RONK_WL": "3"}, {"RONK_TWF_T": "1"}])
+@pytest.mark.parametrize("k,inv,twf", [(22, 0, 22), (22, 1, 18), (21, 1, 21), (23, 0, 0)])
+def test_wave_local_tile_bodies(emu, env, k, inv, twf):
+    """ntt_tile_wl.h -- the 2^11-row x 4-column column / row passes with one wave-local and one cross-wave exchange (round 6; the
+    library's default for these shapes): FULL image (one barrier per pass) and the half image (two 32-bit phases, two barriers),
+    forward / inverse, two-level tables / full matrix (also transposed, RONK_TWF_T), one pass at a time mixed with ntt_tile.h's
+    kernels (RONK_WL = 2 / 3), and RONK_WL=0 -- the same plans on the old kernels; 2^23 is the two-pass 2^12 x 2^11 plan whose
+    row pass has 2^11 rows.  The fibers run one after the other, so a missing barrier / wave_sync between dependent LDS accesses
+    shows up as a mismatch."""
+    out = run(emu, k, 1, inv, 2, twf, 24, env=env)
+    kernels = [l.split("kernel=")[1] for l in out.strip().splitlines() if l.startswith("pass")]
+    wl = env.get("RONK_WL", "1")
+    want_col = k in (21, 22) and wl in ("1", "2")     # the column pass has 2^11 rows at 2^21 / 2^22, the row pass at 2^22 / 2^23
+    want_row = k in (22, 23) and wl in ("1", "3")
+    assert kernels[0].startswith("wl:column") == want_col and kernels[1].startswith("wl:row") == want_row, out
+    # the same bodies over a Montgomery prime (FULL image)
+    if not env and k == 22:
+        p, g = MONT_PRIMES[0]
+        out = run(emu, k, 1, inv, 2, twf, 24, env=mont_env(p, g))
+        assert "kernel=wl:column" in out and "kernel=wl:row" in out
+
+
 @pytest.mark.parametrize("k,d,d2,logc,twf", [(20, 1 << 19, 1 << 19, 2, 18), (20, 300001, 7, 2, 20), (20, 1, 1 << 20, 2, 18),
                                              (22, 1 << 21, 1 << 21, 2, 18), (22, (1 << 21) + 5, (1 << 21) - 4, 2, 22),
                                              (21, 1 << 20, 1 << 20, 2, 18), (21, 700001, 900000, 2, 21),
@@ -113,7 +135,7 @@ def test_fused_multiply_middle(emu, k, d, d2, logc, twf):
 def test_specialised_kernels_are_selected_and_generic_bodies_still_match(emu):
     """the hot two-pass shapes run the compile-time-specialised bodies (tile_cfg_table.h; same selection rule as
     tile_kernels.hip); with RONK_NO_CFG_KERNELS the generic body computes the same plans"""
-    for args, kinds in (((22, 1, 0, 4), ("cfg:column/two-level", "cfg:row")), ((22, 1, 1, 2), ("cfg:column/two-level", "cfg:row")),
+    for args, kinds in (((22, 1, 0, 4), ("cfg:column/two-level", "cfg:row")), ((22, 1, 1, 2), ("wl:column/two-level", "wl:row")),
                         ((16, 3, 0, 4, 18), ("cfg:column/matrix", "cfg:row")), ((18, 1, 1, 4, 18), ("cfg:column/matrix", "cfg:row"))):
         out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
         lines = out.stdout.strip().splitlines()
@@ -179,7 +201,7 @@ def test_half_lds_exchange(emu, args):
     """TileCfg::HALF (RONK_HALF_LDS=1: exchanges between rounds as two 32-bit phases through a half-size LDS image): the
     specialised two- and three-round bodies compute the same plans; a missing barrier between the phases shows up here
     because the fibers run one after the other"""
-    env = dict(os.environ, RONK_HALF_LDS="1")
+    env = dict(os.environ, RONK_HALF_LDS="1", RONK_WL="0")   # (the 2^11-row x 4-column passes: ntt_tile.h's kernels, not ntt_tile_wl.h's)
     out = subprocess.run([emu] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1].startswith("OK"), out.stdout[-400:]
@@ -240,7 +262,7 @@ def test_planner_narrows_tiles_until_every_cu_has_one(emu, k, batch, want_tiles)
     for l in passes:
         f = dict(t.split("=") for t in l.split()[1:])
         assert int(f["tiles"]) == want_tiles and int(f["grid"]) == want_tiles * batch, l
-        assert f["kernel"].startswith("cfg:"), l
+        assert f["kernel"].startswith("cfg:") or f["kernel"].startswith("wl:"), l
 
 
 @pytest.mark.parametrize("args", [(14, 2, 0, 4, 18, 25, 3000, 0, 1, 5000), (20, 2, 0, 2, 18, 25, 300000, 0, 0, 700001),
@@ -266,7 +288,7 @@ def test_three_pass_plans_run_the_specialised_bodies(emu, k, dirs):
 
 @pytest.mark.parametrize("args,kinds", [
     ((20, 2, 0, 2, 18, 25, 300000, 0, 0, 700001), ("feat:column/two-level", "cfg:row")),          # multiply: both operands, zero padded
-    ((22, 2, 0, 2, 18, 25, 2097152, 0, 0, 2097152), ("feat:column/two-level", "cfg:row")),
+    ((22, 2, 0, 2, 18, 25, 2097152, 0, 0, 2097152), ("feat:column/two-level", "wl:row")),
     ((20, 1, 1, 4, 18, 25, 0, 1000001, 1, 0, 1), ("feat:column/two-level", "feat:row")),            # its inverse: fused product in, truncated out
     ((21, 1, 1, 4, 18, 25, 0, 2097151, 1, 0, 1), ("feat:column/two-level", "feat:row")),
     ((22, 1, 1, 4, 18, 25, 0, 4194303, 1, 0, 1), ("feat:column/two-level", "feat:row")),
@@ -283,8 +305,8 @@ def test_feature_kernels(emu, args, kinds):
 
 @pytest.mark.parametrize("args,kinds", [
     ((22, 1, 0, 4, 22, 25, 0, 0, 1), ("cfg:column/matrix", "cfg:row")),                        # the library default at 2^22 / 2^21
-    ((21, 1, 1, 4, 21, 25, 0, 0, 1), ("cfg:column/matrix", "cfg:row")),
-    ((22, 2, 0, 2, 22, 25, 2097152, 0, 0, 2097152), ("feat:column/matrix", "cfg:row")),        # ... and the multiply on it
+    ((21, 1, 1, 4, 21, 25, 0, 0, 1), ("wl:column/matrix", "cfg:row")),                         # (narrowed to 4-column tiles: ntt_tile_wl.h)
+    ((22, 2, 0, 2, 22, 25, 2097152, 0, 0, 2097152), ("feat:column/matrix", "wl:row")),         # ... and the multiply on it
     ((22, 1, 1, 4, 22, 25, 0, 4194303, 1, 0, 1), ("feat:column/matrix", "feat:row")),
     ((21, 1, 1, 4, 21, 25, 0, 2097151, 1, 0, 1), ("feat:column/matrix", "feat:row")),
 ])
