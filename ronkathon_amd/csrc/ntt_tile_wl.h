@@ -1,7 +1,8 @@
-// ntt_tile_wl.h -- the 2^11-row x 4-column tile passes of the two-pass plans (2^21 .. 2^23: the headline 2^22 among them) with
-// ONE wave-local and ONE cross-wave LDS exchange per pass: one workgroup barrier per pass (FULL image) instead of three.
+// ntt_tile_wl.h -- the 2^10 / 2^11 / 2^12-row x 4-column tile passes of the two-pass plans (2^20 .. 2^24: the headline 2^22 among
+// them) with ONE wave-local and ONE cross-wave LDS exchange per pass: one workgroup barrier per pass (FULL image) instead of three.
 //
-// With rows j = 128 j1 + 8 j2 + j3 (digits of the rounds 16, 16, 8) the 16 partners of an exchange always share a column and
+// Written out for 2^11 rows (RL = 8; 2^10: RL = 4, 2^12: RL = 16 -- the radix of the last round = the wavefronts of a workgroup):
+// with rows j = 128 j1 + 8 j2 + j3 (digits of the rounds 16, 16, 8) the 16 partners of an exchange always share a column and
 // one more digit; ntt_tile.h numbers a column's lanes m = 8 j2 + j3 for every round, so both exchanges cross the wavefronts
 // (write / barrier / read / barrier, twice).  Here
 //   column pass (tile_body_wl_col): wavefront = j3 for rounds 1-2, so the exchange behind round 1 stays inside a wavefront (no
@@ -39,21 +40,23 @@
 
 namespace ronk {
 
-constexpr int WL_LOGR = 11, WL_LOGC = 2;
+constexpr int WL_LOGC = 2;
 constexpr u32 WL_BLOCK = 68, WL_REGION = 16 * WL_BLOCK + 4;   // cells; 1092
-constexpr u32 WL_THREADS = 512;
-constexpr size_t wl_lds_bytes(bool full) { return (size_t)8 * WL_REGION * (full ? 8 : 4); }
+constexpr bool wl_logr_ok(int logr) { return logr >= 10 && logr <= 12; }
+constexpr u32 wl_waves(int logr) { return 1u << (logr - 8); }                 // = RL, the radix of the last round
+constexpr u32 wl_threads(int logr) { return 64u * wl_waves(logr); }
+constexpr size_t wl_lds_bytes(int logr, bool full) { return (size_t)wl_waves(logr) * WL_REGION * (full ? 8 : 4); }
 
 // the full twiddle matrix may be laid out transposed, [col][k] (plan.h twf_transposed): tf_sc = R, tf_sk = 1
-inline bool tile_wl_twf_transposed(const TileArgs& a) { return a.tw_full && a.tf_sk == 1 && a.tf_sc == (1u << WL_LOGR); }
+inline bool tile_wl_twf_transposed(const TileArgs& a, int logr) { return a.tw_full && a.tf_sk == 1 && a.tf_sc == (1u << logr); }
 inline bool tile_wl_matches(const TileArgs& a, int logr, int kind) {
-  if (logr != WL_LOGR || !(kind == 1 || kind == 2 || kind == 3)) return false;
-  if (kind == 3 && tile_wl_twf_transposed(a)) {
+  if (!wl_logr_ok(logr) || !(kind == 1 || kind == 2 || kind == 3)) return false;
+  if (kind == 3 && tile_wl_twf_transposed(a, logr)) {
     TileArgs b = a;
     b.tf_sc = 1; b.tf_sk = (u32)a.ncols;   // what tile_cfg_matches knows as the matrix of a column pass
-    return a.logc == (u32)WL_LOGC && a.tf_sb2 == 0 && tile_cfg_matches(b, WL_LOGR, WL_LOGC, 3, 0);
+    return a.logc == (u32)WL_LOGC && a.tf_sb2 == 0 && tile_cfg_matches(b, logr, WL_LOGC, 3, 0);
   }
-  return tile_cfg_matches(a, WL_LOGR, WL_LOGC, kind, 0);
+  return tile_cfg_matches(a, logr, WL_LOGC, kind, 0);
 }
 
 // One LDS cell of the image: 8-byte cells (FULL) or the low / high word of a coefficient in a 4-byte cell
@@ -70,21 +73,22 @@ struct WlImage {
 // execute in order, so it is a compiler fence only; the host emulator (one fiber per lane) passes its barrier.
 
 // ---- column pass: wavefront = j3 ----------------------------------------------------------------------------------
-template <bool INV, int KIND, bool FULL, class FLD = GlField, class Barrier, class WaveSync>
+template <int LOGR, bool INV, int KIND, bool FULL, class FLD = GlField, class Barrier, class WaveSync>
 RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, Barrier&& barrier, WaveSync&& wave_sync) {
   static_assert(KIND == 1 || KIND == 3, "column pass");
-  constexpr int LOGR = WL_LOGR;
+  static_assert(wl_logr_ok(LOGR) && (FULL || LOGR == 11), "2^10 .. 2^12 rows; the half image is written for 2^11");
+  constexpr int LOGL = LOGR - 8, RL = 1 << LOGL, G = 16 / RL;   // last-round radix = wavefronts; groups per lane in the last round
   typedef TileCfg<WL_LOGC, KIND> CFG;
   const WlImage img{l32};
   const u32 c = tid & 3, l = (tid >> 2) & 15, w = wave_uniform(tid >> 6);   // column, lane digit, wavefront (a scalar)
-  // rounds 1-2: j3 = w, j2 (then k1) = l.  ntt_tile.h's lane index of the same coefficients: m = 8 j2 + j3
-  const u32 m_old = l * 8 + w;
+  // rounds 1-2: j3 = w, j2 (then k1) = l.  ntt_tile.h's lane index of the same coefficients: m = RL j2 + j3
+  const u32 m_old = l * RL + w;
   const TileCtx cx = tile_ctx<LOGR, CFG>(a_in, m_old * 4 + c, bid);
   const TileArgs& a = cx.a;
   const FLD f(a.fc);
   u64 x[16];
-  {   // x[j1] = row 128 j1 + 8 j2 + j3 (flat rows, as tile_load for KIND 1 / 3)
-    const u32 j0 = cx.in_lane + m_old * cx.in_sj, step = 128 * cx.in_sj;
+  {   // x[j1] = row 16 RL j1 + RL j2 + j3 (flat rows, as tile_load for KIND 1 / 3)
+    const u32 j0 = cx.in_lane + m_old * cx.in_sj, step = (16 * RL) * cx.in_sj;
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = ld_g<true>(cx.in, j0 + i * step);
   }
@@ -132,12 +136,14 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
   // (the matrix entries of the first two output chunks are requested BEFORE the barrier -- the kernels' barrier waits for LDS
   // only, tile_kernels_wl.hip -- so that their trip to memory passes under the barrier wait and the exchange's LDS reads)
   constexpr int SH = 3;   // NARROW byte offsets (KIND != 0)
-  const u32 kbase = l + 32 * w;
+  // natural output row of register r = g RL + i of the last round: k = k1 + 16 k2 + 256 k3 = l + 16 (G w + g) + 256 brev(i)
+  const u32 kbase = l + 16 * G * w;
+  auto krow = [](int r) -> u32 { return (u32)(16 * (r / RL) + 256 * brev(r % RL, LOGL)); };
   const u32 tf_lane = KIND == 3 ? (cx.col * a_in.tf_sc) << SH : 0, tf_sk = KIND == 3 ? a_in.tf_sk << SH : 0;
   u64 wq[2][4];
-  auto fetch = [&](int q, u64* wv) {   // chunk q = (g, h): registers g*8 + 4h .. + 3
+  auto fetch = [&](int q, u64* wv) {   // chunk q: registers 4 q .. 4 q + 3
 #pragma unroll
-    for (int i = 0; i < 4; i++) wv[i] = ld_g<true>(a.tw_full, tf_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * tf_sk);
+    for (int i = 0; i < 4; i++) wv[i] = ld_g<true>(a.tw_full, tf_lane + (kbase + krow(4 * q + i)) * tf_sk);
   };
   {
     Dif<16, INV, true, FLD>::run(x, f);
@@ -155,12 +161,12 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
     if constexpr (KIND == 3 && FULL) { fetch(0, wq[0]); fetch(1, wq[1]); }
 #endif
     barrier();
-    const u32 gat = l * WL_BLOCK + (2 * w) * 4 + c;
+    const u32 gat = l * WL_BLOCK + (G * w) * 4 + c;
     if constexpr (FULL) {
 #pragma unroll
-      for (int g = 0; g < 2; g++)
+      for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[g * 8 + j] = img.get(gat + j * WL_REGION + g * 4);
+        for (int j = 0; j < RL; j++) x[g * RL + j] = img.get(gat + j * WL_REGION + g * 4);
     } else {
       u32 lo[16];
 #pragma unroll
@@ -197,12 +203,14 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       u64* xq = x + 4 * q;
-      if ((q & 1) == 0) Dif<8, INV, true, FLD>::run(xq, f, false);
+      if ((4 * q) % RL == 0) {   // a group's sub-transform runs when its first chunk comes up (RL = 4: every chunk is a group)
+        Dif<RL, INV, true, FLD>::run(x + (4 * q / RL) * RL, f, false);
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++) xq[i] = f.mul(xq[i], wq[q & 1][i]);
       if (q + 2 < 4) fetch(q + 2, wq[q & 1]);
 #pragma unroll
-      for (int i = 0; i < 4; i++) st_g<true>(outp, out_lane + (kbase + 16 * (q >> 1) + 256 * brev(4 * (q & 1) + i, 3)) * out_sk, xq[i]);
+      for (int i = 0; i < 4; i++) st_g<true>(outp, out_lane + (kbase + krow(4 * q + i)) * out_sk, xq[i]);
     }
   } else {
     // two-level inter-pass twiddle omega_N^{col * k}: exponents pre-scaled by 8 (byte offsets), add chain over i
@@ -210,107 +218,114 @@ RONK_HD void tile_body_wl_col(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
     const u32 lmask8 = ((1u << a.tw_lo_bits) - 1) << 3, hmask8 = (nmask >> a.tw_lo_bits) << 3;
     const u32 twX = cx.col;
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-      u64* xg = x + g * 8;
-      Dif<8, INV, true, FLD>::run(xg, f, false);
-      u32 ej[8];
+    for (int g = 0; g < G; g++) {
+      u64* xg = x + g * RL;
+      Dif<RL, INV, true, FLD>::run(xg, f, false);
+      u32 ej[RL];
       ej[0] = (twX * (kbase + 16 * g)) << 3;
       const u32 estep = (twX * 256u) << 3;
 #pragma unroll
-      for (int j = 1; j < 8; j++) ej[j] = ej[j - 1] + estep;
+      for (int j = 1; j < RL; j++) ej[j] = ej[j - 1] + estep;
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const u32 ee = ej[brev(i, 3)];
+      for (int i = 0; i < RL; i++) {
+        const u32 ee = ej[brev(i, LOGL)];
         const u64 tw = f.mul(ld_tabb(a.tw_lo, ee & lmask8), ld_tabb(a.tw_hi, (ee >> a.tw_lo_bits) & hmask8));
         xg[i] = f.mul(xg[i], tw);
       }
 #pragma unroll
-      for (int i = 0; i < 8; i++) st_g<true>(outp, out_lane + (kbase + 16 * g + 256 * brev(i, 3)) * out_sk, xg[i]);
+      for (int i = 0; i < RL; i++) st_g<true>(outp, out_lane + (kbase + 16 * g + 256 * brev(i, LOGL)) * out_sk, xg[i]);
     }
   }
 }
 
-// ---- row pass: lanes along the tile as in ntt_tile.h, wavefront = k1 pair from round 2 on -----------------------------
-template <bool INV, bool FULL, class FLD = GlField, class Barrier, class WaveSync>
+// ---- row pass: lanes along the tile as in ntt_tile.h, wavefront = k1 group from round 2 on -----------------------------
+template <int LOGR, bool INV, bool FULL, class FLD = GlField, class Barrier, class WaveSync>
 RONK_HD void tile_body_wl_row(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, Barrier&& barrier, WaveSync&& wave_sync) {
-  constexpr int LOGR = WL_LOGR;
+  static_assert(wl_logr_ok(LOGR) && (FULL || LOGR == 11), "2^10 .. 2^12 rows; the half image is written for 2^11");
+  constexpr int LOGL = LOGR - 8, RL = 1 << LOGL, G = 16 / RL;   // last-round radix = wavefronts; j2 values / k1 values per wavefront
   typedef TileCfg<WL_LOGC, 2> CFG;
   const WlImage img{l32};
   const u32 c = tid & 3, l = (tid >> 2) & 15, w = wave_uniform(tid >> 6);
-  const u32 m = tid >> 2;                 // 16 w + l = 8 j2 + j3
-  const u32 e = l >> 3, j3 = l & 7;       // j2 = 2 w + e
+  const u32 m = tid >> 2;                       // 16 w + l = RL j2 + j3
+  const u32 e = l >> LOGL, j3 = l & (RL - 1);   // j2 = G w + e
   const TileCtx cx = tile_ctx<LOGR, CFG>(a_in, tid, bid);
   const TileArgs& a = cx.a;
   const FLD f(a.fc);
   u64 x[16];
-  {   // x[j1] = row 128 j1 + m of the tiled scratch (blocked rows, as tile_load for KIND 2)
+  {   // x[j1] = row 16 RL j1 + m of the tiled scratch (blocked rows, as tile_load for KIND 2)
     const u32 hi = (u32)a.in_sj_hi << 3, jmask = (1u << a.js_log) - 1;
-    const u32 j0 = cx.in_lane + (m >> a.js_log) * hi + (m & jmask) * cx.in_sj, step = (128u >> a.js_log) * hi;
+    const u32 j0 = cx.in_lane + (m >> a.js_log) * hi + (m & jmask) * cx.in_sj, step = ((u32)(16 * RL) >> a.js_log) * hi;
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = ld_g<true>(cx.in, j0 + i * step);
   }
 
-  // ---- round 1 (over j1), twiddle omega_R^{m k1}.  Exchange 1 crosses the wavefronts: k1 = 2 q + s goes to wavefront q,
-  // lane (s, j3), register j2.
-  //   FULL        scattered to region q, block 8 s + j3, slot j2 = 2 w + e   | barrier |  read from the own region, block l
-  //   low words   the same
-  //   high words  parked in the cells just read (own region, block l, slot k1)   | barrier |  gathered from region j2 >> 1,
-  //               block 8 (j2 & 1) + j3, slot 2 w + e
+  // ---- round 1 (over j1), twiddle omega_R^{m k1}.  Exchange 1 crosses the wavefronts: k1 = G q + s goes to wavefront q,
+  // lane (s, j3) = block RL s + j3, register j2; the slot of j2 = G w + e is w + RL e (e-major: the half-wavefront that varies e
+  // and j3 together -- RL = 4 -- still covers 32 distinct banks).
+  //   FULL        scattered to region q, block RL s + j3, slot w + RL e      | barrier |  read from the own region, block l
+  //   low words   the same (2^11 rows: RL = 8, G = 2)
+  //   high words  parked in the cells just read (own region, block l, slot k1)   | barrier |  gathered from region j2's
+  //               wavefront, block of (j2's e, j3), slot of (w, e)
   Dif<16, INV, true, FLD>::run(x, f);
   u32 tb[16];
   tb[0] = 0; tb[1] = m << 3;
 #pragma unroll
   for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
   const u32 own = w * WL_REGION + l * WL_BLOCK + c;
-  const u32 far = j3 * WL_BLOCK + (2 * w + e) * 4 + c;
+  const u32 far = j3 * WL_BLOCK + (w + RL * e) * 4 + c;
   {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const u32 k1 = brev(i, 4);
       if (k1) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k1]));
-      const u32 cell = far + (k1 >> 1) * WL_REGION + (k1 & 1) * (8 * WL_BLOCK);
+      const u32 cell = far + (k1 / G) * WL_REGION + (k1 % G) * (RL * WL_BLOCK);
       if constexpr (FULL) img.put(cell, x[i]); else img.put_lo(cell, x[i]);
     }
     barrier();
+    // register j2 = G w' + e' sits in slot w' + RL e'
     if constexpr (FULL) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = img.get(own + j * 4);
+      for (int j = 0; j < 16; j++) x[j] = img.get(own + ((j / G) + RL * (j % G)) * 4);
     } else {
       u32 lo[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) lo[j] = img.get32(own + j * 4);
+      for (int j = 0; j < 16; j++) lo[j] = img.get32(own + ((j / G) + RL * (j % G)) * 4);
       wave_sync();
+      // (the lane writes the 16 cells it has just read: high word of register k1 into the slot numbered k1)
 #pragma unroll
       for (int i = 0; i < 16; i++) img.put_hi(own + (u32)brev(i, 4) * 4, x[i]);
       barrier();
+      // element (k1 = G w + e of this lane; j2 = G w' + e') was parked by lane (wavefront w', e', j3) = region w', block RL e' + j3,
+      // in the slot numbered k1
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = ((u64)img.get32(far + (j >> 1) * WL_REGION + (j & 1) * (8 * WL_BLOCK)) << 32) | lo[j];
+      for (int j = 0; j < 16; j++)
+        x[j] = ((u64)img.get32((j / G) * WL_REGION + ((j % G) * RL + j3) * WL_BLOCK + (G * w + e) * 4 + c) << 32) | lo[j];
     }
     wave_sync();
   }
-  // ---- round 2 (over j2): lane (k1 = 2 w + e, j3); twiddle omega_R^{16 j3 k2}.  Exchange 2 stays inside the wavefront.
-  //   FULL   after exchange 1 the wavefront's own region is read by nobody else: element (s = e, j3, k2 = 8 g + u) goes to block
-  //          8 s + u, slot 8 g + j3, and lane (s, u) of round 3 reads its block: slot 8 g + j3'
-  //   halves through the cells the wavefront alone has just read (slots 2 w, 2 w + 1 of every block of every region): element
-  //          (s = e, j3, k2) at region j3, block k2, slot 2 w + s; lane (s, u) reads k2 = 8 g + u, i.e. region j3', block 8 g + u
+  // ---- round 2 (over j2): lane (k1 = G w + e, j3); twiddle omega_R^{16 j3 k2}.  Exchange 2 stays inside the wavefront.
+  //   FULL   after exchange 1 the wavefront's own region is read by nobody else: element (s = e, j3, k2 = RL g + u) goes to block
+  //          RL s + u, slot RL g + j3, and lane (s, u) of round 3 reads its block: slot RL g + j3'
+  //   halves (2^11 rows) through the cells the wavefront alone has just read (slots 2 w, 2 w + 1 of every block of every region):
+  //          element (s = e, j3, k2) at region j3, block k2, slot 2 w + s; lane (s, u) reads k2 = 8 g + u: region j3', block 8 g + u
   {
     Dif<16, INV, true, FLD>::run(x, f);
     tb[1] = j3 << 7;
 #pragma unroll
     for (int k = 2; k < 16; k++) tb[k] = tb[k - 1] + tb[1];
     if constexpr (FULL) {
-      const u32 wb = w * WL_REGION + e * (8 * WL_BLOCK) + j3 * 4 + c;   // + u * WL_BLOCK + g * 32, k2 = 8 g + u
+      const u32 wb = w * WL_REGION + e * (RL * WL_BLOCK) + j3 * 4 + c;   // + u * WL_BLOCK + g * RL * 4, k2 = RL g + u
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const u32 k2 = brev(i, 4);
         if (k2) x[i] = f.mul(x[i], ld_tabb(a.wr, tb[k2]));
-        img.put(wb + (k2 & 7) * WL_BLOCK + (k2 >> 3) * 32, x[i]);
+        img.put(wb + (k2 % RL) * WL_BLOCK + (k2 / RL) * (RL * 4), x[i]);
       }
       wave_sync();
 #pragma unroll
-      for (int g = 0; g < 2; g++)
+      for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[g * 8 + j] = img.get(own + (8 * g + j) * 4);
+        for (int j = 0; j < RL; j++) x[g * RL + j] = img.get(own + (RL * g + j) * 4);
     } else {
       const u32 wbase = j3 * WL_REGION + (2 * w + e) * 4 + c;          // + k2 * WL_BLOCK
       const u32 rbase = j3 * WL_BLOCK + (2 * w + e) * 4 + c;           // u = j3 of the lane: + j3' * WL_REGION + g * 8 * WL_BLOCK
@@ -336,17 +351,17 @@ RONK_HD void tile_body_wl_row(const TileArgs& a_in, u32* l32, u32 tid, u32 bid, 
         for (int j = 0; j < 8; j++) x[g * 8 + j] = ((u64)img.get32(rbase + j * WL_REGION + g * (8 * WL_BLOCK)) << 32) | lo[g * 8 + j];
     }
   }
-  // ---- round 3 (over j3): lane (s = e, u = l & 7); register g*8 + j3 = element (k1 = 2 w + e, k2 = 8 g + u, j3);
-  // natural output row k = k1 + 16 k2 + 256 brev3(i)
-  const u32 kbase = (2 * w + e) + 16 * j3;   // u = l & 7
+  // ---- round 3 (over j3): lane (s = e, u = l mod RL); register g RL + j3 = element (k1 = G w + e, k2 = RL g + u, j3);
+  // natural output row k = k1 + 16 k2 + 256 brev(i)
+  const u32 kbase = (G * w + e) + 16 * j3;   // u = l mod RL
   const u32 out_sk = cx.out_sk, out_lane = cx.out_lane;
   u64* __restrict__ const outp = cx.out;
 #pragma unroll
-  for (int g = 0; g < 2; g++) {
-    u64* xg = x + g * 8;
-    Dif<8, INV, false, FLD>::run(xg, f, false);
+  for (int g = 0; g < G; g++) {
+    u64* xg = x + g * RL;
+    Dif<RL, INV, false, FLD>::run(xg, f, false);
 #pragma unroll
-    for (int i = 0; i < 8; i++) st_g<true>(outp, out_lane + (kbase + 128 * g + 256 * brev(i, 3)) * out_sk, xg[i]);
+    for (int i = 0; i < RL; i++) st_g<true>(outp, out_lane + (kbase + 16 * RL * g + 256 * brev(i, LOGL)) * out_sk, xg[i]);
   }
 }
 

@@ -112,15 +112,16 @@ struct PlanBuilder {
       if (d.wr_logr[i] == logr) return (int)i;
     d.wr_logr.push_back(logr);
     d.wr.push_back(power_table(hf, hf.root_pow2(logr, d.inverse), (size_t)1 << logr));
-    if (logr == 11) {
-      // behind the 2^11-entry table, the copy ntt_tile_wl.h's column pass reads: entry R + (w * 16 + k1) * 16 + l =
-      // omega_R^{(8 l + w) k1} -- the first-round twiddles of wavefront w, 16 lanes of a column side by side
+    if (logr >= 10 && logr <= 12) {
+      // behind the R-entry table, the copy ntt_tile_wl.h's column pass reads: entry R + (w * 16 + k1) * 16 + l =
+      // omega_R^{(RL l + w) k1}, RL = R / 256 wavefronts -- the first-round twiddles of wavefront w, 16 lanes of a column side by side
       std::vector<u64>& t = d.wr.back();
       const size_t R = (size_t)1 << logr;
+      const u32 RL = (u32)(R >> 8);
       t.resize(2 * R);
-      for (u32 w = 0; w < 8; w++)
+      for (u32 w = 0; w < RL; w++)
         for (u32 k1 = 0; k1 < 16; k1++)
-          for (u32 l = 0; l < 16; l++) t[R + (w * 16 + k1) * 16 + l] = t[((8 * l + w) * k1) & (R - 1)];
+          for (u32 l = 0; l < 16; l++) t[R + (w * 16 + k1) * 16 + l] = t[((RL * l + w) * k1) & (R - 1)];
     }
     return (int)d.wr.size() - 1;
   }

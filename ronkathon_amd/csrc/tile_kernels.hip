@@ -55,10 +55,12 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
         if (found) return e;
         continue;
       }
-      // 2^11-row x 4-column passes (the two-lane plans of 2^21 .. 2^23): one wave-local and one cross-wave exchange, one barrier
-      // per pass (ntt_tile_wl.h).  Round 6, same box: two lanes at 2^22 22.4 k -> 23.6 k NTT/s, one stream 58.5 -> 55.5 us.
+      // 2^10 / 2^11 / 2^12-row x 4-column passes (the two-lane plans of 2^20 .. 2^22, one transform of 2^20 / 2^21 / 2^23): one
+      // wave-local and one cross-wave exchange, one barrier per pass (ntt_tile_wl.h).  Round 6, same box: two lanes at 2^22
+      // 22.4 k -> 23.6 k NTT/s, one stream 58.5 -> 55.5 us.
+      static const bool r4_on = [] { const char* e_ = getenv("RONK_R4MID"); return e_ && atoi(e_) != 0; }();   // opt-in, below
       bool wl_half = false;
-      if (kind < 4 && logr == 11 && a.logc == 2 && tile_wl_wanted(kind, &wl_half)) {
+      if (kind < 4 && logr >= 10 && logr <= 12 && a.logc == 2 && !(r4_on && logr == 10) && tile_wl_wanted(kind, &wl_half)) {
         hipError_t e = launch_tile_wl(logr, inverse, kind, wl_half, a, grid, s, &found);
         if (found) return e;
       }
@@ -71,7 +73,6 @@ hipError_t launch_tile(int logr, bool inverse, const TileArgs& a, u32 grid, u32 
       // (one table-twiddle layer traded for a wave-uniform shift layer) and is not faster anywhere -- one 2^20 transform
       // 27.7 -> 28.1 us, two lanes 17.05 -> 17.3 us per transform, 64 x 2^20 / 256 x 2^18 / 2^24 .. 2^26 within +-1 % -- so
       // the (16, 16, 2 | 4) kernels stay the default.
-      static const bool r4_on = [] { const char* e_ = getenv("RONK_R4MID"); return e_ && atoi(e_) != 0; }();
       if (r4_on && kind < 4 && (logr == 9 || logr == 10)) {
         hipError_t e = launch_tile_r4(logr, inverse, kind, a, grid, block, lds, s, &found);
         if (found) return e;

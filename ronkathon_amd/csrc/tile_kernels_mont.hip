@@ -65,7 +65,7 @@ hipError_t launch_tile_mont(int logr, bool inverse, const TileArgs& a, u32 grid,
     hipError_t e = launch_tile_mont_feat(logr, inverse, tile_features(a), a, grid, block, lds, s, &found);
     if (found) return e;
   }
-  if (!no_cfg && tile_features(a) == 0 && logr == 11 && a.logc == 2) {   // ntt_tile_wl.h over the Montgomery field policy
+  if (!no_cfg && tile_features(a) == 0 && logr >= 10 && logr <= 12 && a.logc == 2) {   // ntt_tile_wl.h over the Montgomery field policy
     for (int kind : {1, 2, 3}) {
       bool half = false, found = false;
       if (!tile_wl_wanted(kind, &half)) continue;

@@ -59,18 +59,23 @@ static bool dispatch_cfg(int logr, u32 tid) {
   {
     static const int wl = getenv("RONK_WL") ? atoi(getenv("RONK_WL")) : 1;
     static const bool wl_half = getenv("RONK_WL_HALF") && atoi(getenv("RONK_WL_HALF")) != 0;
-    if (wl && logr == WL_LOGR && (int)a.logc == WL_LOGC) {
+    static const bool r4_first = getenv("RONK_R4MID") && atoi(getenv("RONK_R4MID")) != 0;   // the opt-in below wins at 2^10 rows
+    if (wl && wl_logr_ok(logr) && (int)a.logc == WL_LOGC && !(r4_first && logr == 10)) {
       for (int kind : {1, 2, 3}) {
         if (!tile_wl_matches(a, logr, kind)) continue;
         if (kind == 2 ? wl == 2 : wl == 3) continue;
         u32* l32 = reinterpret_cast<u32*>(g_fa.lds);
-        if (wl_half && !FLD::MONT) {
-          if (kind == 1) tile_body_wl_col<INV, 1, false, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-          else if (kind == 3) tile_body_wl_col<INV, 3, false, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-          else tile_body_wl_row<INV, false, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-        } else if (kind == 1) tile_body_wl_col<INV, 1, true, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-        else if (kind == 3) tile_body_wl_col<INV, 3, true, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
-        else tile_body_wl_row<INV, true, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);
+#define EMU_WL_RUN(LR, FULLIMG)                                                                                                  \
+  do {                                                                                                                           \
+    if (kind == 1) tile_body_wl_col<LR, INV, 1, FULLIMG, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);              \
+    else if (kind == 3) tile_body_wl_col<LR, INV, 3, FULLIMG, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);         \
+    else tile_body_wl_row<LR, INV, FULLIMG, FLD>(a, l32, tid, g_fa.bid, fiber_barrier, fiber_barrier);                           \
+  } while (0)
+        if (wl_half && !FLD::MONT && logr == 11) EMU_WL_RUN(11, false);
+        else if (logr == 10) EMU_WL_RUN(10, true);
+        else if (logr == 11) EMU_WL_RUN(11, true);
+        else EMU_WL_RUN(12, true);
+#undef EMU_WL_RUN
         g_cfg_used = 30 + kind;
         return true;
       }

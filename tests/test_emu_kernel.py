@@ -100,24 +100,23 @@ def test_tuned_tile_widths(emu, k, logc):
 
 
 @pytest.mark.parametrize("env", [{}, {"RONK_WL_HALF": "1"}, {"RONK_WL": "0"}, {"RONK_WL": "2"}, {"RONK_WL": "3"}, {"RONK_TWF_T": "1"}])
-@pytest.mark.parametrize("k,inv,twf", [(22, 0, 22), (22, 1, 18), (21, 1, 21), (23, 0, 0)])
+@pytest.mark.parametrize("k,inv,twf", [(22, 0, 22), (22, 1, 18), (21, 1, 21), (23, 0, 0), (20, 0, 20), (20, 1, 18), (24, 1, 0)])
 def test_wave_local_tile_bodies(emu, env, k, inv, twf):
-    """ntt_tile_wl.h -- the 2^11-row x 4-column column / row passes with one wave-local and one cross-wave exchange (round 6; the
-    library's default for these shapes): FULL image (one barrier per pass) and the half image (two 32-bit phases, two barriers),
-    forward / inverse, two-level tables / full matrix (also transposed, RONK_TWF_T), one pass at a time mixed with ntt_tile.h's
-    kernels (RONK_WL = 2 / 3), and RONK_WL=0 -- the same plans on the old kernels; 2^23 is the two-pass 2^12 x 2^11 plan whose
-    row pass has 2^11 rows.  The fibers run one after the other, so a missing barrier / wave_sync between dependent LDS accesses
-    shows up as a mismatch."""
-    out = run(emu, k, 1, inv, 2, twf, 24, env=env)
+    """ntt_tile_wl.h -- the 2^10 / 2^11 / 2^12-row x 4-column column / row passes with one wave-local and one cross-wave exchange
+    (round 6; the library's default for these shapes): FULL image (one barrier per pass) and, for 2^11 rows, the half image (two
+    32-bit phases, two barriers), forward / inverse, two-level tables / full matrix (also transposed, RONK_TWF_T), one pass at a
+    time mixed with ntt_tile.h's kernels (RONK_WL = 2 / 3), and RONK_WL=0 -- the same plans on the old kernels; the plans are
+    2^10 x 2^10, 2^11 x 2^10, 2^11 x 2^11, 2^12 x 2^11 and 2^12 x 2^12.  The fibers run one after the other, so a missing
+    barrier / wave_sync between dependent LDS accesses shows up as a mismatch."""
+    out = run(emu, k, 1, inv, 2, twf, 25, env=env)
     kernels = [l.split("kernel=")[1] for l in out.strip().splitlines() if l.startswith("pass")]
     wl = env.get("RONK_WL", "1")
-    want_col = k in (21, 22) and wl in ("1", "2")     # the column pass has 2^11 rows at 2^21 / 2^22, the row pass at 2^22 / 2^23
-    want_row = k in (22, 23) and wl in ("1", "3")
+    want_col, want_row = wl in ("1", "2"), wl in ("1", "3")
     assert kernels[0].startswith("wl:column") == want_col and kernels[1].startswith("wl:row") == want_row, out
     # the same bodies over a Montgomery prime (FULL image)
-    if not env and k == 22:
+    if not env and k in (20, 22, 24):
         p, g = MONT_PRIMES[0]
-        out = run(emu, k, 1, inv, 2, twf, 24, env=mont_env(p, g))
+        out = run(emu, k, 1, inv, 2, twf, 25, env=mont_env(p, g))
         assert "kernel=wl:column" in out and "kernel=wl:row" in out
 
 
@@ -287,7 +286,7 @@ def test_three_pass_plans_run_the_specialised_bodies(emu, k, dirs):
 
 
 @pytest.mark.parametrize("args,kinds", [
-    ((20, 2, 0, 2, 18, 25, 300000, 0, 0, 700001), ("feat:column/two-level", "cfg:row")),          # multiply: both operands, zero padded
+    ((20, 2, 0, 2, 18, 25, 300000, 0, 0, 700001), ("feat:column/two-level", "wl:row")),           # multiply: both operands, zero padded
     ((22, 2, 0, 2, 18, 25, 2097152, 0, 0, 2097152), ("feat:column/two-level", "wl:row")),
     ((20, 1, 1, 4, 18, 25, 0, 1000001, 1, 0, 1), ("feat:column/two-level", "feat:row")),            # its inverse: fused product in, truncated out
     ((21, 1, 1, 4, 18, 25, 0, 2097151, 1, 0, 1), ("feat:column/two-level", "feat:row")),

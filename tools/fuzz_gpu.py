@@ -285,8 +285,8 @@ def sec_divrem(deadline):
     it = 0
     while time.time() < deadline:
         it += 1
-        p = rng.choice([GP, GP, 101, 17, 0xFFFFFFFFFFFFFFC5])
-        big = p == GP and rng.random() < 0.25
+        p = rng.choice([GP, GP, 101, 17, 0xFFFFFFFFFFFFFFC5, 0xFFFFFFFC00000001, 29 * 2**57 + 1])   # (the last two: Newton over Montgomery)
+        big = p in (GP, 0xFFFFFFFC00000001, 29 * 2**57 + 1) and rng.random() < 0.25
         d = rng.randrange(1, 40000 if big else 700)
         d2 = rng.randrange(1, d + 3)
         a = edge_values(p, d, 2 * it); b = edge_values(p, d2, 2 * it + 1)
@@ -335,6 +335,27 @@ def sec_divrem(deadline):
                 report("divrem", "dev status", p, d, d2, code)
             elif not (np.array_equal(dq.cpu().numpy().view(np.uint64), want[0]) and np.array_equal(dr.cpu().numpy().view(np.uint64), want[1])):
                 report("divrem", "dev values", p, d, d2, shape, alias)
+            # the fully asynchronous form for full-length operands (ronk_poly_divrem_full_dev): values when the promise holds,
+            # RONK_ERR_INVALID in the status word when a top coefficient is ZERO, RONK_ERR_UNSUPPORTED for fields without the roots
+            if not alias:
+                dq.fill_(-1); dr.fill_(-1); dst.fill_(55)
+                torch.cuda.synchronize()
+                rc3 = L.lib.ronk_poly_divrem_full_dev(p, da.data_ptr(), d, db.data_ptr(), d2, dq.data_ptr(), dr.data_ptr(), dst.data_ptr(),
+                                                      st.cuda_stream if st is not None else None)
+                torch.cuda.synchronize()
+                full = int(a[-1]) != 0 and int(b[-1]) != 0
+                if rc3 == L.ERR_UNSUPPORTED:
+                    if p in (GP, 0xFFFFFFFC00000001, 29 * 2**57 + 1):
+                        report("divrem", "full: unsupported over an NTT-friendly prime", p, d, d2)
+                elif rc3 != 0:
+                    report("divrem", "full rc", p, d, d2, rc3)
+                elif not full:
+                    if int(dst.item()) != L.ERR_INVALID:
+                        report("divrem", "full: broken promise not reported", p, d, d2, int(dst.item()))
+                elif isinstance(want, Exception) or int(dst.item()) != 0:
+                    report("divrem", "full status", p, d, d2, int(dst.item()))
+                elif not (np.array_equal(dq.cpu().numpy().view(np.uint64), want[0]) and np.array_equal(dr.cpu().numpy().view(np.uint64), want[1])):
+                    report("divrem", "full values", p, d, d2)
     counts["divrem"] = it
 
 
@@ -458,6 +479,22 @@ def sec_vec(deadline):
                 report("vec", "inverse of zero accepted", p, n, rc)
         elif rc != 0 or not np.array_equal(out, orc.vec_inv(p, a)):
             report("vec", "inv", p, n, rc)
+        # FieldExt (prime/mod.rs:142-226): euler_criterion of everything, sqrt of the squares; a non-residue is the reference's assert
+        if p > 2:
+            L.check(L.lib.ronk_vec_euler(p, L.ptr(a), L.ptr(out), n))
+            if not np.array_equal(out, orc.vec_euler(p, a)):
+                report("vec", "euler", p, n)
+            sq = orc.vec_mul(p, a, a)
+            r0 = np.empty(n, dtype=np.uint64); r1 = np.empty(n, dtype=np.uint64)
+            rc = L.lib.ronk_vec_sqrt(p, L.ptr(sq), L.ptr(r0), L.ptr(r1), n)
+            o0, o1 = orc.vec_sqrt(p, sq)
+            if rc != 0 or not (np.array_equal(r0, o0) and np.array_equal(r1, o1)):
+                report("vec", "sqrt", p, n, rc)
+            nonres = a[(orc.vec_euler(p, a) == 0) & (a != 0)]
+            if nonres.size:
+                t = sq.copy(); t[rng.randrange(n)] = nonres[0]
+                if L.lib.ronk_vec_sqrt(p, L.ptr(t), L.ptr(r0), L.ptr(r1), n) != L.ERR_NOT_RESIDUE:
+                    report("vec", "sqrt of a non-residue accepted", p, n)
     counts["vec"] = it
 
 
@@ -545,17 +582,18 @@ def sec_sharded(deadline):
         k = rng.randrange(max(8, 2 * w.bit_length()), 23)
         inverse = rng.random() < 0.4
         chunks = rng.choice([0, 1, 2, 4])
-        x = edge_values(GP, 1 << k, it)
+        p, g = rng.choice([(GP, GG), (GP, GG), (0xFFFFFFFC00000001, 10), (29 * 2**57 + 1, 3)])   # (the four-step phases over Montgomery too)
+        x = edge_values(p, 1 << k, it)
         try:
-            sp = L.ShardedPlan(k, [0] * w, inverse=inverse, chunks=chunks)
+            sp = L.ShardedPlan(k, [0] * w, inverse=inverse, chunks=chunks) if p == GP else L.ShardedPlan(k, [0] * w, inverse=inverse, chunks=chunks, p=p, g=g)
         except L.RonkPanic as e:
             if e.code in (L.ERR_INVALID, L.ERR_UNSUPPORTED):
                 continue    # a split this size cannot take (too few columns per rank / chunk)
             report("sharded", "create", k, w, chunks, str(e)); continue
         y = sp.transform(x)
-        want = orc.ifft(GP, GG, x) if inverse else orc.fft(GP, GG, x)
+        want = orc.ifft(p, g, x) if inverse else orc.fft(p, g, x)
         if not np.array_equal(y, want):
-            report("sharded", "transform", k, w, inverse, chunks)
+            report("sharded", "transform", hex(p), k, w, inverse, chunks)
         sp.close()
     counts["sharded"] = it
 
