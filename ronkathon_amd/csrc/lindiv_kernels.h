@@ -73,11 +73,11 @@ constexpr int LINDIV_DLOAD = 1;
 template <int MODE, bool APPLY>
 constexpr int lindiv_lds_words() { return 8 + ((MODE & LINDIV_DLOAD) && !APPLY ? 0 : LINDIV_CHUNK + 256); }
 
-// the lane's run e[m] = c[base + PL tid + m] (ZERO beyond d)
-template <int MODE, class Ctx>
+// the lane's run e[m] = c[base + PL tid + m] (ZERO beyond d); NL lanes per workgroup
+template <int MODE, int NL = 256, class Ctx>
 RONK_HD void lindiv_load_run(const u64* __restrict__ c, size_t d, size_t base, u32 tid, u64* buf, u64 (&e)[LINDIV_PL], Ctx& cx) {
   constexpr int PL = LINDIV_PL;
-  const bool full = base + 256 * PL <= d;
+  const bool full = base + NL * PL <= d;
   if constexpr ((MODE & LINDIV_DLOAD) != 0) {
     const size_t i0 = base + (size_t)PL * tid;
     if (full) {
@@ -91,7 +91,7 @@ RONK_HD void lindiv_load_run(const u64* __restrict__ c, size_t d, size_t base, u
     // coalesced, lane-strided fill; one pad word per run so that the PL-contiguous reads are conflict free
 #pragma unroll
     for (int r = 0; r < PL; r++) {
-      const u32 k = tid + 256 * r;
+      const u32 k = tid + NL * r;
       const size_t i = base + k;
       buf[k + k / PL] = (full || i < d) ? c[i] : 0;
     }
@@ -205,6 +205,188 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
   }
 }
 
+// ---- ONE launch (round 6): 16 bytes of HBM traffic per coefficient ---------------------------------------------------------------
+// The two launches above read the dividend twice (24 + 2/PL bytes per coefficient against 16 algorithmic).  Here a workgroup keeps
+// its chunk in registers while the chunk sums travel: workgroups of NL = 1024 lanes x PL = 8 coefficients (chunks of 8192; at most
+// LINDIV1_MAX_CHUNKS = 512 per call = 2^22 coefficients, all resident at two workgroups per CU), and
+//   1  the lanes' Horner values, the suffix scan over the wavefront (cross-lane network) and over the 16 wavefront sums (one
+//      barrier): W_t, H_b = W_0 -- published with ONE agent-scope write-through store into the call's look-back array;
+//   2  the carry G_(b+1) = sum_{j > b} H_j Y^(j-b-1): lane t polls entry b+1+t (agent-scope loads; "not there yet" = 2^64 - 1, no
+//      canonical residue) -- ONE entry per lane, 512 x 8 polled wavefront requests per round against the 64 k of the round-2
+//      one-launch form (scan_kernels.h lindiv_onepass_kernel: 2048 workgroups x 8 gathers; its waits were what made it slower);
+//   3  the recurrence down the lane's run and the coalesced store through the LDS image, as in lindiv_apply_body.
+// Measured (round 6, profiles/r06_lindiv_one.txt): 2^22 coefficients 22.3-23.0 -> 21.4-21.7 us per call, 2^21 14.5 -> 12.6-14.1, 2^20
+// 11.2 -> 11.5 (slower: the entry point keeps two launches up to 2^20).  Less than the 16 / 24 traffic ratio promises, and the
+// variants that skip phases say why -- load + all arithmetic 13.3 us, + stores 18.6, + the wait 21.5: with every chunk resident the
+// whole device loads, computes and stores in lock-step (ONE round: nothing overlaps the arithmetic or the hand-off), where the second
+// of two launches streams.
+// Nothing can deadlock: workgroup i takes chunk nchunks-1-i and waits for HIGHER chunks only, i.e. for workgroups dispatched before
+// it; every wait is bounded (the context's lb_wait gives up after 50 ms) and a workgroup whose wait ran out recomputes the chunk
+// sums above it from the coefficients (slow, correct) -- which is why the entry point keeps the two-launch form for a quotient
+// written over the dividend.  The array of the NEXT call is cleared here (two arrays per workspace slot, used alternately).
+constexpr int LINDIV1_NL = 1024;
+constexpr int LINDIV1_NW = LINDIV1_NL / 64;
+constexpr int LINDIV1_CHUNK = LINDIV1_NL * LINDIV_PL;
+constexpr u32 LINDIV1_MAX_CHUNKS = 512;
+constexpr u64 LINDIV_LB_EMPTY = ~(u64)0;
+constexpr int LINDIV1_STREAM = 2;   // lindiv1_chunk_scan: MODE of the recompute path
+constexpr int LINDIV1_SC = 40;   // LDS words ahead of the image: 16 wavefront sums, 16 carry partials, flag, broadcast word
+constexpr int lindiv1_lds_words() { return LINDIV1_SC + LINDIV1_CHUNK + LINDIV1_NL; }
+
+struct LinDiv1Tab {
+  u64 z;
+  u64 scale;      // 1/b1
+  u64 zs[6];      // z^(PL 2^s): the scan inside a wavefront
+  u64 zx[4];      // z^(64 PL 2^s): the scan over the wavefront sums
+  u64 zp[65];     // z^(PL k), k <= 64
+  u64 zw[16];     // z^(64 PL k)
+  u64 Y;          // z^(NL PL): one chunk
+  u64 YA[16];     // Y^i
+  u64 YB[16];     // Y^(16 i)
+  u64 YC[2];      // Y^(256 i):   Y^t = YA[t & 15] YB[(t >> 4) & 15] YC[t >> 8], t < 512
+  u64 test_flags; // bit 0: every wait fails at once (the recompute path under test)
+};
+
+inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Tab* t) {
+  const int pl = LINDIV_PL;
+  auto mulm = [p](u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % p); };
+  auto powm = [&](u64 a, u64 e) { u64 r = 1 % p; while (e) { if (e & 1) r = mulm(r, a); a = mulm(a, a); e >>= 1; } return r; };
+  t->z = z % p;
+  t->scale = scale;
+  t->test_flags = test_flags;
+  const u64 zpl = powm(t->z, (u64)pl);
+  u64 y = 1 % p;
+  for (int k = 0; k <= 64; k++) { t->zp[k] = y; y = mulm(y, zpl); }
+  for (int s = 0; s < 6; s++) t->zs[s] = t->zp[1 << s];
+  const u64 zwave = t->zp[64];                            // z^(64 pl)
+  y = 1 % p;
+  for (int k = 0; k < 16; k++) { t->zw[k] = y; y = mulm(y, zwave); }
+  t->Y = y;                                               // z^(1024 pl)
+  for (int s = 0; s < 4; s++) t->zx[s] = t->zw[1 << s];
+  const u64 Y16 = powm(t->Y, 16);
+  u64 cc = 1 % p, dd = 1 % p;
+  for (int i = 0; i < 16; i++) {
+    t->YA[i] = cc; t->YB[i] = dd;
+    cc = mulm(cc, t->Y); dd = mulm(dd, Y16);
+  }
+  t->YC[0] = 1 % p; t->YC[1] = powm(Y16, 16);
+}
+
+// steps 1 of the list above for chunk b: returns the lane's W_t (U) and the value C of the chunk's suffix that starts behind the
+// lane's wavefront.  One barrier (two when the run goes through the LDS image); the caller must not touch sc[0 .. NW) before the
+// next barrier.
+template <int MODE, class Ops, class Ctx>
+RONK_HD void lindiv1_chunk_scan(const Ops& ops, const u64* __restrict__ c, size_t d, u32 b, const LinDiv1Tab& tab, u64* sc,
+                                u64 (&e)[LINDIV_PL], u64* Uout, u64* Cout, Ctx& cx) {
+  constexpr int PL = LINDIV_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
+  const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
+  const u64 zup = tab.zp[64 - lane];
+  const u64 z = tab.z;
+  u64 U;
+  if constexpr (MODE == LINDIV1_STREAM) {
+    // (the recompute path: the coefficients one at a time, nothing kept)
+    const size_t i0 = (size_t)b * (NL * PL) + (size_t)PL * tid;
+    U = 0;
+    for (int m = PL - 1; m >= 0; m--) U = ops.add(ops.mul(U, z), i0 + m < d ? c[i0 + m] : 0);
+  } else {
+    lindiv_load_run<MODE, NL>(c, d, (size_t)b * (NL * PL), tid, sc + LINDIV1_SC, e, cx);
+    U = e[PL - 1];
+#pragma unroll
+    for (int m = PL - 2; m >= 0; m--) U = ops.add(ops.mul(U, z), e[m]);
+  }
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    const u32 off = 1u << s;
+    const u64 up = cx.shfl_down(U, off);
+    if (lane + off < 64) U = ops.add(U, ops.mul(tab.zs[s], up));
+  }
+  if (lane == 0) sc[w] = U;
+  cx.barrier();
+  // V_k = T_k + z^(64 PL) V_(k+1): the chunk's suffix from the start of wavefront k (every wavefront computes all 16)
+  u64 V = lane < (u32)NW ? sc[lane] : 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const u32 off = 1u << s;
+    const u64 up = cx.shfl_down(V, off);
+    if (lane + off < (u32)NW) V = ops.add(V, ops.mul(tab.zx[s], up));
+  }
+  const u64 Vn = cx.shfl(V, w + 1 < (u32)NW ? w + 1 : 0);
+  const u64 C = w + 1 < (u32)NW ? Vn : 0;
+  *Uout = ops.add(U, ops.mul(zup, C));
+  *Cout = C;
+}
+
+template <int MODE, class Ops, class Ctx>
+RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d, const LinDiv1Tab& tab, u64* lb_cur, u64* lb_next,
+                             u32 lb_words, u32 nchunks, u64* __restrict__ quot, u64* __restrict__ rem, Ctx& cx) {
+  constexpr int PL = LINDIV_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
+  const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
+  const u32 b = nchunks - 1 - cx.bid();
+  u64* sc = cx.lds();
+  u64* buf = sc + LINDIV1_SC;
+  const size_t base = (size_t)b * (NL * PL);
+  const bool full = base + NL * PL <= d;
+  for (u32 i = cx.bid() * NL + tid; i < lb_words; i += nchunks * NL) lb_next[i] = LINDIV_LB_EMPTY;
+  u64 e[PL], U, C;
+  lindiv1_chunk_scan<MODE>(ops, c, d, b, tab, sc, e, &U, &C, cx);
+  if (tid == 0) cx.lb_store(&lb_cur[b], U);               // H_b = W_0
+  u64 wn = cx.shfl_down(U, 1);                            // W_(t+1)
+  if (lane == 63) wn = C;
+  // the other per-lane table entries, requested before the wait
+  const u64 zpk = ops.mul(tab.zp[63 - lane], tab.zw[NW - 1 - w]);   // z^(PL (NL - 1 - t))
+  const u64 yt = ops.mul(ops.mul(tab.YA[tid & 15], tab.YB[(tid >> 4) & 15]), tab.YC[(tid >> 8) & 1]);
+  // carry: lane t takes H_(b+1+t) Y^t
+  const u32 j = b + 1 + tid;
+  u64 cpart = 0;
+  bool late = false;
+  if (j < nchunks) {
+    u64 v = 0;
+    if (cx.lb_wait(&lb_cur[j], &v, tab.test_flags)) cpart = ops.mul(v, yt);
+    else late = true;
+  }
+  if (tid == 0) sc[2 * NW] = 0;
+  cx.barrier();                                           // (also: every wavefront is done with sc[0 .. NW))
+  if (late) sc[2 * NW] = 1;
+#pragma unroll
+  for (int s = 0; s < 6; s++) cpart = ops.add(cpart, cx.shfl_xor(cpart, 1u << s));
+  if (lane == 0) sc[NW + w] = cpart;
+  cx.barrier();
+  u64 cin = 0;
+  if (sc[2 * NW] == 0) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) cin = ops.add(cin, sc[NW + k]);
+  } else {
+    // somebody never showed up: Horner over the chunk sums above b, every one recomputed here from the coefficients
+    for (u32 jj = nchunks - 1; jj > b; jj--) {
+      u64 U2, C2;
+      cx.barrier();
+      lindiv1_chunk_scan<LINDIV1_STREAM>(ops, c, d, jj, tab, sc, e, &U2, &C2, cx);
+      if (tid == 0) sc[2 * NW + 1] = U2;
+      cx.barrier();
+      cin = ops.add(ops.mul(cin, tab.Y), sc[2 * NW + 1]);
+    }
+    cx.barrier();
+  }
+  if (b == 0 && tid == 0 && rem) *rem = ops.add(U, ops.mul(tab.Y, cin));   // c(z) = H_0 + Y G_1
+  u64 r = ops.add(wn, ops.mul(zpk, cin));
+  const u64 z = tab.z;
+  // straight into the LDS image (it is free: since its fill's barrier a lane has read nothing but its own run's words, and the
+  // recompute path ends on a barrier) -- eight results held in registers beside the run do not fit 64 VGPRs
+  const bool scaled = tab.scale != 1;
+#pragma unroll
+  for (int m = PL - 1; m >= 0; m--) {
+    buf[(PL + 1) * tid + m] = scaled ? ops.mul(r, tab.scale) : r;
+    r = ops.add(ops.mul(r, z), e[m]);
+  }
+  cx.barrier();
+#pragma unroll
+  for (int rr = 0; rr < PL; rr++) {
+    const u32 kk = tid + NL * rr;
+    const size_t i = base + kk;
+    if (full || i < d) quot[i] = buf[kk + kk / PL];
+  }
+}
+
 }  // namespace ronk
 
 #if defined(__HIPCC__)
@@ -221,6 +403,22 @@ struct LinDivDevCtx {
   __device__ __forceinline__ void barrier() const { __syncthreads(); }
   __device__ __forceinline__ u64 shfl_down(u64 v, u32 off) const { return __shfl_down((unsigned long long)v, off, 64); }
   __device__ __forceinline__ u64 shfl_xor(u64 v, u32 mask) const { return __shfl_xor((unsigned long long)v, (int)mask, 64); }
+  __device__ __forceinline__ u64 shfl(u64 v, u32 src) const { return __shfl((unsigned long long)v, (int)src, 64); }
+  // the look-back array of the one-launch form: agent-scope write-through store / L2-bypassing load, no fence (the entry is the
+  // whole message); a wait gives up after 50 ms of the 100 MHz wall clock
+  __device__ __forceinline__ void lb_store(u64* p, u64 v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ bool lb_wait(const u64* p, u64* v, u64 test_flags) const {
+    if (test_flags & 1) return false;
+    u64 x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (x != LINDIV_LB_EMPTY) { *v = x; return true; }
+    const u64 t0 = wall_clock64();
+    for (;;) {
+      __builtin_amdgcn_s_sleep(8);
+      x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (x != LINDIV_LB_EMPTY) { *v = x; return true; }
+      if (wall_clock64() - t0 > 5000000) return false;
+    }
+  }
   typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
   __device__ __forceinline__ void ld2(const u64* p, u64& a, u64& b) const {
     const v2 v = *reinterpret_cast<const v2*>(p);
@@ -247,6 +445,16 @@ __global__ void __launch_bounds__(256) lindiv_apply_kernel2(Ops ops, const u64* 
   __shared__ __attribute__((aligned(16))) u64 lds[lindiv_lds_words<MODE, true>()];
   LinDivDevCtx cx{lds};
   lindiv_apply_body<MODE>(ops, c, d, tab, W, H, gridDim.x, quot, rem, cx);
+}
+
+// 8 wavefronts per SIMD: two workgroups per CU, LINDIV1_MAX_CHUNKS resident at once
+template <int MODE, class Ops>
+__global__ void __launch_bounds__(LINDIV1_NL, 8) lindiv_one_kernel(Ops ops, const u64* __restrict__ c, size_t d, LinDiv1Tab tab,
+                                                                   u64* lb_cur, u64* lb_next, u32 lb_words,
+                                                                   u64* __restrict__ quot, u64* __restrict__ rem) {
+  __shared__ __attribute__((aligned(16))) u64 lds[lindiv1_lds_words()];
+  LinDivDevCtx cx{lds};
+  lindiv_one_body<MODE>(ops, c, d, tab, lb_cur, lb_next, lb_words, gridDim.x, quot, rem, cx);
 }
 
 }  // namespace ronk

@@ -256,6 +256,26 @@ static void make_lindiv_tab(u64 p, u64 z, u64 scale, LinDivTab* t) {   // (kept 
   if (lp != p || lz != z || lscale != scale) { lindiv_build_tab(p, z, scale, &last); lp = p; lz = z; lscale = scale; }
   *t = last;
 }
+// the one-launch form (lindiv_kernels.h lindiv_one_kernel): RONK_LINDIV_ONE = 0 never, 1 (default) above 2^20 coefficients, 2 at every size
+static const int g_lindiv_one = [] { const char* e = getenv("RONK_LINDIV_ONE"); return e ? atoi(e) : 1; }();
+static void make_lindiv1_tab(u64 p, u64 z, u64 scale, LinDiv1Tab* t) {   // (kept for the next call: see make_horner_tab2)
+  static std::mutex mu;
+  static LinDiv1Tab last;
+  static u64 lp = 0, lz = 0, lscale = 0;
+  static const u64 test_flags = [] { const char* e = getenv("RONK_LB_TEST_FLAGS"); return e ? (u64)atoi(e) : (u64)0; }();
+  std::lock_guard<std::mutex> lk(mu);
+  if (lp != p || lz != z || lscale != scale) { lindiv1_build_tab(p, z, scale, test_flags, &last); lp = p; lz = z; lscale = scale; }
+  *t = last;
+}
+static_assert(LINDIV_LB_EMPTY == LB_EMPTY && LINDIV1_MAX_CHUNKS <= LB_WORDS, "one look-back array convention for every one-launch scan");
+template <int MODE>
+static int lindiv1_launch(const FieldCtx& f, const u64* d_c, size_t d, const LinDiv1Tab& tab, u64* cur, u64* next, u32 nch,
+                          u64* d_quot, u64* d_rem, hipStream_t s) {
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_one_kernel<MODE, decltype(ops)>), dim3(nch), dim3(LINDIV1_NL), 0, s, ops, d_c, d,
+                                        tab, cur, next, (u32)LB_WORDS, d_quot, d_rem); });
+  HIPCHK(hipGetLastError());
+  return RONK_OK;
+}
 template <int MODE>
 static int lindiv2_launch(const FieldCtx& f, const u64* d_c, size_t d, const LinDivTab& tab, u64* W, u64* H, u32 nch, u64* d_quot,
                           u64* d_rem, hipStream_t s) {
@@ -359,8 +379,27 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
   const u64 b1inv = h_powmod(b1, p - 2, p);
   const u64 z = h_mulmod((p - b0) % p, b1inv, p);        // -b0 / b1
   if (g_lindiv && d <= (size_t)LINDIV_CHUNK * 4096 && !g_no_fused_scans && !g_onepass_div) {   // lindiv_kernels.h
-    const size_t nch = (d + LINDIV_CHUNK - 1) / LINDIV_CHUNK;
     const bool direct = g_lindiv == 2 && ((uintptr_t)d_c & 15) == 0;
+    // ONE launch, 16 bytes of traffic per coefficient, up to 2^22 coefficients (every chunk resident).  Not for a quotient written
+    // over the dividend (a workgroup whose wait runs out recomputes chunk sums from the coefficients, which other workgroups may
+    // have overwritten by then) and not under stream capture (the look-back parity is host state).
+    const size_t nch1 = (d + LINDIV1_CHUNK - 1) / LINDIV1_CHUNK;
+    const bool overlap1 = d_quot < d_c + d && d_c < d_quot + d;
+    // A 16-byte aligned dividend only: the form that fills the runs through the LDS image does not fit 64 VGPRs.
+    // From 2^20 coefficients up: below, two launches are faster (measured: lindiv_kernels.h); RONK_LINDIV_ONE=2 lifts the floor.
+    if (g_lindiv_one && direct && (nch1 > 128 || g_lindiv_one == 2) && nch1 <= LINDIV1_MAX_CHUNKS && !overlap1 && !g_no_onepass_scans &&
+        !stream_is_capturing(s)) {
+      LinDiv1Tab tab1;
+      make_lindiv1_tab(p, z, b1inv, &tab1);
+      WsLease ws;
+      RCHK(ws.acquire(64, s));
+      u64 *cur, *next;
+      ws.lb_arrays(&cur, &next);
+      RCHK(lindiv1_launch<LINDIV_DLOAD>(f, d_c, d, tab1, cur, next, (u32)nch1, d_quot, d_rem, s));
+      ws.lb_commit();
+      return RONK_OK;
+    }
+    const size_t nch = (d + LINDIV_CHUNK - 1) / LINDIV_CHUNK;
     LinDivTab tab;
     make_lindiv_tab(p, z, b1inv, &tab);
     WsLease ws;

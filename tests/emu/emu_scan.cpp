@@ -6,7 +6,8 @@
 // oracle's field operations (and, for small d, with oracle/ orc_poly_divrem itself).  Built and run by
 // tests/test_emu_kernel.py only; the product library never contains or calls it.
 //
-// usage: emu_scan <p> <d> <z> <b1> <direct loads 0|1> [seed]      (prints OK or the first mismatch)
+// usage: emu_scan <p> <d> <z> <b1> <mode> [seed]      (prints OK or the first mismatch)
+//   mode: bit 0 = 16-byte direct loads, bit 1 = the one-launch form (lindiv_one_body), bit 2 = ... with every look-back wait failing
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,7 +25,7 @@ static std::vector<ucontext_t> g_ctx;
 static std::vector<char> g_stacks;
 static std::vector<char> g_done;
 static int g_cur;
-static u64 g_xch[256];
+static u64 g_xch[1024];
 
 struct GlHostOps {
   u64 add(u64 a, u64 b) const { return gl64::add(a, b); }
@@ -56,6 +57,20 @@ struct FiberCtx {
     barrier();
     return r;
   }
+  u64 shfl(u64 v, u32 src) const {                         // __shfl(v, src, 64)
+    g_xch[t] = v; barrier();
+    const u64 r = g_xch[(t & ~63u) | (src & 63)];
+    barrier();
+    return r;
+  }
+  // the one-launch form's look-back array: the emulator runs the workgroups in dispatch order, one after the other, so an entry is
+  // either there or never will be (the body then recomputes it: the path RONK_LB_TEST_FLAGS=1 forces on the device)
+  void lb_store(u64* p, u64 v) const { *p = v; }
+  bool lb_wait(const u64* p, u64* v, u64 test_flags) const {
+    if ((test_flags & 1) || *p == LINDIV_LB_EMPTY) return false;
+    *v = *p;
+    return true;
+  }
   void ld2(const u64* p, u64& a, u64& c) const {
     if ((uintptr_t)p & 15) { printf("FAIL: unaligned 16-byte load\n"); exit(1); }
     a = p[0]; c = p[1];
@@ -69,13 +84,15 @@ struct FiberCtx {
 struct Job {
   int phase, pl, direct; bool gl; u64 p;
   const u64* c; size_t d; const LinDivTab* tab; u64 *W, *H; u32 nch; u64 *quot, *rem; u64* lds; u32 bid;
+  const LinDiv1Tab* tab1; u64 *lb_cur, *lb_next; u32 lb_words;   // phase 2: the one-launch form
 };
 static Job g_job;
 
 template <int MODE, class Ops>
 static void run_item(const Ops& ops, u32 tid) {
   FiberCtx cx{tid, g_job.bid, g_job.lds};
-  if (g_job.phase == 0) lindiv_scan_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab, g_job.W, g_job.H, cx);
+  if (g_job.phase == 2) lindiv_one_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab1, g_job.lb_cur, g_job.lb_next, g_job.lb_words, g_job.nch, g_job.quot, g_job.rem, cx);
+  else if (g_job.phase == 0) lindiv_scan_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab, g_job.W, g_job.H, cx);
   else lindiv_apply_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab, g_job.W, g_job.H, g_job.nch, g_job.quot, g_job.rem, cx);
 }
 template <class Ops>
@@ -123,9 +140,10 @@ int main(int argc, char** argv) {
   const u64 p = strtoull(argv[1], 0, 0);
   const size_t d = (size_t)strtoull(argv[2], 0, 0);
   const u64 z = strtoull(argv[3], 0, 0) % p, b1 = strtoull(argv[4], 0, 0) % p;
-  const int pl = LINDIV_PL, direct = atoi(argv[5]);
+  const int pl = LINDIV_PL, mode = atoi(argv[5]), direct = mode & 1;
+  const bool one = (mode & 2) != 0, lb_fail = (mode & 4) != 0;   // the one-launch form; ... with every look-back wait failing
   u64 seed = argc > 6 ? strtoull(argv[6], 0, 0) : 1;
-  if (d == 0 || b1 == 0 || (direct != 0 && direct != 1)) { printf("bad arguments\n"); return 2; }
+  if (d == 0 || b1 == 0 || mode < 0 || mode > 7) { printf("bad arguments\n"); return 2; }
   std::vector<u64> cbuf(d + 2), qbuf(d + 2, 0x5555555555555555ull);
   u64* c = cbuf.data();
   u64* quot = qbuf.data();
@@ -141,7 +159,24 @@ int main(int argc, char** argv) {
   std::vector<u64> H(nch, 0xAAAAAAAAAAAAAAAAull), W(nch * 256, 0xAAAAAAAAAAAAAAAAull), lds(8192);
   u64 rem = ~0ull;
   g_job = Job{0, pl, direct, p == 0xFFFFFFFF00000001ull, p, c, d, &tab, W.data(), H.data(), (u32)nch, quot, &rem, lds.data(), 0};
-  for (int phase = 0; phase < 2; phase++) {
+  LinDiv1Tab tab1;
+  lindiv1_build_tab(p, z, b1inv, lb_fail ? 1 : 0, &tab1);
+  const size_t nch1 = (d + LINDIV1_CHUNK - 1) / LINDIV1_CHUNK;
+  const u32 lbw = (u32)nch1 + 37;                          // (the library's arrays hold LB_WORDS entries; any length >= chunks works)
+  std::vector<u64> lbc(lbw, LINDIV_LB_EMPTY), lbn(lbw, 0x1111111111111111ull), lds1(lindiv1_lds_words());
+  if (one) {
+    if (nch1 > LINDIV1_MAX_CHUNKS) { printf("bad arguments: more than %u chunks\n", LINDIV1_MAX_CHUNKS); return 2; }
+    g_job.phase = 2; g_job.nch = (u32)nch1; g_job.tab1 = &tab1; g_job.lb_cur = lbc.data(); g_job.lb_next = lbn.data(); g_job.lb_words = lbw;
+    g_job.lds = lds1.data();
+    for (u32 bid = 0; bid < nch1; bid++) {                 // dispatch order: workgroup i takes chunk nch1-1-i
+      g_job.bid = bid;
+      for (auto& w : lds1) w = 0xDEADBEEFDEADBEEFull;
+      run_block(LINDIV1_NL);
+    }
+    for (u32 i = 0; i < lbw; i++)
+      if (lbn[i] != LINDIV_LB_EMPTY) { printf("FAIL: look-back array of the next call not cleared at %u\n", i); return 1; }
+  }
+  for (int phase = 0; phase < 2 && !one; phase++) {
     g_job.phase = phase;
     for (u32 b = 0; b < nch; b++) {
       const u32 bid = phase ? (u32)(nch - 1 - b) : b;      // (any order: the workgroups of a launch are independent)
@@ -166,6 +201,7 @@ int main(int argc, char** argv) {
       if (oq[j] != quot[j]) { printf("FAIL vs orc_poly_divrem at %zu\n", j); return 1; }
     if (orr[0] != rem) { printf("FAIL remainder vs orc_poly_divrem\n"); return 1; }
   }
-  printf("OK p=%llu d=%zu pl=%d direct=%d chunks=%zu\n", (unsigned long long)p, d, pl, direct, nch);
+  printf("OK p=%llu d=%zu pl=%d direct=%d %s chunks=%zu\n", (unsigned long long)p, d, pl, direct, one ? (lb_fail ? "one-launch/recompute" : "one-launch") : "two-launch",
+         one ? nch1 : nch);
   return 0;
 }

@@ -61,6 +61,14 @@ def main():
                 assert np.array_equal(q2, orc.vec_mul(p, q, np.full(d, orc.inverse(p, b1), dtype=np.uint64))), (p, d, "scaled, unaligned, in place")
                 assert int(dr.cpu().numpy().view(np.uint64)[0]) == val
                 assert not db.cpu().numpy()[off + d:].any() and (off == 0 or int(db[0]) == 0), "wrote outside the operand"
+                # the same divisor, aligned and out of place (the one-launch form up to 2^22 coefficients), twice in a row on the
+                # same stream (the two look-back arrays alternate)
+                for _ in range(2):
+                    dq.fill_(-1)
+                    L.check(L.lib.ronk_poly_div_linear_dev(p, da.data_ptr(), d, b0, b1, dq.data_ptr(), dr.data_ptr(), st))
+                    torch.cuda.synchronize()
+                    assert np.array_equal(dq.cpu().numpy().view(np.uint64), q2), (p, d, "scaled, aligned, out of place")
+                    assert int(dr.cpu().numpy().view(np.uint64)[0]) == val
     print("scan check ok")
 
 
