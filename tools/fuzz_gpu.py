@@ -365,7 +365,8 @@ def sec_lindiv(deadline):
         it += 1
         p = rng.choice([GP, GP, GP, 101, 2, 0xFFFFFFFFFFFFFFC5])
         d = rng.choice([rng.randrange(1, 64), rng.randrange(1, 5000), rng.randrange(1, 400000),
-                        2048 * rng.randrange(1, 40) + rng.choice([-1, 0, 1]), rng.randrange(1, 1 << 23)])
+                        2048 * rng.randrange(1, 40) + rng.choice([-1, 0, 1]), rng.randrange(1, 1 << 23),
+                        8192 * rng.randrange(129, 513) + rng.choice([-1, 0, 1])])   # (the one-launch form: 129 .. 512 chunks of 8192)
         a = edge_values(p, d, it)
         z = rng.choice([0, 1, p - 1, rng.randrange(p)]) % p
         b1 = rng.choice([1, 1, rng.randrange(1, p) if p > 2 else 1])

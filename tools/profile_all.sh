@@ -46,6 +46,7 @@ RONK_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup
 RONK_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --workload fourstep --log2n 24 --steps 10 --warmup 2 --no-cpu > $OUT/bench_fourstep_2ranks_gloo_smoke.json 2>> $OUT/err
 timeout 300 python tools/mul_sizes.py > $OUT/mul_sizes.txt 2>> $OUT/err
 FUZZ_SEED=51 FUZZ_SECONDS=150 timeout 400 python tools/fuzz_gpu.py mont ntt mul > $OUT/fuzz_mont.txt 2>&1
+FUZZ_SEED=61 FUZZ_SECONDS=200 timeout 500 python tools/fuzz_gpu.py lindiv divrem vec sharded > $OUT/fuzz_callers.txt 2>&1
 tail -2 $OUT/err
 python - <<PY
 import json,glob
