@@ -74,9 +74,8 @@ template <int MODE, bool APPLY>
 constexpr int lindiv_lds_words() { return 8 + ((MODE & LINDIV_DLOAD) && !APPLY ? 0 : LINDIV_CHUNK + 256); }
 
 // the lane's run e[m] = c[base + PL tid + m] (ZERO beyond d); NL lanes per workgroup
-template <int MODE, int NL = 256, class Ctx>
-RONK_HD void lindiv_load_run(const u64* __restrict__ c, size_t d, size_t base, u32 tid, u64* buf, u64 (&e)[LINDIV_PL], Ctx& cx) {
-  constexpr int PL = LINDIV_PL;
+template <int MODE, int NL = 256, int PL = LINDIV_PL, class Ctx>
+RONK_HD void lindiv_load_run(const u64* __restrict__ c, size_t d, size_t base, u32 tid, u64* buf, u64 (&e)[PL], Ctx& cx) {
   const bool full = base + NL * PL <= d;
   if constexpr ((MODE & LINDIV_DLOAD) != 0) {
     const size_t i0 = base + (size_t)PL * tid;
@@ -224,10 +223,22 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
 // it; every wait is bounded (the context's lb_wait gives up after 50 ms) and a workgroup whose wait ran out recomputes the chunk
 // sums above it from the coefficients (slow, correct) -- which is why the entry point keeps the two-launch form for a quotient
 // written over the dividend.  The array of the NEXT call is cleared here (two arrays per workspace slot, used alternately).
+// Compile-time forms (A/B builds; profiles/r06_lindiv_one.txt): 16 coefficients per lane (one workgroup per CU, 4 waves per SIMD, half
+// the per-lane scan overhead per coefficient) is no faster at 2^22 -- 21.4 us with direct loads, 24.0 us with the runs filled through
+// the LDS image -- and much slower below (2^21: 17.8 us against 14.2: 128 workgroups leave half the CUs idle), so 8 per lane with
+// 16-byte direct loads is what ships: the instruction count is not what binds a one-round launch.
+#ifndef RONK_LINDIV1_PL
+#define RONK_LINDIV1_PL 8
+#endif
+#ifndef RONK_LINDIV1_DIRECT
+#define RONK_LINDIV1_DIRECT 1
+#endif
 constexpr int LINDIV1_NL = 1024;
 constexpr int LINDIV1_NW = LINDIV1_NL / 64;
-constexpr int LINDIV1_CHUNK = LINDIV1_NL * LINDIV_PL;
-constexpr u32 LINDIV1_MAX_CHUNKS = 512;
+constexpr int LINDIV1_PL = RONK_LINDIV1_PL;             // coefficients per lane
+constexpr int LINDIV1_CHUNK = LINDIV1_NL * LINDIV1_PL;
+constexpr u32 LINDIV1_MAX_CHUNKS = LINDIV1_PL == 16 ? 256 : 512;   // resident at once: one / two workgroups per CU
+constexpr bool LINDIV1_DIRECT = RONK_LINDIV1_DIRECT != 0;          // 16-byte loads of the lanes' runs instead of the LDS image
 constexpr u64 LINDIV_LB_EMPTY = ~(u64)0;
 constexpr int LINDIV1_STREAM = 2;   // lindiv1_chunk_scan: MODE of the recompute path
 constexpr int LINDIV1_SC = 40;   // LDS words ahead of the image: 16 wavefront sums, 16 carry partials, flag, broadcast word
@@ -248,7 +259,7 @@ struct LinDiv1Tab {
 };
 
 inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Tab* t) {
-  const int pl = LINDIV_PL;
+  const int pl = LINDIV1_PL;
   auto mulm = [p](u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % p); };
   auto powm = [&](u64 a, u64 e) { u64 r = 1 % p; while (e) { if (e & 1) r = mulm(r, a); a = mulm(a, a); e >>= 1; } return r; };
   t->z = z % p;
@@ -277,8 +288,8 @@ inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Ta
 // next barrier.
 template <int MODE, class Ops, class Ctx>
 RONK_HD void lindiv1_chunk_scan(const Ops& ops, const u64* __restrict__ c, size_t d, u32 b, const LinDiv1Tab& tab, u64* sc,
-                                u64 (&e)[LINDIV_PL], u64* Uout, u64* Cout, Ctx& cx) {
-  constexpr int PL = LINDIV_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
+                                u64 (&e)[LINDIV1_PL], u64* Uout, u64* Cout, Ctx& cx) {
+  constexpr int PL = LINDIV1_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
   const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
   const u64 zup = tab.zp[64 - lane];
   const u64 z = tab.z;
@@ -289,7 +300,7 @@ RONK_HD void lindiv1_chunk_scan(const Ops& ops, const u64* __restrict__ c, size_
     U = 0;
     for (int m = PL - 1; m >= 0; m--) U = ops.add(ops.mul(U, z), i0 + m < d ? c[i0 + m] : 0);
   } else {
-    lindiv_load_run<MODE, NL>(c, d, (size_t)b * (NL * PL), tid, sc + LINDIV1_SC, e, cx);
+    lindiv_load_run<MODE, NL, PL>(c, d, (size_t)b * (NL * PL), tid, sc + LINDIV1_SC, e, cx);
     U = e[PL - 1];
 #pragma unroll
     for (int m = PL - 2; m >= 0; m--) U = ops.add(ops.mul(U, z), e[m]);
@@ -319,7 +330,7 @@ RONK_HD void lindiv1_chunk_scan(const Ops& ops, const u64* __restrict__ c, size_
 template <int MODE, class Ops, class Ctx>
 RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d, const LinDiv1Tab& tab, u64* lb_cur, u64* lb_next,
                              u32 lb_words, u32 nchunks, u64* __restrict__ quot, u64* __restrict__ rem, Ctx& cx) {
-  constexpr int PL = LINDIV_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
+  constexpr int PL = LINDIV1_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
   const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
   const u32 b = nchunks - 1 - cx.bid();
   u64* sc = cx.lds();
@@ -449,7 +460,7 @@ __global__ void __launch_bounds__(256) lindiv_apply_kernel2(Ops ops, const u64* 
 
 // 8 wavefronts per SIMD: two workgroups per CU, LINDIV1_MAX_CHUNKS resident at once
 template <int MODE, class Ops>
-__global__ void __launch_bounds__(LINDIV1_NL, 8) lindiv_one_kernel(Ops ops, const u64* __restrict__ c, size_t d, LinDiv1Tab tab,
+__global__ void __launch_bounds__(LINDIV1_NL, LINDIV1_PL == 16 ? 4 : 8) lindiv_one_kernel(Ops ops, const u64* __restrict__ c, size_t d, LinDiv1Tab tab,
                                                                    u64* lb_cur, u64* lb_next, u32 lb_words,
                                                                    u64* __restrict__ quot, u64* __restrict__ rem) {
   __shared__ __attribute__((aligned(16))) u64 lds[lindiv1_lds_words()];

@@ -387,15 +387,15 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
     const bool overlap1 = d_quot < d_c + d && d_c < d_quot + d;
     // A 16-byte aligned dividend only: the form that fills the runs through the LDS image does not fit 64 VGPRs.
     // From 2^20 coefficients up: below, two launches are faster (measured: lindiv_kernels.h); RONK_LINDIV_ONE=2 lifts the floor.
-    if (g_lindiv_one && direct && (nch1 > 128 || g_lindiv_one == 2) && nch1 <= LINDIV1_MAX_CHUNKS && !overlap1 && !g_no_onepass_scans &&
-        !stream_is_capturing(s)) {
+    if (g_lindiv_one && (direct || !LINDIV1_DIRECT) && (d > ((size_t)1 << 20) || g_lindiv_one == 2) && nch1 <= LINDIV1_MAX_CHUNKS && !overlap1 &&
+        !g_no_onepass_scans && !stream_is_capturing(s)) {
       LinDiv1Tab tab1;
       make_lindiv1_tab(p, z, b1inv, &tab1);
       WsLease ws;
       RCHK(ws.acquire(64, s));
       u64 *cur, *next;
       ws.lb_arrays(&cur, &next);
-      RCHK(lindiv1_launch<LINDIV_DLOAD>(f, d_c, d, tab1, cur, next, (u32)nch1, d_quot, d_rem, s));
+      RCHK(lindiv1_launch<LINDIV1_DIRECT ? LINDIV_DLOAD : 0>(f, d_c, d, tab1, cur, next, (u32)nch1, d_quot, d_rem, s));
       ws.lb_commit();
       return RONK_OK;
     }

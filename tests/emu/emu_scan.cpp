@@ -201,7 +201,7 @@ int main(int argc, char** argv) {
       if (oq[j] != quot[j]) { printf("FAIL vs orc_poly_divrem at %zu\n", j); return 1; }
     if (orr[0] != rem) { printf("FAIL remainder vs orc_poly_divrem\n"); return 1; }
   }
-  printf("OK p=%llu d=%zu pl=%d direct=%d %s chunks=%zu\n", (unsigned long long)p, d, pl, direct, one ? (lb_fail ? "one-launch/recompute" : "one-launch") : "two-launch",
+  printf("OK p=%llu d=%zu pl=%d direct=%d %s chunks=%zu\n", (unsigned long long)p, d, one ? LINDIV1_PL : pl, direct, one ? (lb_fail ? "one-launch/recompute" : "one-launch") : "two-launch",
          one ? nch1 : nch);
   return 0;
 }
