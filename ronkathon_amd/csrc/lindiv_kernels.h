@@ -208,17 +208,21 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
 // The two launches above read the dividend twice (24 + 2/PL bytes per coefficient against 16 algorithmic).  Here a workgroup keeps
 // its chunk in registers while the chunk sums travel: workgroups of NL = 1024 lanes x PL = 8 coefficients (chunks of 8192; at most
 // LINDIV1_MAX_CHUNKS = 512 per call = 2^22 coefficients, all resident at two workgroups per CU), and
-//   1  the lanes' Horner values, the suffix scan over the wavefront (cross-lane network) and over the 16 wavefront sums (one
-//      barrier): W_t, H_b = W_0 -- published with ONE agent-scope write-through store into the call's look-back array;
+//   1  the lanes' Horner values U_t, weighted by z^(PL t), and their suffix SUMS over the wavefront (cross-lane network) and over the
+//      16 wavefront sums (one barrier): additions only (lindiv1_chunk_sums) -- H_b published with ONE agent-scope write-through
+//      store into the call's look-back array, before any lane has un-weighted its own sum (one product per lane, afterwards);
 //   2  the carry G_(b+1) = sum_{j > b} H_j Y^(j-b-1): lane t polls entry b+1+t (agent-scope loads; "not there yet" = 2^64 - 1, no
 //      canonical residue) -- ONE entry per lane, 512 x 8 polled wavefront requests per round against the 64 k of the round-2
 //      one-launch form (scan_kernels.h lindiv_onepass_kernel: 2048 workgroups x 8 gathers; its waits were what made it slower);
 //   3  the recurrence down the lane's run and the coalesced store through the LDS image, as in lindiv_apply_body.
-// Measured (round 6, profiles/r06_lindiv_one.txt): 2^22 coefficients 22.3-23.0 -> 21.4-21.7 us per call, 2^21 14.5 -> 12.6-14.1, 2^20
-// 11.2 -> 11.5 (slower: the entry point keeps two launches up to 2^20).  Less than the 16 / 24 traffic ratio promises, and the
-// variants that skip phases say why -- load + all arithmetic 13.3 us, + stores 18.6, + the wait 21.5: with every chunk resident the
-// whole device loads, computes and stores in lock-step (ONE round: nothing overlaps the arithmetic or the hand-off), where the second
-// of two launches streams.
+// Measured (round 6, profiles/r06_lindiv_one.txt; two launches -> one): 2^22 coefficients 22.3-23.2 -> 19.6-19.9 us per call, 2^21
+// 14.6-16.2 -> 11.9, 2^20 11.1 -> 10.9, 2^19 9.9 -> 10.3 (the entry point keeps two launches below 2^20).  Three steps: the first
+// version scanned the unweighted values (a field product per scan step: ten dependent products on the way to H_b) -- 21.6 us; the
+// weighted additive scans -- 20.2 us at 2^22 but SLOWER below (2^20: 11.6 -> 12.7 us) until the per-lane table entries that are not
+// on the way to H_b were requested after H_b is out: per-lane reads of the kernel-argument segment are the slowest loads of the
+// kernel, and five of them ahead of the first product cost more than the products saved.  Variants that skip phases (first version):
+// load + all arithmetic 13.3 us, + stores 18.6, + the wait 21.5: with every chunk resident the whole device loads, computes and
+// stores in lock-step (ONE round: nothing overlaps the arithmetic or the hand-off), where the second of two launches streams.
 // Nothing can deadlock: workgroup i takes chunk nchunks-1-i and waits for HIGHER chunks only, i.e. for workgroups dispatched before
 // it; every wait is bounded (the context's lb_wait gives up after 50 ms) and a workgroup whose wait ran out recomputes the chunk
 // sums above it from the coefficients (slow, correct) -- which is why the entry point keeps the two-launch form for a quotient
@@ -247,10 +251,10 @@ constexpr int lindiv1_lds_words() { return LINDIV1_SC + LINDIV1_CHUNK + LINDIV1_
 struct LinDiv1Tab {
   u64 z;
   u64 scale;      // 1/b1
-  u64 zs[6];      // z^(PL 2^s): the scan inside a wavefront
-  u64 zx[4];      // z^(64 PL 2^s): the scan over the wavefront sums
   u64 zp[65];     // z^(PL k), k <= 64
   u64 zw[16];     // z^(64 PL k)
+  u64 zpinv[65];  // z^(-PL k), k <= 64
+  u64 zwinv[16];  // z^(-64 PL k)
   u64 Y;          // z^(NL PL): one chunk
   u64 YA[16];     // Y^i
   u64 YB[16];     // Y^(16 i)
@@ -258,6 +262,7 @@ struct LinDiv1Tab {
   u64 test_flags; // bit 0: every wait fails at once (the recompute path under test)
 };
 
+// p prime, z != 0 (mod p): the scans below run on values weighted by powers of z and need the inverse powers
 inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Tab* t) {
   const int pl = LINDIV1_PL;
   auto mulm = [p](u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % p); };
@@ -265,15 +270,13 @@ inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Ta
   t->z = z % p;
   t->scale = scale;
   t->test_flags = test_flags;
-  const u64 zpl = powm(t->z, (u64)pl);
-  u64 y = 1 % p;
-  for (int k = 0; k <= 64; k++) { t->zp[k] = y; y = mulm(y, zpl); }
-  for (int s = 0; s < 6; s++) t->zs[s] = t->zp[1 << s];
-  const u64 zwave = t->zp[64];                            // z^(64 pl)
-  y = 1 % p;
-  for (int k = 0; k < 16; k++) { t->zw[k] = y; y = mulm(y, zwave); }
+  const u64 zpl = powm(t->z, (u64)pl), zpli = powm(zpl, p - 2);
+  u64 y = 1 % p, yi = 1 % p;
+  for (int k = 0; k <= 64; k++) { t->zp[k] = y; t->zpinv[k] = yi; y = mulm(y, zpl); yi = mulm(yi, zpli); }
+  const u64 zwave = t->zp[64], zwavei = t->zpinv[64];     // z^(+-64 pl)
+  y = 1 % p; yi = 1 % p;
+  for (int k = 0; k < 16; k++) { t->zw[k] = y; t->zwinv[k] = yi; y = mulm(y, zwave); yi = mulm(yi, zwavei); }
   t->Y = y;                                               // z^(1024 pl)
-  for (int s = 0; s < 4; s++) t->zx[s] = t->zw[1 << s];
   const u64 Y16 = powm(t->Y, 16);
   u64 cc = 1 % p, dd = 1 % p;
   for (int i = 0; i < 16; i++) {
@@ -283,15 +286,18 @@ inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Ta
   t->YC[0] = 1 % p; t->YC[1] = powm(Y16, 16);
 }
 
-// steps 1 of the list above for chunk b: returns the lane's W_t (U) and the value C of the chunk's suffix that starts behind the
-// lane's wavefront.  One barrier (two when the run goes through the LDS image); the caller must not touch sc[0 .. NW) before the
-// next barrier.
+// Step 1 of the list above for chunk b, as ADDITIVE scans of weighted values: with V_t = U_t z^(PL t) (t = the lane's index in the
+// chunk, U_t = the value of its run at z) the suffix sums F_t = sum_{s >= t} V_s need additions only -- six cross-lane steps inside
+// the wavefront, the 16 wavefront sums through LDS, four more steps -- where the scan of the unweighted values pays a field product
+// per step; F_0 = H_b is there BEFORE any lane has un-weighted anything (it is what the other workgroups wait for), and a lane needs
+// one product, W_(t+1) = z^(-PL (t+1)) F_(t+1), instead of ten.  `wgt` = z^(PL t).  Returns F_(t+1) (ZERO behind the last lane) and
+// H_b (every lane).  The lane's run e[] is the caller's (MODE != LINDIV1_STREAM).  One barrier; the caller must not touch
+// sc[0 .. NW) before the next barrier.
 template <int MODE, class Ops, class Ctx>
-RONK_HD void lindiv1_chunk_scan(const Ops& ops, const u64* __restrict__ c, size_t d, u32 b, const LinDiv1Tab& tab, u64* sc,
-                                u64 (&e)[LINDIV1_PL], u64* Uout, u64* Cout, Ctx& cx) {
+RONK_HD void lindiv1_chunk_sums(const Ops& ops, const u64* __restrict__ c, size_t d, u32 b, const LinDiv1Tab& tab, u64 wgt, u64* sc,
+                                u64 (&e)[LINDIV1_PL], u64* Fn_out, u64* H_out, Ctx& cx) {
   constexpr int PL = LINDIV1_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
   const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
-  const u64 zup = tab.zp[64 - lane];
   const u64 z = tab.z;
   u64 U;
   if constexpr (MODE == LINDIV1_STREAM) {
@@ -300,31 +306,34 @@ RONK_HD void lindiv1_chunk_scan(const Ops& ops, const u64* __restrict__ c, size_
     U = 0;
     for (int m = PL - 1; m >= 0; m--) U = ops.add(ops.mul(U, z), i0 + m < d ? c[i0 + m] : 0);
   } else {
-    lindiv_load_run<MODE, NL, PL>(c, d, (size_t)b * (NL * PL), tid, sc + LINDIV1_SC, e, cx);
+    // (the run was loaded by the caller: lindiv_one_body issues those loads before anything else)
     U = e[PL - 1];
 #pragma unroll
     for (int m = PL - 2; m >= 0; m--) U = ops.add(ops.mul(U, z), e[m]);
   }
+  u64 A = ops.mul(U, wgt);
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     const u32 off = 1u << s;
-    const u64 up = cx.shfl_down(U, off);
-    if (lane + off < 64) U = ops.add(U, ops.mul(tab.zs[s], up));
+    const u64 up = cx.shfl_down(A, off);
+    if (lane + off < 64) A = ops.add(A, up);
   }
-  if (lane == 0) sc[w] = U;
+  if (lane == 0) sc[w] = A;
   cx.barrier();
-  // V_k = T_k + z^(64 PL) V_(k+1): the chunk's suffix from the start of wavefront k (every wavefront computes all 16)
-  u64 V = lane < (u32)NW ? sc[lane] : 0;
+  // S_k = sum of the wavefront sums k, k+1, ... (every wavefront computes all 16)
+  u64 S = lane < (u32)NW ? sc[lane] : 0;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const u32 off = 1u << s;
-    const u64 up = cx.shfl_down(V, off);
-    if (lane + off < (u32)NW) V = ops.add(V, ops.mul(tab.zx[s], up));
+    const u64 up = cx.shfl_down(S, off);
+    if (lane + off < (u32)NW) S = ops.add(S, up);
   }
-  const u64 Vn = cx.shfl(V, w + 1 < (u32)NW ? w + 1 : 0);
-  const u64 C = w + 1 < (u32)NW ? Vn : 0;
-  *Uout = ops.add(U, ops.mul(zup, C));
-  *Cout = C;
+  const u64 Sn_raw = cx.shfl(S, w + 1 < (u32)NW ? w + 1 : 0);
+  const u64 Sn = w + 1 < (u32)NW ? Sn_raw : 0;            // everything behind this wavefront
+  *H_out = cx.shfl(S, 0);
+  u64 An = cx.shfl_down(A, 1);
+  if (lane == 63) An = 0;
+  *Fn_out = ops.add(An, Sn);
 }
 
 template <int MODE, class Ops, class Ctx>
@@ -338,13 +347,17 @@ RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d
   const size_t base = (size_t)b * (NL * PL);
   const bool full = base + NL * PL <= d;
   for (u32 i = cx.bid() * NL + tid; i < lb_words; i += nchunks * NL) lb_next[i] = LINDIV_LB_EMPTY;
-  u64 e[PL], U, C;
-  lindiv1_chunk_scan<MODE>(ops, c, d, b, tab, sc, e, &U, &C, cx);
-  if (tid == 0) cx.lb_store(&lb_cur[b], U);               // H_b = W_0
-  u64 wn = cx.shfl_down(U, 1);                            // W_(t+1)
-  if (lane == 63) wn = C;
-  // the other per-lane table entries, requested before the wait
-  const u64 zpk = ops.mul(tab.zp[63 - lane], tab.zw[NW - 1 - w]);   // z^(PL (NL - 1 - t))
+  // Order of the loads (one in-order counter for all of them; per-lane table entries come out of the kernel-argument segment, the
+  // slowest memory a kernel reads): only the ONE entry the path to H_b needs is requested ahead of the run; the four that serve the
+  // carry and the way back are requested once H_b is out, their trip passes under the look-back wait.  (All five requested up
+  // front: 2^20 coefficients 11.6 -> 12.7 us, 2^21 12.6 -> 14.2 us.)
+  const u64 t_zp = tab.zp[lane];
+  u64 e[PL], Fn, H;
+  lindiv_load_run<MODE, NL, PL>(c, d, base, tid, buf, e, cx);
+  const u64 wgt = ops.mul(t_zp, tab.zw[w]);                         // z^(PL t)
+  lindiv1_chunk_sums<MODE>(ops, c, d, b, tab, wgt, sc, e, &Fn, &H, cx);
+  if (tid == 0) cx.lb_store(&lb_cur[b], H);
+  const u64 unw = ops.mul(tab.zpinv[lane + 1], tab.zwinv[w]);       // z^(-PL (t + 1))
   const u64 yt = ops.mul(ops.mul(tab.YA[tid & 15], tab.YB[(tid >> 4) & 15]), tab.YC[(tid >> 8) & 1]);
   // carry: lane t takes H_(b+1+t) Y^t
   const u32 j = b + 1 + tid;
@@ -369,17 +382,17 @@ RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d
   } else {
     // somebody never showed up: Horner over the chunk sums above b, every one recomputed here from the coefficients
     for (u32 jj = nchunks - 1; jj > b; jj--) {
-      u64 U2, C2;
+      u64 F2, H2;
       cx.barrier();
-      lindiv1_chunk_scan<LINDIV1_STREAM>(ops, c, d, jj, tab, sc, e, &U2, &C2, cx);
-      if (tid == 0) sc[2 * NW + 1] = U2;
-      cx.barrier();
-      cin = ops.add(ops.mul(cin, tab.Y), sc[2 * NW + 1]);
+      lindiv1_chunk_sums<LINDIV1_STREAM>(ops, c, d, jj, tab, wgt, sc, e, &F2, &H2, cx);
+      cin = ops.add(ops.mul(cin, tab.Y), H2);
     }
     cx.barrier();
   }
-  if (b == 0 && tid == 0 && rem) *rem = ops.add(U, ops.mul(tab.Y, cin));   // c(z) = H_0 + Y G_1
-  u64 r = ops.add(wn, ops.mul(zpk, cin));
+  const u64 ycin = ops.mul(tab.Y, cin);
+  if (b == 0 && tid == 0 && rem) *rem = ops.add(H, ycin);            // c(z) = H_0 + Y G_1
+  // S(first coefficient of lane t+1) = W_(t+1) + z^(PL (NL-1-t)) cin = z^(-PL (t+1)) (F_(t+1) + Y cin)
+  u64 r = ops.mul(unw, ops.add(Fn, ycin));
   const u64 z = tab.z;
   // straight into the LDS image (it is free: since its fill's barrier a lane has read nothing but its own run's words, and the
   // recompute path ends on a barrier) -- eight results held in registers beside the run do not fit 64 VGPRs

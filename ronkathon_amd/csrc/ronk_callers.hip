@@ -256,7 +256,7 @@ static void make_lindiv_tab(u64 p, u64 z, u64 scale, LinDivTab* t) {   // (kept 
   if (lp != p || lz != z || lscale != scale) { lindiv_build_tab(p, z, scale, &last); lp = p; lz = z; lscale = scale; }
   *t = last;
 }
-// the one-launch form (lindiv_kernels.h lindiv_one_kernel): RONK_LINDIV_ONE = 0 never, 1 (default) above 2^20 coefficients, 2 at every size
+// the one-launch form (lindiv_kernels.h lindiv_one_kernel): RONK_LINDIV_ONE = 0 never, 1 (default) from 2^20 coefficients up, 2 at every size
 static const int g_lindiv_one = [] { const char* e = getenv("RONK_LINDIV_ONE"); return e ? atoi(e) : 1; }();
 static void make_lindiv1_tab(u64 p, u64 z, u64 scale, LinDiv1Tab* t) {   // (kept for the next call: see make_horner_tab2)
   static std::mutex mu;
@@ -386,8 +386,9 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
     const size_t nch1 = (d + LINDIV1_CHUNK - 1) / LINDIV1_CHUNK;
     const bool overlap1 = d_quot < d_c + d && d_c < d_quot + d;
     // A 16-byte aligned dividend only: the form that fills the runs through the LDS image does not fit 64 VGPRs.
-    // From 2^20 coefficients up: below, two launches are faster (measured: lindiv_kernels.h); RONK_LINDIV_ONE=2 lifts the floor.
-    if (g_lindiv_one && (direct || !LINDIV1_DIRECT) && (d > ((size_t)1 << 20) || g_lindiv_one == 2) && nch1 <= LINDIV1_MAX_CHUNKS && !overlap1 &&
+    // From 2^20 coefficients up: below, two launches are as fast or faster (measured: lindiv_kernels.h); RONK_LINDIV_ONE=2 lifts the floor.
+    // z != 0: its scans run on values weighted by powers of z (division by b1 x is a shift: the two launches do it).
+    if (g_lindiv_one && z != 0 && (direct || !LINDIV1_DIRECT) && (d >= ((size_t)1 << 20) || g_lindiv_one == 2) && nch1 <= LINDIV1_MAX_CHUNKS && !overlap1 &&
         !g_no_onepass_scans && !stream_is_capturing(s)) {
       LinDiv1Tab tab1;
       make_lindiv1_tab(p, z, b1inv, &tab1);

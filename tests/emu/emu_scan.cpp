@@ -141,7 +141,8 @@ int main(int argc, char** argv) {
   const size_t d = (size_t)strtoull(argv[2], 0, 0);
   const u64 z = strtoull(argv[3], 0, 0) % p, b1 = strtoull(argv[4], 0, 0) % p;
   const int pl = LINDIV_PL, mode = atoi(argv[5]), direct = mode & 1;
-  const bool one = (mode & 2) != 0, lb_fail = (mode & 4) != 0;   // the one-launch form; ... with every look-back wait failing
+  // the one-launch form (z != 0: like the library, which keeps two launches for a divisor b1 x); ... with every look-back wait failing
+  const bool one = (mode & 2) != 0 && z != 0, lb_fail = (mode & 4) != 0;
   u64 seed = argc > 6 ? strtoull(argv[6], 0, 0) : 1;
   if (d == 0 || b1 == 0 || mode < 0 || mode > 7) { printf("bad arguments\n"); return 2; }
   std::vector<u64> cbuf(d + 2), qbuf(d + 2, 0x5555555555555555ull);
@@ -160,7 +161,7 @@ int main(int argc, char** argv) {
   u64 rem = ~0ull;
   g_job = Job{0, pl, direct, p == 0xFFFFFFFF00000001ull, p, c, d, &tab, W.data(), H.data(), (u32)nch, quot, &rem, lds.data(), 0};
   LinDiv1Tab tab1;
-  lindiv1_build_tab(p, z, b1inv, lb_fail ? 1 : 0, &tab1);
+  if (z != 0) lindiv1_build_tab(p, z, b1inv, lb_fail ? 1 : 0, &tab1);
   const size_t nch1 = (d + LINDIV1_CHUNK - 1) / LINDIV1_CHUNK;
   const u32 lbw = (u32)nch1 + 37;                          // (the library's arrays hold LB_WORDS entries; any length >= chunks works)
   std::vector<u64> lbc(lbw, LINDIV_LB_EMPTY), lbn(lbw, 0x1111111111111111ull), lds1(lindiv1_lds_words());
