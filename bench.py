@@ -36,7 +36,7 @@ WORKLOADS = {
     "batch16":     (16, 1024, 16.0 * 1024,   "NTT/s", None),   # config 4: 1024 x 2^16 in one launch pair
     "mul22":       (22, 1,    48.0,          "op/s",  None),   # config 3: 3 transforms of size 2^22, pad/pointwise/truncate fused
     "roundtrip16": (16, 1,    32.0,          "op/s",  None),   # config 2: forward + inverse
-    "open22":      (22, 1,    16.0,          "op/s",  "lindiv_one_kernel (csrc/lindiv_kernels.h; up to 2^20 coefficients: lindiv_scan_kernel + lindiv_apply_kernel2)"),
+    "open22":      (22, 1,    16.0,          "op/s",  "lindiv_one_kernel (csrc/lindiv_kernels.h: one launch up to 2^23 coefficients)"),
     "eval22":      (22, 1,    8.0,           "op/s",  "eval_onepass_kernel (csrc/scan_kernels.h)"),
     "rs16":        (16, 1024, 12.0 * 1024,   "op/s",  None),   # reads n/2, writes n coefficients per codeword
     "vecmul24":    (24, 1,    24.0,          "op/s",  "vec_binary2_kernel<GlOps, VEC_MUL>"),

@@ -221,8 +221,8 @@ int ronk_poly_divrem(uint64_t p, const uint64_t* a, size_t d, const uint64_t* b,
  * divisor b0 + b1*x, b1 != 0, as an affine suffix scan.  d_quot receives d coefficients (the top one ZERO, like the
  * reference's D-long quotient); d_rem (may be NULL) receives ONE element, the remainder's constant coefficient (its
  * other coefficients are ZERO).  d_quot may be d_c itself (the quotient written over the dividend); any other overlap
- * of the two is not allowed.  From 2^20 up to 2^22 coefficients, out of place, with a 16-byte aligned dividend and b0 != 0, the call
- * is ONE launch that moves the algorithmic 16 bytes per coefficient; otherwise two launches (24 bytes).  Asynchronous on
+ * of the two is not allowed.  Up to 2^23 coefficients, out of place, with a 16-byte aligned dividend and b0 != 0, the call is ONE
+ * launch that moves the algorithmic 16 bytes per coefficient; otherwise two launches (24 bytes).  Asynchronous on
  * `stream`.  NOT for hipGraph capture (nor is ronk_poly_eval_dev): the
  * workspace comes from an event-guarded pool whose slot would be baked into the graph while later calls reuse it; capture
  * the plan entry points (ronk_ntt_forward_dev / inverse_dev with a plan the graph owns) instead. */

@@ -206,8 +206,9 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
 
 // ---- ONE launch (round 6): 16 bytes of HBM traffic per coefficient ---------------------------------------------------------------
 // The two launches above read the dividend twice (24 + 2/PL bytes per coefficient against 16 algorithmic).  Here a workgroup keeps
-// its chunk in registers while the chunk sums travel: workgroups of NL = 1024 lanes x PL = 8 coefficients (chunks of 8192; at most
-// LINDIV1_MAX_CHUNKS = 512 per call = 2^22 coefficients, all resident at two workgroups per CU), and
+// its chunk in registers while the chunk sums travel: workgroups of NL = 1024 lanes x PL = 4 or 8 coefficients (chunks of 4096 / 8192;
+// two workgroups per CU, 512 resident at once; at most LINDIV1_MAX_CHUNKS = 1024 per call = one look-back entry per lane = 2^23
+// coefficients at 8 per lane -- beyond 512 chunks the workgroups enter in two rounds), and
 //   1  the lanes' Horner values U_t, weighted by z^(PL t), and their suffix SUMS over the wavefront (cross-lane network) and over the
 //      16 wavefront sums (one barrier): additions only (lindiv1_chunk_sums) -- H_b published with ONE agent-scope write-through
 //      store into the call's look-back array, before any lane has un-weighted its own sum (one product per lane, afterwards);
@@ -215,38 +216,37 @@ RONK_HD void lindiv_apply_body(const Ops& ops, const u64* __restrict__ c, size_t
 //      canonical residue) -- ONE entry per lane, 512 x 8 polled wavefront requests per round against the 64 k of the round-2
 //      one-launch form (scan_kernels.h lindiv_onepass_kernel: 2048 workgroups x 8 gathers; its waits were what made it slower);
 //   3  the recurrence down the lane's run and the coalesced store through the LDS image, as in lindiv_apply_body.
-// Measured (round 6, profiles/r06_lindiv_one.txt; two launches -> one): 2^22 coefficients 22.3-23.2 -> 19.6-19.9 us per call, 2^21
-// 14.6-16.2 -> 11.9, 2^20 11.1 -> 10.9, 2^19 9.9 -> 10.3 (the entry point keeps two launches below 2^20).  Three steps: the first
-// version scanned the unweighted values (a field product per scan step: ten dependent products on the way to H_b) -- 21.6 us; the
+// Measured (round 6, profiles/r06_lindiv_one.txt; two launches -> one, at every size): 2^16 9.5 -> 7.8 us, 2^20 11.2 -> 8.9, 2^21
+// 14.6 -> 11.8, 2^22 22.4 -> 19.6 (0.43 of the roofline), 2^23 40.2 -> 34.9 us (0.48: two rounds stream).  Steps: the first version
+// scanned the unweighted values (a field product per scan step: ten dependent products on the way to H_b) -- 21.6 us at 2^22; the
 // weighted additive scans -- 20.2 us at 2^22 but SLOWER below (2^20: 11.6 -> 12.7 us) until the per-lane table entries that are not
 // on the way to H_b were requested after H_b is out: per-lane reads of the kernel-argument segment are the slowest loads of the
-// kernel, and five of them ahead of the first product cost more than the products saved.  Variants that skip phases (first version):
-// load + all arithmetic 13.3 us, + stores 18.6, + the wait 21.5: with every chunk resident the whole device loads, computes and
-// stores in lock-step (ONE round: nothing overlaps the arithmetic or the hand-off), where the second of two launches streams.
+// kernel, and five of them ahead of the first product cost more than the products saved; 4 coefficients per lane below 1.5 M
+// coefficients (2^20: 10.9 -> 8.9 us: every CU gets a workgroup).  Variants that skip phases (first version, 2^22): load + all
+// arithmetic 13.3 us, + stores 18.6, + the wait 21.5: with every chunk resident the whole device loads, computes and stores in
+// lock-step (ONE round: nothing overlaps the arithmetic or the hand-off), where the second of two launches streams.
 // Nothing can deadlock: workgroup i takes chunk nchunks-1-i and waits for HIGHER chunks only, i.e. for workgroups dispatched before
 // it; every wait is bounded (the context's lb_wait gives up after 50 ms) and a workgroup whose wait ran out recomputes the chunk
-// sums above it from the coefficients (slow, correct) -- which is why the entry point keeps the two-launch form for a quotient
+// sums above it from the coefficients (slow, correct; with more chunks than resident workgroups the argument is the same: the lowest
+// unfinished workgroup never waits for one that is not resident) -- which is why the entry point keeps the two-launch form for a quotient
 // written over the dividend.  The array of the NEXT call is cleared here (two arrays per workspace slot, used alternately).
-// Compile-time forms (A/B builds; profiles/r06_lindiv_one.txt): 16 coefficients per lane (one workgroup per CU, 4 waves per SIMD, half
-// the per-lane scan overhead per coefficient) is no faster at 2^22 -- 21.4 us with direct loads, 24.0 us with the runs filled through
-// the LDS image -- and much slower below (2^21: 17.8 us against 14.2: 128 workgroups leave half the CUs idle), so 8 per lane with
-// 16-byte direct loads is what ships: the instruction count is not what binds a one-round launch.
-#ifndef RONK_LINDIV1_PL
-#define RONK_LINDIV1_PL 8
-#endif
+// Coefficients per lane PL (a template parameter; the entry point picks it by size, profiles/r06_lindiv_one.txt): 8 from 1.5 M
+// coefficients up (2^22: 19.6 us; 4 per lane -- two rounds of resident workgroups -- 23.8 us), 4 below (2^20: 8.9 us against 10.9 us
+// with 8 per lane, which leaves half the CUs without a workgroup; two launches: 11.1 us).  16 per lane (one workgroup per CU, half the
+// per-lane overhead per coefficient) is no faster at 2^22 -- 21.4 us with direct loads, 24.0 us with the runs filled through the LDS
+// image -- and much slower below: the instruction count is not what binds a one-round launch.
 #ifndef RONK_LINDIV1_DIRECT
 #define RONK_LINDIV1_DIRECT 1
 #endif
 constexpr int LINDIV1_NL = 1024;
 constexpr int LINDIV1_NW = LINDIV1_NL / 64;
-constexpr int LINDIV1_PL = RONK_LINDIV1_PL;             // coefficients per lane
-constexpr int LINDIV1_CHUNK = LINDIV1_NL * LINDIV1_PL;
-constexpr u32 LINDIV1_MAX_CHUNKS = LINDIV1_PL == 16 ? 256 : 512;   // resident at once: one / two workgroups per CU
+constexpr u32 LINDIV1_RESIDENT = 512;                              // workgroups resident at once (two per CU)
+constexpr u32 LINDIV1_MAX_CHUNKS = LINDIV1_NL;                     // one look-back entry per lane: 2^23 coefficients at 8 per lane
 constexpr bool LINDIV1_DIRECT = RONK_LINDIV1_DIRECT != 0;          // 16-byte loads of the lanes' runs instead of the LDS image
 constexpr u64 LINDIV_LB_EMPTY = ~(u64)0;
 constexpr int LINDIV1_STREAM = 2;   // lindiv1_chunk_scan: MODE of the recompute path
 constexpr int LINDIV1_SC = 40;   // LDS words ahead of the image: 16 wavefront sums, 16 carry partials, flag, broadcast word
-constexpr int lindiv1_lds_words() { return LINDIV1_SC + LINDIV1_CHUNK + LINDIV1_NL; }
+constexpr int lindiv1_lds_words(int pl) { return LINDIV1_SC + LINDIV1_NL * pl + LINDIV1_NL; }
 
 struct LinDiv1Tab {
   u64 z;
@@ -258,13 +258,12 @@ struct LinDiv1Tab {
   u64 Y;          // z^(NL PL): one chunk
   u64 YA[16];     // Y^i
   u64 YB[16];     // Y^(16 i)
-  u64 YC[2];      // Y^(256 i):   Y^t = YA[t & 15] YB[(t >> 4) & 15] YC[t >> 8], t < 512
+  u64 YC[4];      // Y^(256 i):   Y^t = YA[t & 15] YB[(t >> 4) & 15] YC[t >> 8], t < 1024
   u64 test_flags; // bit 0: every wait fails at once (the recompute path under test)
 };
 
 // p prime, z != 0 (mod p): the scans below run on values weighted by powers of z and need the inverse powers
-inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Tab* t) {
-  const int pl = LINDIV1_PL;
+inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, int pl, LinDiv1Tab* t) {
   auto mulm = [p](u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % p); };
   auto powm = [&](u64 a, u64 e) { u64 r = 1 % p; while (e) { if (e & 1) r = mulm(r, a); a = mulm(a, a); e >>= 1; } return r; };
   t->z = z % p;
@@ -284,6 +283,7 @@ inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Ta
     cc = mulm(cc, t->Y); dd = mulm(dd, Y16);
   }
   t->YC[0] = 1 % p; t->YC[1] = powm(Y16, 16);
+  t->YC[2] = mulm(t->YC[1], t->YC[1]); t->YC[3] = mulm(t->YC[2], t->YC[1]);
 }
 
 // Step 1 of the list above for chunk b, as ADDITIVE scans of weighted values: with V_t = U_t z^(PL t) (t = the lane's index in the
@@ -293,10 +293,10 @@ inline void lindiv1_build_tab(u64 p, u64 z, u64 scale, u64 test_flags, LinDiv1Ta
 // one product, W_(t+1) = z^(-PL (t+1)) F_(t+1), instead of ten.  `wgt` = z^(PL t).  Returns F_(t+1) (ZERO behind the last lane) and
 // H_b (every lane).  The lane's run e[] is the caller's (MODE != LINDIV1_STREAM).  One barrier; the caller must not touch
 // sc[0 .. NW) before the next barrier.
-template <int MODE, class Ops, class Ctx>
+template <int MODE, int PL, class Ops, class Ctx>
 RONK_HD void lindiv1_chunk_sums(const Ops& ops, const u64* __restrict__ c, size_t d, u32 b, const LinDiv1Tab& tab, u64 wgt, u64* sc,
-                                u64 (&e)[LINDIV1_PL], u64* Fn_out, u64* H_out, Ctx& cx) {
-  constexpr int PL = LINDIV1_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
+                                u64 (&e)[PL], u64* Fn_out, u64* H_out, Ctx& cx) {
+  constexpr int NL = LINDIV1_NL, NW = LINDIV1_NW;
   const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
   const u64 z = tab.z;
   u64 U;
@@ -336,10 +336,10 @@ RONK_HD void lindiv1_chunk_sums(const Ops& ops, const u64* __restrict__ c, size_
   *Fn_out = ops.add(An, Sn);
 }
 
-template <int MODE, class Ops, class Ctx>
+template <int MODE, int PL, class Ops, class Ctx>
 RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d, const LinDiv1Tab& tab, u64* lb_cur, u64* lb_next,
                              u32 lb_words, u32 nchunks, u64* __restrict__ quot, u64* __restrict__ rem, Ctx& cx) {
-  constexpr int PL = LINDIV1_PL, NL = LINDIV1_NL, NW = LINDIV1_NW;
+  constexpr int NL = LINDIV1_NL, NW = LINDIV1_NW;
   const u32 tid = cx.tid(), lane = tid & 63, w = cx.wave();
   const u32 b = nchunks - 1 - cx.bid();
   u64* sc = cx.lds();
@@ -355,10 +355,10 @@ RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d
   u64 e[PL], Fn, H;
   lindiv_load_run<MODE, NL, PL>(c, d, base, tid, buf, e, cx);
   const u64 wgt = ops.mul(t_zp, tab.zw[w]);                         // z^(PL t)
-  lindiv1_chunk_sums<MODE>(ops, c, d, b, tab, wgt, sc, e, &Fn, &H, cx);
+  lindiv1_chunk_sums<MODE, PL>(ops, c, d, b, tab, wgt, sc, e, &Fn, &H, cx);
   if (tid == 0) cx.lb_store(&lb_cur[b], H);
   const u64 unw = ops.mul(tab.zpinv[lane + 1], tab.zwinv[w]);       // z^(-PL (t + 1))
-  const u64 yt = ops.mul(ops.mul(tab.YA[tid & 15], tab.YB[(tid >> 4) & 15]), tab.YC[(tid >> 8) & 1]);
+  const u64 yt = ops.mul(ops.mul(tab.YA[tid & 15], tab.YB[(tid >> 4) & 15]), tab.YC[(tid >> 8) & 3]);
   // carry: lane t takes H_(b+1+t) Y^t
   const u32 j = b + 1 + tid;
   u64 cpart = 0;
@@ -384,7 +384,7 @@ RONK_HD void lindiv_one_body(const Ops& ops, const u64* __restrict__ c, size_t d
     for (u32 jj = nchunks - 1; jj > b; jj--) {
       u64 F2, H2;
       cx.barrier();
-      lindiv1_chunk_sums<LINDIV1_STREAM>(ops, c, d, jj, tab, wgt, sc, e, &F2, &H2, cx);
+      lindiv1_chunk_sums<LINDIV1_STREAM, PL>(ops, c, d, jj, tab, wgt, sc, e, &F2, &H2, cx);
       cin = ops.add(ops.mul(cin, tab.Y), H2);
     }
     cx.barrier();
@@ -471,14 +471,14 @@ __global__ void __launch_bounds__(256) lindiv_apply_kernel2(Ops ops, const u64* 
   lindiv_apply_body<MODE>(ops, c, d, tab, W, H, gridDim.x, quot, rem, cx);
 }
 
-// 8 wavefronts per SIMD: two workgroups per CU, LINDIV1_MAX_CHUNKS resident at once
-template <int MODE, class Ops>
-__global__ void __launch_bounds__(LINDIV1_NL, LINDIV1_PL == 16 ? 4 : 8) lindiv_one_kernel(Ops ops, const u64* __restrict__ c, size_t d, LinDiv1Tab tab,
+// 8 wavefronts per SIMD: two workgroups per CU
+template <int MODE, int PL, class Ops>
+__global__ void __launch_bounds__(LINDIV1_NL, 8) lindiv_one_kernel(Ops ops, const u64* __restrict__ c, size_t d, LinDiv1Tab tab,
                                                                    u64* lb_cur, u64* lb_next, u32 lb_words,
                                                                    u64* __restrict__ quot, u64* __restrict__ rem) {
-  __shared__ __attribute__((aligned(16))) u64 lds[lindiv1_lds_words()];
+  __shared__ __attribute__((aligned(16))) u64 lds[lindiv1_lds_words(PL)];
   LinDivDevCtx cx{lds};
-  lindiv_one_body<MODE>(ops, c, d, tab, lb_cur, lb_next, lb_words, gridDim.x, quot, rem, cx);
+  lindiv_one_body<MODE, PL>(ops, c, d, tab, lb_cur, lb_next, lb_words, gridDim.x, quot, rem, cx);
 }
 
 }  // namespace ronk

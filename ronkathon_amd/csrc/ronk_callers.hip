@@ -256,22 +256,30 @@ static void make_lindiv_tab(u64 p, u64 z, u64 scale, LinDivTab* t) {   // (kept 
   if (lp != p || lz != z || lscale != scale) { lindiv_build_tab(p, z, scale, &last); lp = p; lz = z; lscale = scale; }
   *t = last;
 }
-// the one-launch form (lindiv_kernels.h lindiv_one_kernel): RONK_LINDIV_ONE = 0 never, 1 (default) from 2^20 coefficients up, 2 at every size
+// the one-launch form (lindiv_kernels.h lindiv_one_kernel): RONK_LINDIV_ONE = 0 never, else (default) whenever it applies
 static const int g_lindiv_one = [] { const char* e = getenv("RONK_LINDIV_ONE"); return e ? atoi(e) : 1; }();
-static void make_lindiv1_tab(u64 p, u64 z, u64 scale, LinDiv1Tab* t) {   // (kept for the next call: see make_horner_tab2)
+// RONK_LINDIV_ONE_MAXCH: most chunks of 8192 coefficients it is used for (default: one look-back entry per lane, 1024; 512 = only
+// while every chunk is resident at once)
+static const u32 g_lindiv_one_maxch = [] {
+  const char* e = getenv("RONK_LINDIV_ONE_MAXCH");
+  const long v = e ? atol(e) : (long)LINDIV1_MAX_CHUNKS;
+  return (u32)(v < 1 ? 1 : v > (long)LINDIV1_MAX_CHUNKS ? (long)LINDIV1_MAX_CHUNKS : v);
+}();
+static void make_lindiv1_tab(u64 p, u64 z, u64 scale, int pl, LinDiv1Tab* t) {   // (kept for the next call: see make_horner_tab2)
   static std::mutex mu;
   static LinDiv1Tab last;
   static u64 lp = 0, lz = 0, lscale = 0;
+  static int lpl = 0;
   static const u64 test_flags = [] { const char* e = getenv("RONK_LB_TEST_FLAGS"); return e ? (u64)atoi(e) : (u64)0; }();
   std::lock_guard<std::mutex> lk(mu);
-  if (lp != p || lz != z || lscale != scale) { lindiv1_build_tab(p, z, scale, test_flags, &last); lp = p; lz = z; lscale = scale; }
+  if (lp != p || lz != z || lscale != scale || lpl != pl) { lindiv1_build_tab(p, z, scale, test_flags, pl, &last); lp = p; lz = z; lscale = scale; lpl = pl; }
   *t = last;
 }
 static_assert(LINDIV_LB_EMPTY == LB_EMPTY && LINDIV1_MAX_CHUNKS <= LB_WORDS, "one look-back array convention for every one-launch scan");
-template <int MODE>
+template <int MODE, int PL>
 static int lindiv1_launch(const FieldCtx& f, const u64* d_c, size_t d, const LinDiv1Tab& tab, u64* cur, u64* next, u32 nch,
                           u64* d_quot, u64* d_rem, hipStream_t s) {
-  FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_one_kernel<MODE, decltype(ops)>), dim3(nch), dim3(LINDIV1_NL), 0, s, ops, d_c, d,
+  FIELD_DISPATCH(f, { hipLaunchKernelGGL((lindiv_one_kernel<MODE, PL, decltype(ops)>), dim3(nch), dim3(LINDIV1_NL), 0, s, ops, d_c, d,
                                         tab, cur, next, (u32)LB_WORDS, d_quot, d_rem); });
   HIPCHK(hipGetLastError());
   return RONK_OK;
@@ -380,23 +388,32 @@ extern "C" int ronk_poly_div_linear_dev(uint64_t p, const uint64_t* d_c, size_t 
   const u64 z = h_mulmod((p - b0) % p, b1inv, p);        // -b0 / b1
   if (g_lindiv && d <= (size_t)LINDIV_CHUNK * 4096 && !g_no_fused_scans && !g_onepass_div) {   // lindiv_kernels.h
     const bool direct = g_lindiv == 2 && ((uintptr_t)d_c & 15) == 0;
-    // ONE launch, 16 bytes of traffic per coefficient, up to 2^22 coefficients (every chunk resident).  Not for a quotient written
-    // over the dividend (a workgroup whose wait runs out recomputes chunk sums from the coefficients, which other workgroups may
-    // have overwritten by then) and not under stream capture (the look-back parity is host state).
-    const size_t nch1 = (d + LINDIV1_CHUNK - 1) / LINDIV1_CHUNK;
+    // ONE launch, 16 bytes of traffic per coefficient (lindiv_kernels.h lindiv_one_kernel): 4 coefficients per lane below 1.5 M
+    // coefficients (chunks of 4096: every CU has a workgroup from 2^20 coefficients on), 8 from there to 2^23 (chunks of 8192, at most
+    // one look-back entry per lane; beyond 2^22 the workgroups enter in two rounds, each waiting for earlier ones only).  Measured
+    // against the two launches at every size from 2^16 to 2^23: 7.8 / 9.5 us ... 8.9 / 11.1 (2^20) ... 19.6 / 22.9 (2^22) ... 34.9 /
+    // 41.7 us (profiles/r06_lindiv_one.txt).  Not for a quotient written over the dividend (a workgroup whose wait runs out
+    // recomputes chunk sums from the coefficients, which other workgroups may have overwritten by then), not under stream capture
+    // (the look-back parity is host state), not for an unaligned dividend (the 16-byte run loads; the LDS-image fill does not fit
+    // 64 VGPRs), not for z = 0 (its scans run on values weighted by powers of z; division by b1 x is a shift: the two launches do
+    // it).  RONK_LINDIV_ONE=0: never; RONK_LINDIV_ONE_PL=4 / 8: that many per lane at every size (A/B).
+    static const int pl_forced = [] { const char* e = getenv("RONK_LINDIV_ONE_PL"); const int v = e ? atoi(e) : 0; return v == 4 || v == 8 ? v : 0; }();
+    const int pl1 = pl_forced ? pl_forced : d < ((size_t)3 << 19) ? 4 : 8;
+    const size_t nch1 = (d + (size_t)LINDIV1_NL * pl1 - 1) / ((size_t)LINDIV1_NL * pl1);
     const bool overlap1 = d_quot < d_c + d && d_c < d_quot + d;
-    // A 16-byte aligned dividend only: the form that fills the runs through the LDS image does not fit 64 VGPRs.
-    // From 2^20 coefficients up: below, two launches are as fast or faster (measured: lindiv_kernels.h); RONK_LINDIV_ONE=2 lifts the floor.
-    // z != 0: its scans run on values weighted by powers of z (division by b1 x is a shift: the two launches do it).
-    if (g_lindiv_one && z != 0 && (direct || !LINDIV1_DIRECT) && (d >= ((size_t)1 << 20) || g_lindiv_one == 2) && nch1 <= LINDIV1_MAX_CHUNKS && !overlap1 &&
-        !g_no_onepass_scans && !stream_is_capturing(s)) {
+    if (g_lindiv_one && z != 0 && (direct || !LINDIV1_DIRECT) && nch1 <= g_lindiv_one_maxch && !overlap1 && !g_no_onepass_scans &&
+        !stream_is_capturing(s)) {
       LinDiv1Tab tab1;
-      make_lindiv1_tab(p, z, b1inv, &tab1);
+      make_lindiv1_tab(p, z, b1inv, pl1, &tab1);
       WsLease ws;
       RCHK(ws.acquire(64, s));
       u64 *cur, *next;
       ws.lb_arrays(&cur, &next);
-      RCHK(lindiv1_launch<LINDIV1_DIRECT ? LINDIV_DLOAD : 0>(f, d_c, d, tab1, cur, next, (u32)nch1, d_quot, d_rem, s));
+      constexpr int M1 = LINDIV1_DIRECT ? LINDIV_DLOAD : 0;
+      int rc1;
+      if (pl1 == 4) rc1 = lindiv1_launch<M1, 4>(f, d_c, d, tab1, cur, next, (u32)nch1, d_quot, d_rem, s);
+      else rc1 = lindiv1_launch<M1, 8>(f, d_c, d, tab1, cur, next, (u32)nch1, d_quot, d_rem, s);
+      RCHK(rc1);
       ws.lb_commit();
       return RONK_OK;
     }

@@ -84,14 +84,17 @@ struct FiberCtx {
 struct Job {
   int phase, pl, direct; bool gl; u64 p;
   const u64* c; size_t d; const LinDivTab* tab; u64 *W, *H; u32 nch; u64 *quot, *rem; u64* lds; u32 bid;
-  const LinDiv1Tab* tab1; u64 *lb_cur, *lb_next; u32 lb_words;   // phase 2: the one-launch form
+  const LinDiv1Tab* tab1; u64 *lb_cur, *lb_next; u32 lb_words; int pl1;   // phase 2: the one-launch form
 };
 static Job g_job;
 
 template <int MODE, class Ops>
 static void run_item(const Ops& ops, u32 tid) {
   FiberCtx cx{tid, g_job.bid, g_job.lds};
-  if (g_job.phase == 2) lindiv_one_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab1, g_job.lb_cur, g_job.lb_next, g_job.lb_words, g_job.nch, g_job.quot, g_job.rem, cx);
+  if (g_job.phase == 2) {
+    if (g_job.pl1 == 4) lindiv_one_body<MODE, 4>(ops, g_job.c, g_job.d, *g_job.tab1, g_job.lb_cur, g_job.lb_next, g_job.lb_words, g_job.nch, g_job.quot, g_job.rem, cx);
+    else lindiv_one_body<MODE, 8>(ops, g_job.c, g_job.d, *g_job.tab1, g_job.lb_cur, g_job.lb_next, g_job.lb_words, g_job.nch, g_job.quot, g_job.rem, cx);
+  }
   else if (g_job.phase == 0) lindiv_scan_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab, g_job.W, g_job.H, cx);
   else lindiv_apply_body<MODE>(ops, g_job.c, g_job.d, *g_job.tab, g_job.W, g_job.H, g_job.nch, g_job.quot, g_job.rem, cx);
 }
@@ -161,13 +164,16 @@ int main(int argc, char** argv) {
   u64 rem = ~0ull;
   g_job = Job{0, pl, direct, p == 0xFFFFFFFF00000001ull, p, c, d, &tab, W.data(), H.data(), (u32)nch, quot, &rem, lds.data(), 0};
   LinDiv1Tab tab1;
-  if (z != 0) lindiv1_build_tab(p, z, b1inv, lb_fail ? 1 : 0, &tab1);
-  const size_t nch1 = (d + LINDIV1_CHUNK - 1) / LINDIV1_CHUNK;
+  // coefficients per lane of the one-launch form: the library's rule (4 below 1.5 M coefficients, else 8) unless EMU_LINDIV1_PL says
+  const int pl1 = getenv("EMU_LINDIV1_PL") ? atoi(getenv("EMU_LINDIV1_PL")) : d < ((size_t)3 << 19) ? 4 : 8;
+  if (pl1 != 4 && pl1 != 8) { printf("bad EMU_LINDIV1_PL\n"); return 2; }
+  if (z != 0) lindiv1_build_tab(p, z, b1inv, lb_fail ? 1 : 0, pl1, &tab1);
+  const size_t ch1 = (size_t)LINDIV1_NL * pl1, nch1 = (d + ch1 - 1) / ch1;
   const u32 lbw = (u32)nch1 + 37;                          // (the library's arrays hold LB_WORDS entries; any length >= chunks works)
-  std::vector<u64> lbc(lbw, LINDIV_LB_EMPTY), lbn(lbw, 0x1111111111111111ull), lds1(lindiv1_lds_words());
+  std::vector<u64> lbc(lbw, LINDIV_LB_EMPTY), lbn(lbw, 0x1111111111111111ull), lds1(lindiv1_lds_words(8));
   if (one) {
     if (nch1 > LINDIV1_MAX_CHUNKS) { printf("bad arguments: more than %u chunks\n", LINDIV1_MAX_CHUNKS); return 2; }
-    g_job.phase = 2; g_job.nch = (u32)nch1; g_job.tab1 = &tab1; g_job.lb_cur = lbc.data(); g_job.lb_next = lbn.data(); g_job.lb_words = lbw;
+    g_job.phase = 2; g_job.nch = (u32)nch1; g_job.tab1 = &tab1; g_job.lb_cur = lbc.data(); g_job.lb_next = lbn.data(); g_job.lb_words = lbw; g_job.pl1 = pl1;
     g_job.lds = lds1.data();
     for (u32 bid = 0; bid < nch1; bid++) {                 // dispatch order: workgroup i takes chunk nch1-1-i
       g_job.bid = bid;
@@ -202,7 +208,7 @@ int main(int argc, char** argv) {
       if (oq[j] != quot[j]) { printf("FAIL vs orc_poly_divrem at %zu\n", j); return 1; }
     if (orr[0] != rem) { printf("FAIL remainder vs orc_poly_divrem\n"); return 1; }
   }
-  printf("OK p=%llu d=%zu pl=%d direct=%d %s chunks=%zu\n", (unsigned long long)p, d, one ? LINDIV1_PL : pl, direct, one ? (lb_fail ? "one-launch/recompute" : "one-launch") : "two-launch",
+  printf("OK p=%llu d=%zu pl=%d direct=%d %s chunks=%zu\n", (unsigned long long)p, d, one ? pl1 : pl, direct, one ? (lb_fail ? "one-launch/recompute" : "one-launch") : "two-launch",
          one ? nch1 : nch);
   return 0;
 }

@@ -362,25 +362,28 @@ def test_linear_division_kernels_on_fibers(emu_scan, direct):
     run(emu_scan, GP, 700001, 987654321987, 3, direct, 5)       # 342 chunks: two sums per lane for the low chunks
 
 
+@pytest.mark.parametrize("pl", [4, 8])
 @pytest.mark.parametrize("mode", [2, 3, 6])
-def test_one_launch_linear_division_on_fibers(emu_scan, mode):
-    """lindiv_one_body -- ronk_poly_div_linear_dev's default up to 2^22 coefficients from round 6: ONE launch, the chunk kept in
-    registers while the chunk sums travel through the look-back array (workgroups of 1024 lanes, run in dispatch order here);
-    mode 2 / 3 = through the LDS image / 16-byte direct loads, 6 = every look-back wait fails, so every workgroup recomputes the
-    chunk sums above it (the path a timeout takes on the device).  Lane, wavefront and chunk edges, several hundred chunks (more
-    than 256: the Y^t table's third factor), z = 0 / 1 / p - 1, non-monic divisors, F_101 and F_2; the array of the next call
-    must come back cleared."""
+def test_one_launch_linear_division_on_fibers(emu_scan, mode, pl):
+    """lindiv_one_body -- ronk_poly_div_linear_dev's default up to 2^23 coefficients from round 6: ONE launch, the chunk kept in
+    registers while the chunk sums travel through the look-back array (workgroups of 1024 lanes x 4 or 8 coefficients, run in dispatch
+    order here; suffix sums of values weighted by powers of z: additions only); mode 2 / 3 = through the LDS image / 16-byte direct
+    loads, 6 = every look-back wait fails, so every workgroup recomputes the chunk sums above it (the path a timeout takes on the
+    device).  Lane, wavefront and chunk edges, several hundred chunks (more than 256 and more than 512: the Y^t table's third
+    factor), z = 1 / p - 1 (z = 0 stays with the two launches, as in the library), non-monic divisors, F_101 and F_2; the array of
+    the next call must come back cleared."""
     GP = 0xFFFFFFFF00000001
-    for d in (1, 2, 7, 8, 9, 511, 512, 513, 8191, 8192, 8193, 16384, 70001):
-        run(emu_scan, GP, d, 123456789, 1, mode)
-    run(emu_scan, GP, 9000, GP - 1, 77, mode)
-    run(emu_scan, GP, 9000, 1, 1, mode)
-    run(emu_scan, GP, 9000, 0, 5, mode)
-    run(emu_scan, 101, 25000, 7, 3, mode)
-    run(emu_scan, 101, 300, 0, 1, mode)
-    run(emu_scan, 2, 9000, 1, 1, mode)
+    env = {"EMU_LINDIV1_PL": str(pl)}
+    for d in (1, 2, 7, 8, 9, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193, 16384, 70001):
+        run(emu_scan, GP, d, 123456789, 1, mode, env=env)
+    run(emu_scan, GP, 9000, GP - 1, 77, mode, env=env)
+    run(emu_scan, GP, 9000, 1, 1, mode, env=env)
+    run(emu_scan, GP, 9000, 0, 5, mode, env=env)
+    run(emu_scan, 101, 25000, 7, 3, mode, env=env)
+    run(emu_scan, 101, 300, 0, 1, mode, env=env)
+    run(emu_scan, 2, 9000, 1, 1, mode, env=env)
     if mode != 6:
-        run(emu_scan, GP, 2500001, 987654321987, 3, mode, 5)   # 306 chunks
+        run(emu_scan, GP, 4096 * pl // 4 * 601 + 5, 987654321987, 3, mode, 5, env=env)   # 601 chunks
 
 
 # ---- the long-division kernel (ronkathon_amd/csrc/longdiv_kernel.h) on fibers: tests/emu/emu_longdiv.cpp

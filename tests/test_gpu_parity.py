@@ -840,14 +840,17 @@ def test_scan_paths_fused_and_three_kernel(R, orc):
 
 @pytest.mark.parametrize("env", [{}, {"RONK_ONEPASS_DIV": "1"}, {"RONK_ONEPASS_DIV": "1", "RONK_LB_TEST_FLAGS": "1"},
                                  {"RONK_NO_ONEPASS_SCANS": "1"}, {"RONK_NO_FUSED_SCANS": "1"},
-                                 {"RONK_LINDIV": "l"}, {"RONK_LINDIV": "0"}, {"RONK_LB_TEST_FLAGS": "1"}, {"RONK_LINDIV_ONE": "0"}, {"RONK_LINDIV_ONE": "2"},
-                                 {"RONK_LINDIV_ONE": "2", "RONK_LB_TEST_FLAGS": "1"}])
+                                 {"RONK_LINDIV": "l"}, {"RONK_LINDIV": "0"}, {"RONK_LB_TEST_FLAGS": "1"}, {"RONK_LINDIV_ONE": "0"}, {"RONK_LINDIV_ONE_PL": "4"},
+                                 {"RONK_LINDIV_ONE_PL": "8"}, {"RONK_LINDIV_ONE_PL": "8", "RONK_LB_TEST_FLAGS": "1"},
+                                 {"RONK_LINDIV_ONE_MAXCH": "512"}])
 def test_scan_onepass_variants(R, env):
     """the one-launch evaluate / linear division (look-back through an agent-coherent array), the same with every wait
     forced to give up (the recompute-from-coefficients path that makes the waits bounded), the two- and three-launch
-    forms; the lane-scan division (lindiv_kernels.h): {} = the default, ONE launch of 1024-lane workgroups up to 2^22 coefficients
-    (round 6, lindiv_one_kernel, from 2^20 coefficients up -- RONK_LINDIV_ONE=2: at every size; RONK_LB_TEST_FLAGS=1: its recompute path) and two launches beyond / in place / unaligned;
-    RONK_LINDIV_ONE=0 two launches everywhere, with 16-byte reads of the lanes' runs or with the
+    forms; the lane-scan division (lindiv_kernels.h): {} = the default, ONE launch of 1024-lane workgroups up to 2^23 coefficients
+    (round 6, lindiv_one_kernel: 4 coefficients per lane below 1.5 M coefficients, 8 above -- RONK_LINDIV_ONE_PL forces one of them at
+    every size; RONK_LINDIV_ONE_MAXCH=512: only while every chunk is resident; RONK_LB_TEST_FLAGS=1: its recompute path) and two
+    launches beyond / in place / unaligned / for z = 0; RONK_LINDIV_ONE=0 two launches everywhere, with 16-byte reads of the lanes' runs
+    or with the
     LDS image both ways ("l"; what unaligned dividends get anyway), "0" = the scan_kernels.h division: each in its own
     process, since the library reads its knobs once"""
     import subprocess, sys
