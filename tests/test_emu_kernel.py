@@ -19,9 +19,18 @@ def emu():
                                                                                   "field_policy.h", "mont64.h", "ntt_tile_wl.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
-        subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", EXE, srcs[0], obj])
+        _build(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")], obj)
+        _build(["g++", "-O2", "-std=c++17", "-o", EXE, srcs[0], obj], EXE)
     return EXE
+
+
+
+def _build(cmd_prefix, out):
+    """compile to a private name, then rename: several pytest-xdist workers may decide to rebuild the same emulator at once, and a
+    binary that is being written cannot be executed ("text file busy")"""
+    tmp = "%s.tmp.%d" % (out, os.getpid())
+    subprocess.check_call(cmd_prefix[:cmd_prefix.index("-o") + 1] + [tmp] + cmd_prefix[cmd_prefix.index("-o") + 2:])
+    os.replace(tmp, out)
 
 
 def run(emu, *args, env=None):
@@ -339,8 +348,8 @@ def emu_scan():
     deps = [src] + [os.path.join(ROOT, "ronkathon_amd", "csrc", f) for f in ("lindiv_kernels.h", "gl64.h")]
     if not os.path.exists(SCAN_EXE) or any(os.path.getmtime(d) > os.path.getmtime(SCAN_EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu.o")
-        subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SCAN_EXE, src, obj])
+        _build(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")], obj)
+        _build(["g++", "-O2", "-std=c++17", "-o", SCAN_EXE, src, obj], SCAN_EXE)
     return SCAN_EXE
 
 
@@ -398,8 +407,8 @@ def emu_longdiv():
            [os.path.join(ROOT, "oracle", "ronk_oracle.c")]
     if not os.path.exists(LONGDIV_EXE) or any(os.path.getmtime(d) > os.path.getmtime(LONGDIV_EXE) for d in deps):
         obj = os.path.join(ROOT, "build", "orc_emu_longdiv.o")
-        subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", LONGDIV_EXE, src, obj])
+        _build(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "ronk_oracle.c")], obj)
+        _build(["g++", "-O2", "-std=c++17", "-o", LONGDIV_EXE, src, obj], LONGDIV_EXE)
     return LONGDIV_EXE
 
 
