@@ -61,7 +61,7 @@ def main():
                 assert np.array_equal(q2, orc.vec_mul(p, q, np.full(d, orc.inverse(p, b1), dtype=np.uint64))), (p, d, "scaled, unaligned, in place")
                 assert int(dr.cpu().numpy().view(np.uint64)[0]) == val
                 assert not db.cpu().numpy()[off + d:].any() and (off == 0 or int(db[0]) == 0), "wrote outside the operand"
-                # the same divisor, aligned and out of place (the one-launch form up to 2^22 coefficients), twice in a row on the
+                # the same divisor, aligned and out of place (the one-launch form up to 2^23 coefficients), twice in a row on the
                 # same stream (the two look-back arrays alternate)
                 for _ in range(2):
                     dq.fill_(-1)
