@@ -45,13 +45,12 @@ sanitize:
 	RONK_EMU_P=0xc0000001 RONK_EMU_G=5 ./build/san/emu_tile 12 3 0 4 | tail -1
 	RONK_R4MID=1 ./build/san/emu_tile 19 1 0 4 18 | tail -1
 	./build/san/emu_tile 20 1 1 2 20 | tail -1
-	./build/san/emu_tile 21 1 0 2 18 | tail -1
 	RONK_WL_HALF=1 ./build/san/emu_tile 22 1 0 2 22 | tail -1
 	RONK_EMU_P=0xFFFFFFFC00000001 RONK_EMU_G=10 ./build/san/emu_tile 20 1 0 2 18 | tail -1
 	./build/san/emu_scan 18446744069414584321 70001 123456789 3 1 | tail -1
 	./build/san/emu_scan 101 5000 7 3 0 | tail -1
 	./build/san/emu_scan 18446744069414584321 70001 123456789 3 3 | tail -1
-	./build/san/emu_scan 18446744069414584321 30001 123456789 1 6 | tail -1
+	EMU_LINDIV1_PL=4 ./build/san/emu_scan 18446744069414584321 30001 123456789 1 6 | tail -1
 	./build/san/emu_scan 101 25000 7 3 2 | tail -1
 	./build/san/emu_longdiv 18446744069414584321 120 300 64 3 | tail -1
 	./build/san/emu_longdiv 101 120 300 64 3 | tail -1
